@@ -1,0 +1,134 @@
+"""Seeded synthetic scenes and cameras for tests and bench.py.
+
+The camera helpers restate the reference's matrix conventions so that the kernels see exactly
+what GScream's `Camera` hands to the rasterizer:
+
+* `projection_matrix`  -- utils/graphics_utils.py:51-74 getProjectionMatrix (principal point in
+  P[0,2], P[1,2]; P[2,2] = (zn+zf)/(zf-zn)),
+* `camera_matrices`    -- scene/cameras.py:64-69: world_view_transform = W2C^T,
+  full_proj_transform = W2C^T @ P^T (row-vector convention).
+
+The scene distributions are the ones SURVEY.md section 8(d) pins for BASELINE.json's configs
+(config 1: 2k Gaussians @128x128; configs 2-4: the 1008x567 / 1920x1080 slab generator).
+Everything is numpy + an explicit seed; nothing here touches the GPU.
+"""
+import math
+
+import numpy as np
+
+
+def projection_matrix(znear, zfar, tanfovx, tanfovy, cx=0.0, cy=0.0):
+    P = np.zeros((4, 4), np.float32)
+    top, right = tanfovy * znear, tanfovx * znear
+    P[0, 0] = 2.0 * znear / (2.0 * right)
+    P[1, 1] = 2.0 * znear / (2.0 * top)
+    P[0, 2] = cx
+    P[1, 2] = cy
+    P[3, 2] = 1.0
+    P[2, 2] = (znear + zfar) / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def camera_matrices(tanfovx, tanfovy, w2c=None, cx=0.0, cy=0.0, znear=0.01, zfar=100.0):
+    """Returns (viewmatrix, projmatrix, campos) in the transposed form the rasterizer expects."""
+    w2c = np.eye(4, dtype=np.float32) if w2c is None else np.asarray(w2c, np.float32)
+    view = np.ascontiguousarray(w2c.T)
+    proj = np.ascontiguousarray((view @ projection_matrix(znear, zfar, tanfovx, tanfovy, cx, cy).T).astype(np.float32))
+    campos = np.linalg.inv(view)[3, :3].astype(np.float32)
+    return view, proj, np.ascontiguousarray(campos)
+
+
+def random_w2c(rng, max_angle=0.35, max_shift=0.4):
+    """A small random rigid transform (exercises every entry of the view matrix)."""
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    ang = rng.uniform(-max_angle, max_angle)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rm = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+    M = np.eye(4)
+    M[:3, :3] = Rm
+    M[:3, 3] = rng.uniform(-max_shift, max_shift, size=3)
+    return M.astype(np.float32)
+
+
+def _quats(rng, P):
+    q = rng.uniform(-0.5, 0.5, size=(P, 4))
+    q /= np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-8)
+    return q.astype(np.float32)
+
+
+def scene_config1(seed=0, P=2000, W=128, H=128, lateral=0.55, w2c=None, cx=0.0, cy=0.0, bg=(0.1, 0.2, 0.3),
+                  tanfovx=0.5, tanfovy=None):
+    """SURVEY 8(d) config 1 distribution (oracle / plumbing case)."""
+    rng = np.random.default_rng(seed)
+    tanfovy = tanfovx * H / W if tanfovy is None else tanfovy
+    z = rng.uniform(2.0, 6.0, size=P)
+    x = rng.uniform(-lateral, lateral, size=P) * z
+    y = rng.uniform(-lateral, lateral, size=P) * z
+    cam = np.stack([x, y, z], 1)
+    view, proj, campos = camera_matrices(tanfovx, tanfovy, w2c, cx, cy)
+    if w2c is not None:  # place the cloud in front of the moved camera
+        c2w = np.linalg.inv(np.asarray(w2c, np.float64))
+        cam = cam @ c2w[:3, :3].T + c2w[:3, 3]
+    return dict(
+        means3D=cam.astype(np.float32),
+        scales=rng.uniform(0.02, 0.17, size=(P, 3)).astype(np.float32),
+        rotations=_quats(rng, P),
+        opacities=rng.uniform(0.05, 0.95, size=(P, 1)).astype(np.float32),
+        uncertainties=rng.uniform(0, 1, size=(P, 1)).astype(np.float32),
+        colors=rng.uniform(0, 1, size=(P, 3)).astype(np.float32),
+        W=W, H=H, tanfovx=float(tanfovx), tanfovy=float(tanfovy), viewmatrix=view, projmatrix=proj, campos=campos,
+        bg=np.asarray(bg, np.float32), scale_modifier=1.0)
+
+
+def scene_slab(seed, P, W, H, tanfovx=0.6, bg=(0.0, 0.0, 0.0), scale_mu=0.01, scale_sigma=0.6):
+    """the synthetic stand-in for a SPIn-NeRF scene.  Slab z~U(1.5,8),
+    15% lateral overshoot (culling, edge tiles, a few +-1.3*tan clamps), log-normal scales,
+    opacity U(0,1)^2."""
+    rng = np.random.default_rng(seed)
+    tanfovy = tanfovx * H / W
+    z = rng.uniform(1.5, 8.0, size=P)
+    x = rng.uniform(-1.15, 1.15, size=P) * tanfovx * z
+    y = rng.uniform(-1.15, 1.15, size=P) * tanfovy * z
+    view, proj, campos = camera_matrices(tanfovx, tanfovy)
+    return dict(
+        means3D=np.stack([x, y, z], 1).astype(np.float32),
+        scales=np.exp(rng.normal(math.log(scale_mu), scale_sigma, size=(P, 3))).astype(np.float32),
+        rotations=_quats(rng, P),
+        opacities=(rng.uniform(0, 1, size=(P, 1)) ** 2).astype(np.float32),
+        uncertainties=rng.uniform(0, 1, size=(P, 1)).astype(np.float32),
+        colors=rng.uniform(0, 1, size=(P, 3)).astype(np.float32),
+        W=W, H=H, tanfovx=float(tanfovx), tanfovy=float(tanfovy), viewmatrix=view, projmatrix=proj, campos=campos,
+        bg=np.asarray(bg, np.float32), scale_modifier=1.0)
+
+
+def scene_stack(seed=5, P=1500, n_stack=700, W=112, H=71):
+    """SURVEY 8(c) fixture 5: many Gaussians stacked on the centre pixel (multi-batch tile lists,
+    T < 1e-4 early stop) on a non-multiple-of-16 image."""
+    s = scene_config1(seed=seed, P=P, W=W, H=H)
+    rng = np.random.default_rng(seed + 1000)
+    z = rng.uniform(2.0, 6.0, size=n_stack)
+    s["means3D"][:n_stack, 0] = (rng.normal(0, 0.002, size=n_stack) * z).astype(np.float32)
+    s["means3D"][:n_stack, 1] = (rng.normal(0, 0.002, size=n_stack) * z).astype(np.float32)
+    s["means3D"][:n_stack, 2] = z.astype(np.float32)
+    return s
+
+
+def scene_ties(seed=6, P=600, W=64, H=48):
+    """SURVEY 8(c) fixture 6: duplicated depths -> tie order must be ascending Gaussian index."""
+    s = scene_config1(seed=seed, P=P, W=W, H=H)
+    levels = np.asarray([2.5, 3.0, 3.5, 4.0], np.float32)
+    rng = np.random.default_rng(seed + 7)
+    s["means3D"][:, 2] = levels[rng.integers(0, len(levels), size=P)]
+    return s
+
+
+def upstream_grads(seed, W, H, color=True, depth=True, unc=True):
+    """Random upstream gradients dL/d{color, depth, uncertainty} (N(0,1)/N)."""
+    rng = np.random.default_rng(seed)
+    n = W * H
+    gc = rng.normal(size=(3, H, W)).astype(np.float32) / n if color else np.zeros((3, H, W), np.float32)
+    gd = rng.normal(size=(1, H, W)).astype(np.float32) / n if depth else np.zeros((1, H, W), np.float32)
+    gu = rng.normal(size=(1, H, W)).astype(np.float32) / n if unc else np.zeros((1, H, W), np.float32)
+    return gc, gd, gu
