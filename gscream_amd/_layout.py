@@ -1,0 +1,51 @@
+"""Python mirror of the workspace layout in csrc/gsr_common.h (debugging / tests only):
+decodes the opaque geom / image / binning byte tensors the forward returns."""
+import torch
+
+
+def _align(x):
+    return (x + 255) & ~255
+
+
+def num_chunks(P):
+    return max(1, min(256, (P + 2047) // 2048))
+
+
+def _take(buf, off, nbytes, dtype, shape):
+    return buf[off:off + nbytes].view(dtype).reshape(shape)
+
+
+def geom_views(buf, P):
+    p = max(P, 1)
+    off = 0
+    out = {}
+    out["rec_f32"] = _take(buf, off, p * 64, torch.float32, (p, 16)); out["rec_i32"] = _take(buf, off, p * 64, torch.int32, (p, 16)); off += _align(p * 64)
+    out["rect"] = _take(buf, off, p * 8, torch.int32, (p, 2)); off += _align(p * 8)
+    out["depthkey"] = _take(buf, off, p * 4, torch.int32, (p,)); off += _align(p * 4)
+    out["tiles"] = _take(buf, off, p * 4, torch.int32, (p,)); off += _align(p * 4)
+    out["offsets"] = _take(buf, off, p * 4, torch.int32, (p,)); off += _align(p * 4)
+    return {k: v[:P] for k, v in out.items()}
+
+
+def image_views(buf, P, W, H):
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T, N = max(gx * gy, 1), max(W * H, 1)
+    off = 0
+    out = {}
+    out["ranges"] = _take(buf, off, T * 8, torch.int32, (T, 2)); off += _align(T * 8)
+    out["final_T"] = _take(buf, off, N * 4, torch.float32, (H, W)); off += _align(N * 4)
+    out["n_contrib"] = _take(buf, off, N * 4, torch.int32, (H, W)); off += _align(N * 4)
+    nb = num_chunks(P)
+    out["table"] = _take(buf, off, nb * T * 4, torch.int32, (nb, T)); off += _align(nb * T * 4)
+    out["tile_count"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
+    out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
+    return out
+
+
+def binning_views(buf, R):
+    r = max(R, 1)
+    off = 0
+    out = {}
+    out["seg_keys"] = _take(buf, off, r * 8, torch.int64, (r,))[:R]; off += _align(r * 8)
+    out["point_list"] = _take(buf, off, r * 4, torch.int32, (r,))[:R]; off += _align(r * 4)
+    return out

@@ -1,0 +1,105 @@
+"""ctypes binding of libgsraster.so (the C ABI declared in include/gsraster.h).
+
+This is the only place that touches the native library.  There is NO fallback: if the HIP
+library is missing or a call fails, a RuntimeError is raised -- the product path never routes
+through the CPU oracle or through eager PyTorch.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsraster.so")
+
+#: every symbol include/gsraster.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = (
+    "gsr_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
+    "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2",
+    "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
+)
+NUM_STAGES = 7
+
+
+class Stage1Result(ctypes.Structure):
+    _fields_ = [("num_rendered", ctypes.c_int32), ("max_tile_count", ctypes.c_int32)]
+
+
+class Tuning(ctypes.Structure):
+    _fields_ = [("pixels_per_thread_fwd", ctypes.c_int32), ("pixels_per_thread_bwd", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 6)]
+
+
+class Profile(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_double * NUM_STAGES), ("launches", ctypes.c_int64 * NUM_STAGES)]
+
+
+_lib = None
+_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+def load():
+    """Load libgsraster.so once.  Raises RuntimeError (never falls back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"gscream_amd: native library {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gscream_amd/csrc`. "
+            "There is no CPU fallback for the rasterizer.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.gsr_version.restype = ctypes.c_char_p
+    lib.gsr_last_error.restype = ctypes.c_char_p
+    lib.gsr_device_count.restype = _c_int
+    for name in ("gsr_geom_bytes", "gsr_binning_bytes"):
+        getattr(lib, name).restype = ctypes.c_size_t
+        getattr(lib, name).argtypes = [_c_int]
+    lib.gsr_image_bytes.restype = ctypes.c_size_t
+    lib.gsr_image_bytes.argtypes = [_c_int, _c_int, _c_int]
+    lib.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
+    lib.gsr_backward_scratch_bytes.argtypes = [_c_int, _c_int]
+    lib.gsr_forward_stage1.restype = _c_int
+    lib.gsr_forward_stage1.argtypes = (
+        [_c_int] * 5 + [_vp, _vp, _c_float, _vp] + [_vp] * 5 + [_vp, _vp, _vp, _c_float, _c_float, _c_int]
+        + [_vp, _vp, _vp, ctypes.POINTER(Stage1Result), _c_int, _vp])
+    lib.gsr_forward_stage2.restype = _c_int
+    lib.gsr_forward_stage2.argtypes = [_c_int] * 5 + [_vp] * 7 + [ctypes.POINTER(Tuning), _c_int, _vp]
+    lib.gsr_backward.restype = _c_int
+    lib.gsr_backward.argtypes = (
+        [_c_int] * 6 + [_vp] * 6 + [_c_float] + [_vp] * 5 + [_c_float, _c_float] + [_vp] * 3 + [_vp] * 4
+        + [_vp] * 9 + [ctypes.POINTER(Tuning), _c_int, _vp])
+    lib.gsr_filter.restype = _c_int
+    lib.gsr_filter.argtypes = [_c_int] * 3 + [_vp, _vp, _c_float] + [_vp] * 4 + [_c_float, _c_float, _c_int] + [_vp] * 3 + [_c_int, _vp]
+    lib.gsr_mark_visible.restype = _c_int
+    lib.gsr_mark_visible.argtypes = [_c_int] + [_vp] * 5
+    lib.gsr_profile_begin.restype = _c_int
+    lib.gsr_profile_end.restype = _c_int
+    lib.gsr_profile_end.argtypes = [ctypes.POINTER(Profile)]
+    lib.gsr_stage_name.restype = ctypes.c_char_p
+    lib.gsr_stage_name.argtypes = [_c_int]
+    _lib = lib
+    return lib
+
+
+def profile_begin():
+    check(load().gsr_profile_begin(), "gsr_profile_begin")
+
+
+def profile_end():
+    """-> {stage name: (total ms, launches)} measured with HIP events on the launch stream."""
+    lib = load()
+    p = Profile()
+    check(lib.gsr_profile_end(ctypes.byref(p)), "gsr_profile_end")
+    return {lib.gsr_stage_name(i).decode(): (float(p.total_ms[i]), int(p.launches[i])) for i in range(NUM_STAGES)}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gsr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"gscream_amd native call {what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors (the reference's 'not provided')."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())

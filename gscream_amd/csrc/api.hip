@@ -1,0 +1,300 @@
+// api.hip -- the extern "C" surface declared in include/gsraster.h (host code only).
+//
+// Each entry validates its arguments, carves the caller-allocated workspaces, enqueues the stage
+// kernels on the caller's stream and reports failures as an int code + thread-local message.
+// Orchestration replaces CudaRasterizer::Rasterizer::{forward,backward,visible_filter,
+// position2D_filter,markVisible} (DGR rasterizer_impl.cu:141-153,199-347,350-530,536-643).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "gsr_common.h"
+
+static thread_local char g_err[512] = "";
+
+static int gsr_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define GSR_HIP(expr, what)                                                                                     \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return gsr_fail(GSR_ERR_HIP, "%s: %s (%s)", what, hipGetErrorString(e_), #expr); \
+    } while (0)
+
+// ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling only) ----
+#include <mutex>
+#include <vector>
+static const char* const g_stage_names[GSR_NUM_STAGES] = { "preprocess", "count_scan", "scatter", "tile_sort",
+                                                           "blend_forward", "blend_backward", "gauss_backward" };
+struct GsrProfRec { int stage; hipEvent_t t0, t1; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<GsrProfRec> g_prof;
+
+struct GsrStageTimer {
+    bool on = false;
+    GsrProfRec rec{};
+    hipStream_t stream;
+    GsrStageTimer(int stage, hipStream_t s) : stream(s)
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_on) return;
+        if (hipEventCreate(&rec.t0) != hipSuccess || hipEventCreate(&rec.t1) != hipSuccess) return;
+        rec.stage = stage;
+        on = hipEventRecord(rec.t0, stream) == hipSuccess;
+    }
+    ~GsrStageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(rec.t1, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+};
+
+// debug semantics of the reference's CHECK_CUDA (auxiliary.h:166-173): sync + check after a stage
+#define GSR_STAGE(stage_id, expr, what)                              \
+    do {                                                             \
+        {                                                            \
+            GsrStageTimer timer_(stage_id, stream);                  \
+            GSR_HIP(expr, what);                                     \
+        }                                                            \
+        if (debug) GSR_HIP(hipStreamSynchronize(stream), what);      \
+    } while (0)
+
+extern "C" const char* gsr_stage_name(int stage)
+{
+    return (stage >= 0 && stage < GSR_NUM_STAGES) ? g_stage_names[stage] : "";
+}
+
+extern "C" int gsr_profile_begin(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return GSR_OK;
+}
+
+extern "C" int gsr_profile_end(gsr_profile* out_host)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    if (!out_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "out_host is NULL");
+    memset(out_host, 0, sizeof(*out_host));
+    int rc = GSR_OK;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.t1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.t0, r.t1);
+        if (e != hipSuccess) rc = gsr_fail(GSR_ERR_HIP, "profile: %s", hipGetErrorString(e));
+        else { out_host->total_ms[r.stage] += ms; out_host->launches[r.stage] += 1; }
+        (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1);
+    }
+    g_prof.clear();
+    return rc;
+}
+
+extern "C" const char* gsr_version(void) { return "gsraster 0.1 (gfx950)"; }
+extern "C" const char* gsr_last_error(void) { return g_err; }
+
+extern "C" int gsr_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return gsr_fail(GSR_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" size_t gsr_geom_bytes(int P) { return gsr_carve_geom(nullptr, P).bytes; }
+extern "C" size_t gsr_image_bytes(int P, int W, int H) { return gsr_carve_image(nullptr, P, W, H).bytes; }
+extern "C" size_t gsr_binning_bytes(int R) { return gsr_carve_binning(nullptr, R).bytes; }
+extern "C" size_t gsr_backward_scratch_bytes(int P, int R)
+{
+    (void)P;
+    return gsr_align((size_t)(R > 0 ? R : 1) * GSR_SLOT_FLOATS * sizeof(float));
+}
+
+static int gsr_make_cam(GsrCam& cam, int W, int H, const float* view_d, const float* proj_d, const float* campos_d,
+                        float tan_fovx, float tan_fovy, float scale_modifier, hipStream_t stream)
+{
+    (void)stream;
+    cam.view = view_d; cam.proj = proj_d; cam.campos = campos_d;
+    cam.tan_fovx = tan_fovx; cam.tan_fovy = tan_fovy;
+    cam.focal_y = H / (2.0f * tan_fovy);  // DGR rasterizer_impl.cu:226-227
+    cam.focal_x = W / (2.0f * tan_fovx);
+    cam.scale_modifier = scale_modifier;
+    cam.W = W; cam.H = H;
+    cam.gx = (W + GSR_TILE - 1) / GSR_TILE; cam.gy = (H + GSR_TILE - 1) / GSR_TILE;
+    return GSR_OK;
+}
+
+static int gsr_check_dims(int P, int W, int H)
+{
+    if (P < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "P must be >= 0 (got %d)", P);
+    if (W <= 0 || H <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "image size must be positive (got %dx%d)", W, H);
+    const long gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    if (gx > 65535 || gy > 65535) return gsr_fail(GSR_ERR_UNSUPPORTED, "image too large: %ldx%ld tiles", gx, gy);
+    if (gx * gy > GSR_MAX_TILES_LDS)
+        return gsr_fail(GSR_ERR_UNSUPPORTED, "%ld tiles exceed the LDS histogram capacity of %d", gx * gy, GSR_MAX_TILES_LDS);
+    return GSR_OK;
+}
+
+extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float* means3D, const float* scales,
+                                  float scale_modifier, const float* rotations, const float* opacities,
+                                  const float* features, const float* shs, const float* cov3D_precomp,
+                                  const float* colors_precomp, const float* viewmatrix, const float* projmatrix,
+                                  const float* campos, float tan_fovx, float tan_fovy, int prefiltered, void* geom_ws,
+                                  void* image_ws, int32_t* radii, gsr_stage1_result* result_host, int debug,
+                                  void* stream_)
+{
+    (void)prefiltered;  // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = gsr_check_dims(P, W, H);
+    if (rc) return rc;
+    if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
+    result_host->num_rendered = 0;
+    result_host->max_tile_count = 0;
+    if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:85
+    if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    if ((!scales || !rotations) == (cov3D_precomp == nullptr))  // DGR __init__.py:227-228
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations or cov3D_precomp");
+    if ((shs == nullptr) == (colors_precomp == nullptr))  // DGR __init__.py:224-225
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of shs or colors_precomp");
+    if (shs && (!campos || M <= 0)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "SH colours need campos and M > 0");
+
+    GsrCam cam;
+    rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, stream);
+    if (rc) return rc;
+    const GsrGeom geom = gsr_carve_geom(geom_ws, P);
+    const GsrImage image = gsr_carve_image(image_ws, P, W, H);
+    const int T = cam.gx * cam.gy;
+
+    GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(0, P, D, M, cam, means3D, scales, rotations, opacities, features, shs,
+                                    cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr, stream),
+              "preprocess");
+    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, stream), "tile count / scans");
+    uint32_t info[2] = { 0, 0 };
+    GSR_HIP(hipMemcpyAsync(info, image.info, sizeof(info), hipMemcpyDeviceToHost, stream), "read num_rendered");
+    GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
+    if (info[0] > 0x7fffffffu) return gsr_fail(GSR_ERR_UNSUPPORTED, "num_rendered %u overflows int32", info[0]);
+    result_host->num_rendered = (int32_t)info[0];
+    result_host->max_tile_count = (int32_t)info[1];
+    return GSR_OK;
+}
+
+static int gsr_pick_ppt(const gsr_tuning* t, int which, int dflt)
+{
+    int v = t ? (which ? t->pixels_per_thread_bwd : t->pixels_per_thread_fwd) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : dflt;
+}
+
+extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const float* background,
+                                  void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
+                                  float* out_feature, const gsr_tuning* tuning, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = gsr_check_dims(P, W, H);
+    if (rc) return rc;
+    if (P == 0) return GSR_OK;  // outputs keep the caller's zero fill, like DGR rasterize_points.cu:69-85
+    if (!background || !geom_ws || !image_ws || !binning_ws || !out_color || !out_depth || !out_feature)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
+    const GsrGeom geom = gsr_carve_geom(geom_ws, P);
+    const GsrImage image = gsr_carve_image(image_ws, P, W, H);
+    const GsrBinning bin = gsr_carve_binning(binning_ws, R);
+    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, stream), "scatter");
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, R, max_tile_count, image, bin, stream), "tile sort");
+    GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth, out_feature,
+                                       gsr_pick_ppt(tuning, 0, 2), stream),
+              "forward blend");
+    return GSR_OK;
+}
+
+extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const float* background, const float* means3D,
+                            const int32_t* radii, const float* colors_precomp, const float* shs, const float* scales,
+                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                            const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                            float tan_fovy, const float* dL_dout_color, const float* dL_dout_depth,
+                            const float* dL_dout_feature, const void* geom_ws, const void* image_ws,
+                            const void* binning_ws, void* scratch, float* dL_dmeans2D, float* dL_dcolors,
+                            float* dL_dopacity, float* dL_dfeatures, float* dL_dmeans3D, float* dL_dcov3D,
+                            float* dL_dsh, float* dL_dscales, float* dL_drotations, const gsr_tuning* tuning, int debug,
+                            void* stream_)
+{
+    (void)colors_precomp;  // colours live in the geometry records written by the forward
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = gsr_check_dims(P, W, H);
+    if (rc) return rc;
+    if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:172
+    if (!background || !means3D || !radii || !viewmatrix || !projmatrix || !dL_dout_color || !dL_dout_depth ||
+        !dL_dout_feature || !geom_ws || !image_ws || !binning_ws || !scratch || !dL_dmeans2D || !dL_dcolors ||
+        !dL_dopacity || !dL_dfeatures || !dL_dmeans3D)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    if ((!scales || !rotations) == (cov3D_precomp == nullptr))
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations or cov3D_precomp");
+    if (!cov3D_precomp && (!dL_dscales || !dL_drotations))
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "dL_dscales / dL_drotations are required with scales+rotations");
+    if (shs && (!dL_dsh || !campos || M <= 0))
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "SH colours need dL_dsh, campos and M > 0");
+    if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
+
+    GsrCam cam;
+    rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, stream);
+    if (rc) return rc;
+    const int T = cam.gx * cam.gy;
+    const GsrGeom geom = gsr_carve_geom(const_cast<void*>(geom_ws), P);
+    const GsrImage image = gsr_carve_image(const_cast<void*>(image_ws), P, W, H);
+    const GsrBinning bin = gsr_carve_binning(const_cast<void*>(binning_ws), R);
+    float* slots = (float*)scratch;
+    if (R > 0)
+        GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
+                                            dL_dout_feature, slots, gsr_pick_ppt(tuning, 1, 2), stream),
+                  "backward blend");
+    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots,
+                                        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures, dL_dmeans3D, dL_dcov3D,
+                                        dL_dsh, dL_dscales, dL_drotations, stream),
+              "per-Gaussian backward");
+    return GSR_OK;
+}
+
+extern "C" int gsr_filter(int P, int W, int H, const float* means3D, const float* scales, float scale_modifier,
+                          const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                          const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered, int32_t* radii,
+                          float* px, float* py, int debug, void* stream_)
+{
+    (void)prefiltered;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || W <= 0 || H <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad sizes P=%d W=%d H=%d", P, W, H);
+    if (P == 0) return GSR_OK;
+    if (!means3D || !viewmatrix || !projmatrix || !radii) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    if ((!scales || !rotations) == (cov3D_precomp == nullptr))
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations or cov3D_precomp");
+    if ((px == nullptr) != (py == nullptr)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "px and py go together");
+    GsrCam cam;
+    int rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, nullptr, tan_fovx, tan_fovy, scale_modifier, stream);
+    if (rc) return rc;
+    GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(px ? 2 : 1, P, 0, 0, cam, means3D, scales, rotations, nullptr, nullptr, nullptr,
+                                    cov3D_precomp, nullptr, nullptr, radii, px, py, stream),
+              "filter preprocess");
+    return GSR_OK;
+}
+
+extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                uint8_t* present, void* stream_)
+{
+    (void)projmatrix;  // unused by the reference's test as well (auxiliary.h:154 checks view-space z only)
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "P must be >= 0");
+    if (P == 0) return GSR_OK;
+    if (!means3D || !viewmatrix || !present) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    GSR_HIP(gsr_launch_mark_visible(P, means3D, viewmatrix, present, stream), "mark_visible");
+    return GSR_OK;
+}

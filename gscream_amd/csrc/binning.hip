@@ -1,0 +1,331 @@
+// binning.hip -- Gaussian -> tile binning and the per-tile depth sort.
+//
+// Replaces, in DGR rasterizer_impl.cu: cub::DeviceScan::InclusiveSum (:283), duplicateWithKeys
+// (:70-111), the 44/45-bit global cub::DeviceRadixSort::SortPairs (:306-314) and identifyTileRanges
+// (:116-138).  The reference sorts all R instances globally by (tile | depth): 6 radix passes over
+// 12-byte pairs.  Here the tile part of the key is handled by ONE counting pass (a T-bin histogram
+// per chunk of Gaussians, kept in LDS), which yields each tile's segment directly (= `ranges`), and
+// the depth part by an independent LDS sort per tile.  Order inside a tile is (depth bits, Gaussian
+// id) ascending: identical to the reference's stable sort, whose ties are broken by emission order
+// = ascending id (SURVEY A-9).  Keys are unique, so the result does not depend on the order in
+// which the scatter claims slots.
+//
+// HBM traffic: hist reads rect (8 B/G); table NB*T*4 B written, scanned, read; scatter reads
+// 16 B/G and writes 8 B/instance + 16 B/G (record tail); sort reads 8 B and writes 4 B per instance.
+#include "gsr_common.h"
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------------------
+// Exclusive prefix scan of tiles[P] -> offsets[P]   (three small kernels, 2048 elements / block)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gsr_block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds /*[8]*/)
+{
+    // wave-level inclusive scan with DPP-free shuffles (4 waves of 64), then across waves in LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t s = lds[w];
+        if (w < wave) base += s;
+    }
+    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(256) gsr_scan_reduce_kernel(int P, const uint32_t* __restrict__ in,
+                                                              uint32_t* __restrict__ sums)
+{
+    __shared__ uint32_t lds[8];
+    const int base = blockIdx.x * GSR_SCAN_ITEMS + threadIdx.x * 8;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += (base + i < P) ? in[base + i] : 0u;
+    uint32_t total;
+    gsr_block_exclusive_scan_256(s, &total, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the block sums in place; sums[nblocks] = grand total
+__global__ void __launch_bounds__(256) gsr_scan_sums_kernel(int nblocks, uint32_t* __restrict__ sums)
+{
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = gsr_block_exclusive_scan_256(v, &total, lds);
+        if (i < nblocks) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[nblocks] = carry;
+}
+
+__global__ void __launch_bounds__(256) gsr_scan_apply_kernel(int P, const uint32_t* __restrict__ in,
+                                                             const uint32_t* __restrict__ sums,
+                                                             uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t lds[8];
+    const int base = blockIdx.x * GSR_SCAN_ITEMS + threadIdx.x * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { v[i] = (base + i < P) ? in[base + i] : 0u; s += v[i]; }
+    uint32_t run = sums[blockIdx.x] + gsr_block_exclusive_scan_256(s, nullptr, lds);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (base + i < P) out[base + i] = run;
+        run += v[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile histogram per chunk of Gaussians  (one counting-sort pass on the tile id, in LDS)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gsr_chunk_bounds(int P, int nchunks, int chunk, int& lo, int& hi)
+{
+    const int per = (P + nchunks - 1) / nchunks;
+    lo = chunk * per;
+    hi = min(P, lo + per);
+}
+
+__global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, int T, int gx, int nchunks,
+                                                                        const uint2* __restrict__ rect,
+                                                                        uint32_t* __restrict__ table)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    int lo, hi;
+    gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
+    for (int g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const uint2 rc = rect[g];
+        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&hist[y * gx + x], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) row[t] = hist[t];
+}
+
+// Column pass over table[nchunks][T]: for every tile, exclusive prefix over chunks (in place) and the
+// tile total.  Block = 64 tiles x 4 chunk groups.
+__global__ void __launch_bounds__(256) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
+                                                                uint32_t* __restrict__ tile_count)
+{
+    __shared__ uint32_t part[4][64];
+    const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 64 + tl;
+    const int per = (nchunks + 3) / 4;
+    const int c0 = grp * per, c1 = min(nchunks, c0 + per);
+    uint32_t s = 0;
+    if (tile < T)
+        for (int c = c0; c < c1; c++) s += table[(size_t)c * T + tile];
+    part[grp][tl] = s;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int g2 = 0; g2 < grp; g2++) run += part[g2][tl];
+    if (tile < T) {
+        for (int c = c0; c < c1; c++) {
+            const uint32_t v = table[(size_t)c * T + tile];
+            table[(size_t)c * T + tile] = run;
+            run += v;
+        }
+        if (grp == 3) tile_count[tile] = part[0][tl] + part[1][tl] + part[2][tl] + part[3][tl];
+    }
+}
+
+// Single block: exclusive scan of the tile totals -> ranges[t] = [start, end); info = {R, max count}.
+__global__ void __launch_bounds__(256) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
+                                                            uint2* __restrict__ ranges, uint32_t* __restrict__ info)
+{
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t smax[4];
+    uint32_t carry = 0, mx = 0;
+    for (int base = 0; base < T; base += 256) {
+        const int t = base + threadIdx.x;
+        const uint32_t v = t < T ? tile_count[t] : 0u;
+        mx = max(mx, v);
+        uint32_t total;
+        const uint32_t ex = gsr_block_exclusive_scan_256(v, &total, lds);
+        if (t < T) ranges[t] = make_uint2(carry + ex, carry + ex + v);
+        carry += total;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[0] = carry;
+        info[1] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scatter: every Gaussian writes (depth bits << 32 | id) into the segment of each tile of its
+// rectangle (slot claimed with an LDS atomic on the chunk's cursor row), and completes its record.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
+    int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const uint32_t* __restrict__ depthkey,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ table,
+    const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, u64* __restrict__ seg_keys)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
+    const uint32_t* row = table + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) cursor[t] = ranges[t].x + row[t];
+    __syncthreads();
+    int lo, hi;
+    gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
+    for (int g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const uint2 rc = rect[g];
+        const uint32_t nt = tiles[g];
+        rec[g].d = make_uint4(offsets[g], rc.x, rc.y, nt);
+        if (nt == 0) continue;
+        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+        const u64 key = ((u64)depthkey[g] << 32) | (uint32_t)g;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
+                seg_keys[slot] = key;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-tile sort.  Bitonic network in the "flip" formulation: every compare-exchange moves the
+// smaller key to the lower index, so indices >= n behave as +infinity padding and are simply
+// skipped -- no padding writes, any n.
+// ---------------------------------------------------------------------------------------------
+template <typename KeyPtr>
+__device__ __forceinline__ void gsr_bitonic(KeyPtr k, const uint32_t n, const int nthreads)
+{
+    uint32_t lm = 0;  // log2 of the padded length m
+    while ((1u << lm) < n) lm++;
+    const uint32_t npairs = (1u << lm) >> 1;
+    for (uint32_t ls = 1; ls <= lm; ls++) {  // merge blocks of size 2^ls
+        const uint32_t lh = ls - 1, half = 1u << lh;
+        for (uint32_t t = threadIdx.x; t < npairs; t += nthreads) {
+            const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
+            const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;  // "flip": i <-> mirror
+            if (j < n) {
+                const u64 a = k[i], b = k[j];
+                if (a > b) { k[i] = b; k[j] = a; }
+            }
+        }
+        __syncthreads();
+        for (int lst = (int)lh - 1; lst >= 0; lst--) {  // half-cleaners, stride 2^lst
+            const uint32_t stride = 1u << lst;
+            for (uint32_t t = threadIdx.x; t < npairs; t += nthreads) {
+                const uint32_t i = ((t >> lst) << (lst + 1)) + (t & (stride - 1)), j = i + stride;
+                if (j < n) {
+                    const u64 a = k[i], b = k[j];
+                    if (a > b) { k[i] = b; k[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// LDS variant for lo < n <= hi (dynamic LDS = 8 * hi bytes).
+__global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
+                                                                const u64* __restrict__ seg_keys,
+                                                                uint32_t* __restrict__ point_list, uint32_t lo,
+                                                                uint32_t hi)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 keys[];
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= lo || n > hi) return;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) keys[i] = seg_keys[rg.x + i];
+    __syncthreads();
+    gsr_bitonic(keys, n, 256);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
+}
+
+// Global-memory variant for lists longer than the LDS capacity (degenerate inputs: e.g. a tiny
+// image with a huge cloud).  Same network, in place on seg_keys, one 1024-thread block per tile.
+__global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2* __restrict__ ranges,
+                                                                    u64* __restrict__ seg_keys,
+                                                                    uint32_t* __restrict__ point_list, uint32_t lo)
+{
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= lo) return;
+    u64* k = seg_keys + rg.x;
+    gsr_bitonic(k, n, 1024);
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[rg.x + i] = (uint32_t)k[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream)
+{
+    const int nchunks = gsr_num_chunks(P);
+    // (1) offsets = exclusive scan of tiles
+    const int nb = gsr_scan_blocks(P);
+    hipLaunchKernelGGL(gsr_scan_reduce_kernel, dim3(nb), dim3(256), 0, stream, P, geom.tiles, geom.scan_sums);
+    hipLaunchKernelGGL(gsr_scan_sums_kernel, dim3(1), dim3(256), 0, stream, nb, geom.scan_sums);
+    hipLaunchKernelGGL(gsr_scan_apply_kernel, dim3(nb), dim3(256), 0, stream, P, geom.tiles, geom.scan_sums,
+                       geom.offsets);
+    // (2) per-chunk tile histogram -> table
+    const size_t lds = (size_t)T * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gsr_tile_hist_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
+                       geom.rect, image.table);
+    // (3) column scan -> per-(chunk, tile) offsets + tile totals, then tile scan -> ranges, info
+    hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
+                       image.tile_count);
+    hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(256), 0, stream, T, image.tile_count, image.ranges,
+                       image.info);
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
+                              hipStream_t stream)
+{
+    const int nchunks = gsr_num_chunks(P);
+    const size_t lds = (size_t)T * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)gsr_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
+                       geom.rect, geom.depthkey, geom.offsets, geom.tiles, image.table, image.ranges, geom.rec,
+                       bin.seg_keys);
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_tile_sort(int T, int R, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
+                                hipStream_t stream)
+{
+    if (R <= 0) return hipSuccess;
+    hipError_t e;
+    // size classes: (0, SMALL] in 32 KiB LDS, (SMALL, LARGE] in 128 KiB LDS, longer in global memory
+    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_SMALL * 8, stream,
+                       image.ranges, bin.seg_keys, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL);
+    if (max_tile_count > GSR_SORT_CAP_SMALL) {
+        e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GSR_SORT_CAP_LARGE * 8);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_LARGE * 8, stream,
+                           image.ranges, bin.seg_keys, bin.point_list, (uint32_t)GSR_SORT_CAP_SMALL,
+                           (uint32_t)GSR_SORT_CAP_LARGE);
+    }
+    if (max_tile_count > GSR_SORT_CAP_LARGE)
+        hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, bin.seg_keys,
+                           bin.point_list, (uint32_t)GSR_SORT_CAP_LARGE);
+    return hipGetLastError();
+}

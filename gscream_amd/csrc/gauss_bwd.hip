@@ -1,0 +1,254 @@
+// gauss_bwd.hip -- per-Gaussian backward: one thread per Gaussian.
+//
+// Fuses, in one streaming pass, what the reference runs as two kernels plus eleven zero-fills:
+//   * the segmented sum of the Gaussian's per-instance gradient slots written by the backward
+//     blend (replaces the 11 global atomicAdd targets of DGR backward.cu:554-601),
+//   * computeCov2DCUDA (backward.cu:144-274): dL/dconic -> dL/dcov2D -> dL/dcov3D, dL/dmean (cov path),
+//   * preprocessCUDA bwd (backward.cu:346-406): projection term, depth term, SH bwd (:20-139),
+//     computeCov3D bwd (:278-341) -> dL/dscale, dL/drot (w.r.t. the un-normalised quaternion).
+// Every output row is written (exact zeros for radii <= 0, backward.cu:156,369), so the caller's
+// gradient tensors need no memset (the reference zero-fills 116 B/Gaussian, rasterize_points.cu:160-170).
+// Built with -ffp-contract=off: same evaluation order and rounding as oracle/gs_oracle.c.
+//
+// HBM traffic per Gaussian: read 48 B x tiles_touched (contiguous slots) + 12 + 12 + 16 + 4 + 12;
+// write 12 + 12 + 4 + 4 + 12 + 12 + 16 = 72 B.
+#include "gsr_math.h"
+
+// DGR backward.cu:20-139 computeColorFromSH (bwd): returns dL/dmean contribution, writes dL/dsh.
+__device__ __forceinline__ float3 gsr_sh_backward(int idx, int deg, int M, float3 pos, const GsrCam& cam,
+                                                  const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+                                                  const float dcol[3], float* __restrict__ dL_dsh)
+{
+    const float dox = pos.x - cam.campos[0], doy = pos.y - cam.campos[1], doz = pos.z - cam.campos[2];
+    const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+    const float x = dox / len, y = doy / len, z = doz / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float* dsh = dL_dsh + (size_t)idx * M * 3;
+    float dRGB[3], ddx[3] = { 0, 0, 0 }, ddy[3] = { 0, 0, 0 }, ddz[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 3; k++) dRGB[k] = dcol[k] * (clamped[3 * idx + k] ? 0.f : 1.f);
+#define SH(i, k) sh[(i) * 3 + (k)]
+#define DSH(i, k) dsh[(i) * 3 + (k)]
+#pragma unroll
+    for (int k = 0; k < 3; k++) DSH(0, k) = GSR_SH_C0 * dRGB[k];
+    if (deg > 0) {
+        const float d1 = -GSR_SH_C1 * y, d2 = GSR_SH_C1 * z, d3 = -GSR_SH_C1 * x;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            DSH(1, k) = d1 * dRGB[k]; DSH(2, k) = d2 * dRGB[k]; DSH(3, k) = d3 * dRGB[k];
+            ddx[k] = -GSR_SH_C1 * SH(3, k); ddy[k] = -GSR_SH_C1 * SH(1, k); ddz[k] = GSR_SH_C1 * SH(2, k);
+        }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float d4 = GSR_SH_C2[0] * xy, d5 = GSR_SH_C2[1] * yz, d6 = GSR_SH_C2[2] * (2.f * zz - xx - yy);
+            const float d7 = GSR_SH_C2[3] * xz, d8 = GSR_SH_C2[4] * (xx - yy);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                DSH(4, k) = d4 * dRGB[k]; DSH(5, k) = d5 * dRGB[k]; DSH(6, k) = d6 * dRGB[k];
+                DSH(7, k) = d7 * dRGB[k]; DSH(8, k) = d8 * dRGB[k];
+                ddx[k] += GSR_SH_C2[0] * y * SH(4, k) + GSR_SH_C2[2] * 2.f * -x * SH(6, k) + GSR_SH_C2[3] * z * SH(7, k)
+                          + GSR_SH_C2[4] * 2.f * x * SH(8, k);
+                ddy[k] += GSR_SH_C2[0] * x * SH(4, k) + GSR_SH_C2[1] * z * SH(5, k) + GSR_SH_C2[2] * 2.f * -y * SH(6, k)
+                          + GSR_SH_C2[4] * 2.f * -y * SH(8, k);
+                ddz[k] += GSR_SH_C2[1] * y * SH(5, k) + GSR_SH_C2[2] * 2.f * 2.f * z * SH(6, k) + GSR_SH_C2[3] * x * SH(7, k);
+            }
+            if (deg > 2) {
+                const float d9 = GSR_SH_C3[0] * y * (3.f * xx - yy), d10 = GSR_SH_C3[1] * xy * z;
+                const float d11 = GSR_SH_C3[2] * y * (4.f * zz - xx - yy);
+                const float d12 = GSR_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                const float d13 = GSR_SH_C3[4] * x * (4.f * zz - xx - yy), d14 = GSR_SH_C3[5] * z * (xx - yy);
+                const float d15 = GSR_SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    DSH(9, k) = d9 * dRGB[k]; DSH(10, k) = d10 * dRGB[k]; DSH(11, k) = d11 * dRGB[k];
+                    DSH(12, k) = d12 * dRGB[k]; DSH(13, k) = d13 * dRGB[k]; DSH(14, k) = d14 * dRGB[k];
+                    DSH(15, k) = d15 * dRGB[k];
+                    ddx[k] += (GSR_SH_C3[0] * SH(9, k) * 3.f * 2.f * xy + GSR_SH_C3[1] * SH(10, k) * yz
+                               + GSR_SH_C3[2] * SH(11, k) * -2.f * xy + GSR_SH_C3[3] * SH(12, k) * -3.f * 2.f * xz
+                               + GSR_SH_C3[4] * SH(13, k) * (-3.f * xx + 4.f * zz - yy) + GSR_SH_C3[5] * SH(14, k) * 2.f * xz
+                               + GSR_SH_C3[6] * SH(15, k) * 3.f * (xx - yy));
+                    ddy[k] += (GSR_SH_C3[0] * SH(9, k) * 3.f * (xx - yy) + GSR_SH_C3[1] * SH(10, k) * xz
+                               + GSR_SH_C3[2] * SH(11, k) * (-3.f * yy + 4.f * zz - xx) + GSR_SH_C3[3] * SH(12, k) * -3.f * 2.f * yz
+                               + GSR_SH_C3[4] * SH(13, k) * -2.f * xy + GSR_SH_C3[5] * SH(14, k) * -2.f * yz
+                               + GSR_SH_C3[6] * SH(15, k) * -3.f * 2.f * xy);
+                    ddz[k] += (GSR_SH_C3[1] * SH(10, k) * xy + GSR_SH_C3[2] * SH(11, k) * 4.f * 2.f * yz
+                               + GSR_SH_C3[3] * SH(12, k) * 3.f * (2.f * zz - xx - yy) + GSR_SH_C3[4] * SH(13, k) * 4.f * 2.f * xz
+                               + GSR_SH_C3[5] * SH(14, k) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    const float gx_ = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
+    const float gy_ = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
+    const float gz_ = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+    // DGR auxiliary.h:107-118 dnormvdv
+    const float sum2 = dox * dox + doy * doy + doz * doz;
+    const float inv = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    float3 r;
+    r.x = ((+sum2 - dox * dox) * gx_ - doy * dox * gy_ - doz * dox * gz_) * inv;
+    r.y = (-dox * doy * gx_ + (sum2 - doy * doy) * gy_ - doz * doy * gz_) * inv;
+    r.z = (-dox * doz * gx_ - doy * doz * gy_ + (sum2 - doz * doz) * gz_) * inv;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
+    int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
+    const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
+    const uint32_t* __restrict__ offsets, const float4* __restrict__ slots, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeatures,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+
+    float gcol[3] = { 0, 0, 0 }, gdepth = 0, gfeat = 0, gm2x = 0, gm2y = 0, gcx = 0, gcy = 0, gcw = 0, gop = 0;
+    float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
+    const bool vis = radii[idx] > 0;
+
+    if (vis) {
+        const uint2 rc = rect[idx];
+        const int nt = (int)(((rc.x >> 16) - (rc.x & 0xffff)) * ((rc.y >> 16) - (rc.y & 0xffff)));
+        const float4* s = slots + (size_t)offsets[idx] * 3;
+        for (int j = 0; j < nt; j++) {
+            const float4 a = s[3 * j], b = s[3 * j + 1], c = s[3 * j + 2];
+            gcol[0] += a.x; gcol[1] += a.y; gcol[2] += a.z; gdepth += a.w;
+            gfeat += b.x; gm2x += b.y; gm2y += b.z; gcx += b.w;
+            gcy += c.x; gcw += c.y; gop += c.z;
+        }
+
+        const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        float cov3D[6];
+        float3 sc = make_float3(0.f, 0.f, 0.f);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            q = reinterpret_cast<const float4*>(rotations)[idx];
+            gsr_cov3d(sc, cam.scale_modifier, q, cov3D);
+        }
+        GsrCov2D c2;
+        gsr_cov2d(m, cam, cov3D, c2);
+        const float* vm = cam.view;
+        const float* proj = cam.proj;
+        const float h_x = cam.focal_x, h_y = cam.focal_y;
+
+        // ---- computeCov2DCUDA, backward.cu:175-273 ----
+        const float x_grad_mul = (c2.txtz < -c2.limx || c2.txtz > c2.limx) ? 0.f : 1.f;
+        const float y_grad_mul = (c2.tytz < -c2.limy || c2.tytz > c2.limy) ? 0.f : 1.f;
+        const float a = c2.a, b = c2.b, c = c2.c;
+        const float* T0 = c2.A0;
+        const float* T1 = c2.A1;
+        const float V[3][3] = { { cov3D[0], cov3D[1], cov3D[2] }, { cov3D[1], cov3D[3], cov3D[4] }, { cov3D[2], cov3D[4], cov3D[5] } };
+        const float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcw);
+            dL_dc = denom2inv * (-a * a * gcw + 2 * a * b * gcy + (denom - a * c) * gcx);
+            dL_db = denom2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcw);
+            dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
+            dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
+            dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
+            dcov[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
+            dcov[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
+            dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+        }
+        const float dL_dT00 = 2 * (T0[0] * V[0][0] + T0[1] * V[0][1] + T0[2] * V[0][2]) * dL_da + (T1[0] * V[0][0] + T1[1] * V[0][1] + T1[2] * V[0][2]) * dL_db;
+        const float dL_dT01 = 2 * (T0[0] * V[1][0] + T0[1] * V[1][1] + T0[2] * V[1][2]) * dL_da + (T1[0] * V[1][0] + T1[1] * V[1][1] + T1[2] * V[1][2]) * dL_db;
+        const float dL_dT02 = 2 * (T0[0] * V[2][0] + T0[1] * V[2][1] + T0[2] * V[2][2]) * dL_da + (T1[0] * V[2][0] + T1[1] * V[2][1] + T1[2] * V[2][2]) * dL_db;
+        const float dL_dT10 = 2 * (T1[0] * V[0][0] + T1[1] * V[0][1] + T1[2] * V[0][2]) * dL_dc + (T0[0] * V[0][0] + T0[1] * V[0][1] + T0[2] * V[0][2]) * dL_db;
+        const float dL_dT11 = 2 * (T1[0] * V[1][0] + T1[1] * V[1][1] + T1[2] * V[1][2]) * dL_dc + (T0[0] * V[1][0] + T0[1] * V[1][1] + T0[2] * V[1][2]) * dL_db;
+        const float dL_dT12 = 2 * (T1[0] * V[2][0] + T1[1] * V[2][1] + T1[2] * V[2][2]) * dL_dc + (T0[0] * V[2][0] + T0[1] * V[2][1] + T0[2] * V[2][2]) * dL_db;
+        const float dL_dJ00 = vm[0] * dL_dT00 + vm[4] * dL_dT01 + vm[8] * dL_dT02;
+        const float dL_dJ02 = vm[2] * dL_dT00 + vm[6] * dL_dT01 + vm[10] * dL_dT02;
+        const float dL_dJ11 = vm[1] * dL_dT10 + vm[5] * dL_dT11 + vm[9] * dL_dT12;
+        const float dL_dJ12 = vm[2] * dL_dT10 + vm[6] * dL_dT11 + vm[10] * dL_dT12;
+        const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c2.tx) * tz3 * dL_dJ02 + (2 * h_y * c2.ty) * tz3 * dL_dJ12;
+        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+        // ---- preprocessCUDA (bwd), backward.cu:371-396 ----
+        const float hw = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+        const float ax = (proj[0] * m_w - proj[3] * mul1) * gm2x + (proj[1] * m_w - proj[3] * mul2) * gm2y;
+        const float ay = (proj[4] * m_w - proj[7] * mul1) * gm2x + (proj[5] * m_w - proj[7] * mul2) * gm2y;
+        const float az = (proj[8] * m_w - proj[11] * mul1) * gm2x + (proj[9] * m_w - proj[11] * mul2) * gm2y;
+        dmean[0] += ax; dmean[1] += ay; dmean[2] += az;
+        dmean[0] += vm[2] * gdepth; dmean[1] += vm[6] * gdepth; dmean[2] += vm[10] * gdepth;
+
+        if (shs) {
+            const float3 e = gsr_sh_backward(idx, D, M, m, cam, shs, clamped, gcol, dL_dsh);
+            dmean[0] += e.x; dmean[1] += e.y; dmean[2] += e.z;
+        }
+
+        if (!cov3D_precomp) {
+            // ---- computeCov3D (bwd), backward.cu:278-341 ----
+            float R[3][3];
+            gsr_quat_to_R(q, R);
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const float s[3] = { cam.scale_modifier * sc.x, cam.scale_modifier * sc.y, cam.scale_modifier * sc.z };
+            float M2[3][3];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) M2[cc][rr] = (s[rr] * R[cc][rr]) * 2.0f;
+            const float Dm[3][3] = { { dcov[0], 0.5f * dcov[1], 0.5f * dcov[2] }, { 0.5f * dcov[1], dcov[3], 0.5f * dcov[4] }, { 0.5f * dcov[2], 0.5f * dcov[4], dcov[5] } };
+            float dMt[3][3];  // dMt[c][r] = dL_dM[r][c],  dL_dM[c][r] = sum_k M2[k][r] * Dm[c][k]
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) dMt[rr][cc] = M2[0][rr] * Dm[cc][0] + M2[1][rr] * Dm[cc][1] + M2[2][rr] * Dm[cc][2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) dscale[i] = R[0][i] * dMt[i][0] + R[1][i] * dMt[i][1] + R[2][i] * dMt[i][2];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) dMt[i][rr] *= s[i];
+            dq[0] = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+            dq[1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
+            dq[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
+            dq[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        }
+    } else if (shs && dL_dsh) {
+        for (int i = 0; i < M * 3; i++) dL_dsh[(size_t)idx * M * 3 + i] = 0.f;
+    }
+
+    dL_dmeans2D[3 * idx] = gm2x; dL_dmeans2D[3 * idx + 1] = gm2y; dL_dmeans2D[3 * idx + 2] = 0.f;
+    dL_dcolors[3 * idx] = gcol[0]; dL_dcolors[3 * idx + 1] = gcol[1]; dL_dcolors[3 * idx + 2] = gcol[2];
+    dL_dopacity[idx] = gop;
+    dL_dfeatures[idx] = gfeat;
+    dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+    }
+    if (dL_dscales) { dL_dscales[3 * idx] = dscale[0]; dL_dscales[3 * idx + 1] = dscale[1]; dL_dscales[3 * idx + 2] = dscale[2]; }
+    if (dL_drotations) reinterpret_cast<float4*>(dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+}
+
+hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
+                                     const float* shs, const float* scales, const float* rotations,
+                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
+                                     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                                     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                                     float* dL_drotations, hipStream_t stream)
+{
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsr_gauss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, cam, means3D, radii,
+                       shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets,
+                       reinterpret_cast<const float4*>(slots), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures,
+                       dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+    return hipGetLastError();
+}

@@ -1,0 +1,163 @@
+// gsr_common.h -- internal layout of the workspaces shared by all translation units.
+//
+// HBM layout (P Gaussians, T = gx*gy 16x16 tiles, N = W*H pixels, R instances):
+//
+//   geom  : rec[P]       64 B  one cache line per Gaussian, gathered by the blend kernels
+//                              a = {px, py, conA, conB}   b = {conC, opacity, depth, feature}
+//                              c = {r, g, b, -}           d = {offset, x0|x1<<16, y0|y1<<16, tiles}
+//           rect[P]       8 B  {x0|x1<<16, y0|y1<<16} tile rectangle (0,0 = culled)
+//           depthkey[P]   4 B  float bits of view-space depth (positive floats sort as uints)
+//           tiles[P]      4 B  tiles touched
+//           offsets[P]    4 B  exclusive scan of tiles = first gradient slot of the Gaussian
+//           clamped[P*3]  1 B  SH clamp flags (only with SH colours)
+//           scan block sums
+//   image : ranges[T]     8 B  [start,end) of each tile in the sorted list
+//           final_T[N], n_contrib[N]
+//           table[NB*T]   4 B  per-(chunk, tile) instance counts -> scatter offsets
+//           tile_count[T] 4 B
+//           info           16 B {R, max tile count}
+//   binning: point_list[R] 4 B sorted Gaussian ids   seg_keys[R] 8 B (depth bits<<32 | id)
+//   scratch (backward): slots[R] 48 B  per-instance partial gradients (12 floats)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gsraster.h"
+
+#define GSR_TILE 16
+#define GSR_MAX_CHUNKS 256       // NB: rows of the (chunk, tile) count table
+#define GSR_HIST_THREADS 512
+#define GSR_MAX_TILES_LDS 36864  // tiles whose histogram fits one LDS allocation (144 KiB)
+#define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
+#define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path
+#define GSR_SLOT_FLOATS 12
+
+struct GsrRec {
+    float4 a, b, c;
+    uint4 d;
+};
+static_assert(sizeof(GsrRec) == 64, "one record per 64-byte line");
+
+static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GsrGeom {
+    GsrRec* rec;
+    uint2* rect;
+    uint32_t* depthkey;
+    uint32_t* tiles;
+    uint32_t* offsets;
+    uint8_t* clamped;
+    uint32_t* scan_sums;
+    size_t bytes;
+};
+
+struct GsrImage {
+    uint2* ranges;
+    float* final_T;
+    uint32_t* n_contrib;
+    uint32_t* table;
+    uint32_t* tile_count;
+    uint32_t* info;  // [0] = R, [1] = max tile count
+    size_t bytes;
+};
+
+struct GsrBinning {
+    uint32_t* point_list;
+    unsigned long long* seg_keys;
+    size_t bytes;
+};
+
+#define GSR_SCAN_ITEMS 2048  // elements per block in the prefix scan
+
+static inline int gsr_scan_blocks(int P) { return (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS; }
+
+static inline int gsr_num_chunks(int P)
+{
+    int nb = (P + 2047) / 2048;
+    if (nb < 1) nb = 1;
+    if (nb > GSR_MAX_CHUNKS) nb = GSR_MAX_CHUNKS;
+    return nb;
+}
+
+static inline GsrGeom gsr_carve_geom(void* base, int P)
+{
+    GsrGeom g;
+    size_t off = 0;
+    char* b = (char*)base;
+    size_t p = (size_t)(P > 0 ? P : 1);
+    g.rec = (GsrRec*)(b + off); off += gsr_align(p * sizeof(GsrRec));
+    g.rect = (uint2*)(b + off); off += gsr_align(p * sizeof(uint2));
+    g.depthkey = (uint32_t*)(b + off); off += gsr_align(p * 4);
+    g.tiles = (uint32_t*)(b + off); off += gsr_align(p * 4);
+    g.offsets = (uint32_t*)(b + off); off += gsr_align(p * 4);
+    g.clamped = (uint8_t*)(b + off); off += gsr_align(p * 3);
+    g.scan_sums = (uint32_t*)(b + off); off += gsr_align((size_t)(gsr_scan_blocks((int)p) + 1) * 4);
+    g.bytes = off;
+    return g;
+}
+
+static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
+{
+    GsrImage im;
+    size_t off = 0;
+    char* b = (char*)base;
+    size_t gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    size_t T = gx * gy > 0 ? gx * gy : 1, N = (size_t)W * H > 0 ? (size_t)W * H : 1;
+    im.ranges = (uint2*)(b + off); off += gsr_align(T * sizeof(uint2));
+    im.final_T = (float*)(b + off); off += gsr_align(N * 4);
+    im.n_contrib = (uint32_t*)(b + off); off += gsr_align(N * 4);
+    im.table = (uint32_t*)(b + off); off += gsr_align((size_t)gsr_num_chunks(P) * T * 4);
+    im.tile_count = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.info = (uint32_t*)(b + off); off += gsr_align(16);
+    im.bytes = off;
+    return im;
+}
+
+static inline GsrBinning gsr_carve_binning(void* base, int R)
+{
+    GsrBinning bn;
+    size_t off = 0;
+    char* b = (char*)base;
+    size_t r = (size_t)(R > 0 ? R : 1);
+    bn.seg_keys = (unsigned long long*)(b + off); off += gsr_align(r * 8);
+    bn.point_list = (uint32_t*)(b + off); off += gsr_align(r * 4);
+    bn.bytes = off;
+    return bn;
+}
+
+// ---- stage launchers implemented in the .hip files (host functions, return hipError_t) ----
+struct GsrCam {
+    // device pointers: wave-uniform addresses, so the kernels fetch them with scalar loads (no host
+    // round trip, unlike copying the matrices into the kernel arguments would need)
+    const float* view;
+    const float* proj;
+    const float* campos;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int W, H, gx, gy;
+};
+
+hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& cam, const float* means3D,
+                                 const float* scales, const float* rotations, const float* opacities,
+                                 const float* features, const float* shs, const float* cov3D_precomp,
+                                 const float* colors_precomp, const GsrGeom* geom, int32_t* radii, float* px, float* py,
+                                 hipStream_t stream);
+hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                                   hipStream_t stream);
+hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream);
+hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
+                              hipStream_t stream);
+hipError_t gsr_launch_tile_sort(int T, int R, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
+                                hipStream_t stream);
+hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
+                                    const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
+                                    float* out_feature, int ppt, hipStream_t stream);
+hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
+                                     const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
+                                     const float* dL_ddepth, const float* dL_dfeature, float* slots, int ppt,
+                                     hipStream_t stream);
+hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
+                                     const float* shs, const float* scales, const float* rotations,
+                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
+                                     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                                     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                                     float* dL_drotations, hipStream_t stream);

@@ -1,0 +1,109 @@
+// gsr_math.h -- per-Gaussian geometry shared by the forward preprocess and the per-Gaussian
+// backward.  Both translation units are compiled with -ffp-contract=off so that this arithmetic
+// is plain IEEE fp32 in the evaluation order of the reference source (GLM mat3 products expanded
+// left to right, see oracle/gs_oracle.c): radii, tile rectangles, depth keys and therefore the
+// whole binning are bit-exact against the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gsr_common.h"
+
+// CUDA's float->int conversion saturates and maps NaN to 0; make that explicit.
+__device__ __forceinline__ int gsr_f2i(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// DGR auxiliary.h:41-44 -- evaluated in double because of the 1.0 / 0.5 literals.
+__device__ __forceinline__ float gsr_ndc2pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+// DGR auxiliary.h:46-56 getRect
+__device__ __forceinline__ void gsr_get_rect(float px, float py, int max_radius, int gx, int gy, int& x0, int& y0,
+                                             int& x1, int& y1)
+{
+    const float r = (float)max_radius;
+    x0 = min(gx, max(0, gsr_f2i((px - r) / 16.0f)));
+    y0 = min(gy, max(0, gsr_f2i((py - r) / 16.0f)));
+    x1 = min(gx, max(0, gsr_f2i((px + r + 15.0f) / 16.0f)));
+    y1 = min(gy, max(0, gsr_f2i((py + r + 15.0f) / 16.0f)));
+}
+
+// Rotation from the quaternion as given (not normalised), stored R[c][r] like the glm::mat3 the
+// reference builds at DGR forward.cu:136-140.
+__device__ __forceinline__ void gsr_quat_to_R(const float4 q, float R[3][3])
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// DGR forward.cu:120-154 computeCov3D:  Sigma = (S R)^T (S R), six unique entries.
+__device__ __forceinline__ void gsr_cov3d(const float3 scale, float mod, const float4 rot, float cov[6])
+{
+    const float s[3] = { mod * scale.x, mod * scale.y, mod * scale.z };
+    float R[3][3];
+    gsr_quat_to_R(rot, R);
+    float M[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) M[c][r] = s[r] * R[c][r];
+#define GSR_SIG(c, r) (M[r][0] * M[c][0] + M[r][1] * M[c][1] + M[r][2] * M[c][2])
+    cov[0] = GSR_SIG(0, 0); cov[1] = GSR_SIG(0, 1); cov[2] = GSR_SIG(0, 2);
+    cov[3] = GSR_SIG(1, 1); cov[4] = GSR_SIG(1, 2); cov[5] = GSR_SIG(2, 2);
+#undef GSR_SIG
+}
+
+struct GsrCov2D {
+    float tx, ty, tz;      // view-space mean with x/z, y/z clamped to +-1.3 tan(fov/2)
+    float txtz, tytz;      // unclamped ratios (the backward's grad multipliers test these)
+    float limx, limy;
+    float A0[3], A1[3];    // rows of the 2x3 matrix J * W_rot  (the reference's T[0][*], T[1][*])
+    float a, b, c;         // 2D covariance WITH the 0.3 low-pass
+};
+
+// DGR forward.cu:76-115 computeCov2D and the recomputation at backward.cu:160-199.
+__device__ __forceinline__ void gsr_cov2d(const float3 mean, const GsrCam& cam, const float cov3D[6], GsrCov2D& o)
+{
+    const float* vm = cam.view;
+    float tx = vm[0] * mean.x + vm[4] * mean.y + vm[8] * mean.z + vm[12];
+    float ty = vm[1] * mean.x + vm[5] * mean.y + vm[9] * mean.z + vm[13];
+    const float tz = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
+    o.limx = 1.3f * cam.tan_fovx;
+    o.limy = 1.3f * cam.tan_fovy;
+    o.txtz = tx / tz;
+    o.tytz = ty / tz;
+    tx = fminf(o.limx, fmaxf(-o.limx, o.txtz)) * tz;
+    ty = fminf(o.limy, fmaxf(-o.limy, o.tytz)) * tz;
+    o.tx = tx; o.ty = ty; o.tz = tz;
+    const float J00 = cam.focal_x / tz, J02 = -(cam.focal_x * tx) / (tz * tz);
+    const float J11 = cam.focal_y / tz, J12 = -(cam.focal_y * ty) / (tz * tz);
+    o.A0[0] = vm[0] * J00 + vm[2] * J02; o.A0[1] = vm[4] * J00 + vm[6] * J02; o.A0[2] = vm[8] * J00 + vm[10] * J02;
+    o.A1[0] = vm[1] * J11 + vm[2] * J12; o.A1[1] = vm[5] * J11 + vm[6] * J12; o.A1[2] = vm[9] * J11 + vm[10] * J12;
+    const float V[3][3] = { { cov3D[0], cov3D[1], cov3D[2] }, { cov3D[1], cov3D[3], cov3D[4] }, { cov3D[2], cov3D[4], cov3D[5] } };
+    float X0[3], X1[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        X0[c] = o.A0[0] * V[c][0] + o.A0[1] * V[c][1] + o.A0[2] * V[c][2];
+        X1[c] = o.A1[0] * V[c][0] + o.A1[1] * V[c][1] + o.A1[2] * V[c][2];
+    }
+    const float c00 = X0[0] * o.A0[0] + X0[1] * o.A0[1] + X0[2] * o.A0[2];
+    const float c01 = X1[0] * o.A0[0] + X1[1] * o.A0[1] + X1[2] * o.A0[2];
+    const float c11 = X1[0] * o.A1[0] + X1[1] * o.A1[1] + X1[2] * o.A1[2];
+    o.a = c00 + 0.3f; o.b = c01; o.c = c11 + 0.3f;
+}
+
+// Spherical-harmonics constants (DGR auxiliary.h:22-39)
+#define GSR_SH_C0 0.28209479177387814f
+#define GSR_SH_C1 0.4886025119029199f
+static __device__ const float GSR_SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                                     -1.0925484305920792f, 0.5462742152960396f };
+static __device__ const float GSR_SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                                     0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                                     -0.5900435899266435f };

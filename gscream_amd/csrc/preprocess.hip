@@ -1,0 +1,169 @@
+// preprocess.hip -- per-Gaussian forward stage (one thread per Gaussian, pure streaming).
+//
+// Replaces DGR forward.cu:157-267 preprocessCUDA, :271-346 filter_preprocessCUDA, :352-433
+// position2D_preprocessCUDA and rasterizer_impl.cu:54-66 checkFrustum.  Built with
+// -ffp-contract=off (see gsr_math.h): outputs are bit-exact against oracle/gs_oracle.c.
+//
+// HBM traffic per Gaussian (mode 0): read 60 B (mean 12, scale 12, quat 16, opacity 4, feature 4,
+// colour 12), write 48 B of the 64-B record + rect 8 + depthkey 4 + tiles 4 + radii 4 = 68 B.
+// cov3D is NOT stored: the backward recomputes it from scale/quat (bit-identical, cheaper than
+// 24 B out + 24 B in).
+#include "gsr_math.h"
+
+// DGR forward.cu:22-73 computeColorFromSH
+__device__ __forceinline__ float3 gsr_sh_to_rgb(int idx, int deg, int M, float3 pos, const GsrCam& cam, const float* shs,
+                                                uint8_t* clamped)
+{
+    float dx = pos.x - cam.campos[0], dy = pos.y - cam.campos[1], dz = pos.z - cam.campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float res[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#define S(i) sh[(i) * 3 + k]
+        float v = GSR_SH_C0 * S(0);
+        if (deg > 0) {
+            v = v - GSR_SH_C1 * y * S(1) + GSR_SH_C1 * z * S(2) - GSR_SH_C1 * x * S(3);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                v = v + GSR_SH_C2[0] * xy * S(4) + GSR_SH_C2[1] * yz * S(5) + GSR_SH_C2[2] * (2.0f * zz - xx - yy) * S(6)
+                      + GSR_SH_C2[3] * xz * S(7) + GSR_SH_C2[4] * (xx - yy) * S(8);
+                if (deg > 2) {
+                    v = v + GSR_SH_C3[0] * y * (3.0f * xx - yy) * S(9) + GSR_SH_C3[1] * xy * z * S(10)
+                          + GSR_SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11)
+                          + GSR_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12)
+                          + GSR_SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) + GSR_SH_C3[5] * z * (xx - yy) * S(14)
+                          + GSR_SH_C3[6] * x * (xx - 3.0f * yy) * S(15);
+                }
+            }
+        }
+#undef S
+        res[k] = v + 0.5f;
+        clamped[3 * idx + k] = (res[k] < 0);
+    }
+    return make_float3(fmaxf(res[0], 0.0f), fmaxf(res[1], 0.0f), fmaxf(res[2], 0.0f));
+}
+
+// MODE 0: full preprocess (writes the geometry state)   MODE 1: radii only   MODE 2: radii + px/py
+template <int MODE>
+__global__ void __launch_bounds__(256) gsr_preprocess_kernel(
+    int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ features,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    GsrRec* __restrict__ rec, uint2* __restrict__ rect, uint32_t* __restrict__ depthkey, uint32_t* __restrict__ tiles,
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, float* __restrict__ out_px, float* __restrict__ out_py)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+
+    int radius = 0;
+    uint2 rc = make_uint2(0u, 0u);
+    uint32_t ntiles = 0;
+    float pix = 0.f, piy = 0.f;
+
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float* pm = cam.proj;
+    const float* vm = cam.view;
+    // DGR auxiliary.h:139-164 in_frustum + forward.cu:200-204
+    const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+    const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+    const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float projx = hx * p_w, projy = hy * p_w;
+    const float viewz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+
+    float conx = 0.f, cony = 0.f, conz = 0.f;
+    if (viewz > 0.2f) {
+        float cov3D[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            gsr_cov3d(s, cam.scale_modifier, q, cov3D);
+        }
+        GsrCov2D c2;
+        gsr_cov2d(p, cam, cov3D, c2);
+        const float det = c2.a * c2.c - c2.b * c2.b;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            conx = c2.c * det_inv; cony = -c2.b * det_inv; conz = c2.a * det_inv;
+            const float mid = 0.5f * (c2.a + c2.c);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            pix = gsr_ndc2pix(projx, cam.W);
+            piy = gsr_ndc2pix(projy, cam.H);
+            int x0, y0, x1, y1;
+            gsr_get_rect(pix, piy, gsr_f2i(my_radius), cam.gx, cam.gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) != 0) {
+                radius = gsr_f2i(my_radius);
+                ntiles = (uint32_t)((y1 - y0) * (x1 - x0));
+                rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+            }
+        }
+    }
+
+    radii[idx] = radius;
+    if (MODE == 1) return;
+    if (MODE == 2) {
+        out_px[idx] = radius > 0 ? pix : 0.f;
+        out_py[idx] = radius > 0 ? piy : 0.f;
+        return;
+    }
+    rect[idx] = rc;
+    tiles[idx] = ntiles;
+    depthkey[idx] = __float_as_uint(viewz);
+    if (radius > 0) {
+        float3 col;
+        if (colors_precomp) col = make_float3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
+        else col = gsr_sh_to_rgb(idx, D, M, p, cam, shs, clamped);
+        GsrRec* r = rec + idx;
+        r->a = make_float4(pix, piy, conx, cony);
+        r->b = make_float4(conz, opacities[idx], viewz, features[idx]);
+        r->c = make_float4(col.x, col.y, col.z, 0.f);
+    }
+}
+
+// DGR rasterizer_impl.cu:54-66 checkFrustum
+__global__ void __launch_bounds__(256) gsr_mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                               const float* __restrict__ vm,
+                                                               uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float z = vm[2] * means3D[3 * idx] + vm[6] * means3D[3 * idx + 1] + vm[10] * means3D[3 * idx + 2] + vm[14];
+    present[idx] = z > 0.2f ? 1 : 0;
+}
+
+hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& cam, const float* means3D,
+                                 const float* scales, const float* rotations, const float* opacities,
+                                 const float* features, const float* shs, const float* cov3D_precomp,
+                                 const float* colors_precomp, const GsrGeom* g, int32_t* radii, float* px, float* py,
+                                 hipStream_t stream)
+{
+    if (P <= 0) return hipSuccess;
+    const dim3 grid((P + 255) / 256), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL(gsr_preprocess_kernel<0>, grid, block, 0, stream, P, D, M, cam, means3D, scales, rotations,
+                           opacities, features, shs, cov3D_precomp, colors_precomp, g->rec, g->rect, g->depthkey,
+                           g->tiles, g->clamped, radii, nullptr, nullptr);
+    else if (mode == 1)
+        hipLaunchKernelGGL(gsr_preprocess_kernel<1>, grid, block, 0, stream, P, D, M, cam, means3D, scales, rotations,
+                           nullptr, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, radii, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL(gsr_preprocess_kernel<2>, grid, block, 0, stream, P, D, M, cam, means3D, scales, rotations,
+                           nullptr, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, radii, px, py);
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t stream)
+{
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, vm, present);
+    return hipGetLastError();
+}

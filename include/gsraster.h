@@ -1,0 +1,158 @@
+/*
+ * gsraster.h -- C ABI of libgsraster.so, the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of W-Ted/GScream: the native module
+ * `diff_gaussian_rasterization._C` (reference: submodules/diff-gaussian-rasterization, "DGR").
+ * The reference binds five pybind11 functions (DGR/ext.cpp:15-21) that take torch::Tensor; this
+ * library exposes the same operations as plain `extern "C"` entry points taking raw DEVICE
+ * pointers, sizes and a hipStream_t -- no torch types, no C++ types, no exceptions.
+ * gscream_amd/_native.py (ctypes) is the only caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a device pointer unless its name ends in _host;
+ *   - all float arrays are contiguous row-major fp32, images are CHW (DGR forward.cu:563);
+ *   - matrices are the transposed / row-vector form GScream passes (scene/cameras.py:64-67):
+ *     p_view = [x y z 1] * viewmatrix, indexed m[0]x + m[4]y + m[8]z + m[12] (auxiliary.h:58-77);
+ *   - a NULL optional pointer means "not provided", like the reference's empty tensors
+ *     (DGR forward.cu:209,245; backward.cu:400,404);
+ *   - every function returns 0 on success and a negative gsr_status on failure;
+ *     gsr_last_error() returns a thread-local message for the last failure on this thread;
+ *   - the library owns no memory and keeps no global state: workspaces are sized by the
+ *     gsr_*_bytes queries, allocated by the caller (PyTorch's caching allocator) and passed in.
+ *     All workspace pointers must be 256-byte aligned.
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream, which is what the reference
+ *     launches on).  debug != 0 synchronises and checks for errors after every stage, the
+ *     semantics of the reference's CHECK_CUDA (auxiliary.h:166-173).
+ */
+#ifndef GSRASTER_H_INCLUDED
+#define GSRASTER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gsr_status {
+    GSR_OK = 0,
+    GSR_ERR_INVALID_ARGUMENT = -1,
+    GSR_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed */
+    GSR_ERR_UNSUPPORTED = -3,  /* e.g. more tiles than the binning kernels support */
+    GSR_ERR_NO_DEVICE = -4
+} gsr_status;
+
+/* Result of forward stage 1, written to host memory (pinned memory avoids a staging copy). */
+typedef struct gsr_stage1_result {
+    int32_t num_rendered;  /* R: number of (Gaussian, tile) instances; the reference's return value
+                              of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:346) */
+    int32_t max_tile_count; /* longest per-tile list; selects the per-tile sort variant */
+} gsr_stage1_result;
+
+/* Tunables; zero-initialise for defaults.  Pure performance knobs: results do not depend on them. */
+typedef struct gsr_tuning {
+    int32_t pixels_per_thread_fwd; /* 0 = default; 1, 2 or 4 */
+    int32_t pixels_per_thread_bwd; /* 0 = default; 1, 2 or 4 */
+    int32_t reserved[6];
+} gsr_tuning;
+
+/* Pipeline stages, for the optional per-stage timing below. */
+enum { GSR_STAGE_PREPROCESS = 0, GSR_STAGE_COUNT_SCAN, GSR_STAGE_SCATTER, GSR_STAGE_TILE_SORT, GSR_STAGE_BLEND_FWD,
+       GSR_STAGE_BLEND_BWD, GSR_STAGE_GAUSS_BWD, GSR_NUM_STAGES };
+
+typedef struct gsr_profile {
+    double total_ms[GSR_NUM_STAGES];   /* sum of HIP-event elapsed times per stage */
+    int64_t launches[GSR_NUM_STAGES];  /* number of timed stage invocations */
+} gsr_profile;
+
+const char* gsr_version(void);
+const char* gsr_last_error(void);
+/* Number of visible HIP devices, or a negative gsr_status. */
+int gsr_device_count(void);
+
+/* ---- workspace sizes (replace the obtain()/required<T>() carving of rasterizer_impl.h:21-74) ---- */
+size_t gsr_geom_bytes(int P);                 /* per-Gaussian state kept from forward to backward   */
+size_t gsr_image_bytes(int P, int W, int H);  /* per-pixel / per-tile state kept forward -> backward */
+size_t gsr_binning_bytes(int R);              /* per-instance state: sorted point list (+ sort keys)  */
+size_t gsr_backward_scratch_bytes(int P, int R); /* per-instance gradient slots used inside backward  */
+
+/*
+ * Forward, stage 1 of 2: per-Gaussian preprocess + tile histogram + scans.
+ * Replaces FORWARD::preprocess, cub::DeviceScan::InclusiveSum and the 4-byte D2H read of
+ * num_rendered in CudaRasterizer::Rasterizer::forward (DGR rasterizer_impl.cu:252-287).
+ *   means3D[P,3] opacities[P] features[P] (GScream's per-Gaussian `uncertainty`)
+ *   scales[P,3]+rotations[P,4]  XOR  cov3D_precomp[P,6]
+ *   colors_precomp[P,3]         XOR  shs[P,M,3] with degree D (campos[3] needed for SH)
+ * Outputs: radii[P] (int32; 0 = culled), *result_host.  The call synchronises `stream` once,
+ * like the reference's blocking cudaMemcpy (rasterizer_impl.cu:287).
+ */
+int gsr_forward_stage1(int P, int D, int M, int W, int H,
+                       const float* means3D, const float* scales, float scale_modifier, const float* rotations,
+                       const float* opacities, const float* features, const float* shs,
+                       const float* cov3D_precomp, const float* colors_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos,
+                       float tan_fovx, float tan_fovy, int prefiltered,
+                       void* geom, void* image, int32_t* radii, gsr_stage1_result* result_host,
+                       int debug, void* stream);
+
+/*
+ * Forward, stage 2 of 2: instance scatter into per-tile segments, per-tile depth sort, blend.
+ * Replaces duplicateWithKeys, cub::DeviceRadixSort::SortPairs, identifyTileRanges and
+ * FORWARD::render (DGR rasterizer_impl.cu:295-344).  `binning` must hold gsr_binning_bytes(R).
+ * Outputs (every pixel is written): out_color[3,H,W], out_depth[1,H,W], out_feature[1,H,W].
+ */
+int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const float* background,
+                       void* geom, void* image, void* binning,
+                       float* out_color, float* out_depth, float* out_feature,
+                       const gsr_tuning* tuning, int debug, void* stream);
+
+/*
+ * Backward.  Replaces CudaRasterizer::Rasterizer::backward (DGR rasterizer_impl.cu:536-643):
+ * BACKWARD::render + computeCov2DCUDA + preprocessCUDA(bwd).  geom/image/binning are the buffers
+ * the forward filled.  Every output row is written (culled Gaussians get exact zeros), so the
+ * caller need not zero-fill.  Optional outputs may be NULL: dL_dcov3D[P,6], dL_dsh[P,M,3].
+ *   dL_dmeans2D[P,3] (z = 0)  dL_dcolors[P,3]  dL_dopacity[P]  dL_dfeatures[P]
+ *   dL_dmeans3D[P,3]  dL_dscales[P,3]  dL_drotations[P,4]
+ * Gradients are bit-reproducible run to run (no floating-point atomics on global memory).
+ */
+int gsr_backward(int P, int D, int M, int W, int H, int R, const float* background,
+                 const float* means3D, const int32_t* radii, const float* colors_precomp, const float* shs,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy,
+                 const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_feature,
+                 const void* geom, const void* image, const void* binning, void* scratch,
+                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                 float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations,
+                 const gsr_tuning* tuning, int debug, void* stream);
+
+/*
+ * Visibility filters on a point cloud (GScream calls them on the anchors every iteration,
+ * train.py:433).  Replaces Rasterizer::visible_filter (px = py = NULL) and
+ * Rasterizer::position2D_filter (DGR rasterizer_impl.cu:350-406, :470-530).  No workspace.
+ * radii[P]; px[P], py[P] = pixel-space centre, 0 when culled (forward.cu:378-379).
+ */
+int gsr_filter(int P, int W, int H, const float* means3D, const float* scales, float scale_modifier,
+               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+               const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered,
+               int32_t* radii, float* px, float* py, int debug, void* stream);
+
+/* Replaces Rasterizer::markVisible (DGR rasterizer_impl.cu:141-153): present[i] = view-space z > 0.2. */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/*
+ * Optional per-stage timing (bench.py's roofline numbers; the reference has no counterpart -- its only
+ * timing is two CUDA events around a whole training iteration, train.py:343-344,406,578).
+ * Between gsr_profile_begin() and gsr_profile_end() every stage of every call is bracketed by a pair
+ * of HIP events recorded on the stream the stage is launched on.  gsr_profile_end() waits for them and
+ * returns the per-stage totals.  This is the only process-wide state in the library; off by default.
+ */
+int gsr_profile_begin(void);
+int gsr_profile_end(gsr_profile* out_host);
+const char* gsr_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRASTER_H_INCLUDED */

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def native_lib():
+    """libgsraster.so, built in-tree if missing (hipcc cross-compiles without a GPU)."""
+    from gscream_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _native.load()

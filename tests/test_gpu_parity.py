@@ -1,0 +1,267 @@
+"""GPU parity tests: the HIP path (through the public API -> ctypes -> C ABI -> kernels) against the
+committed golden vectors and against the live CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer results (radii, num_rendered, per-tile sorted id lists) bit-exact;
+images within 1e-4 abs; gradients within 1e-3 rel (denominator |ref| + 1e-3 max|ref|)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers as Hh  # noqa: E402
+from golden import make_golden as MG  # noqa: E402
+from gscream_amd import _layout, set_tuning  # noqa: E402
+from gscream_amd import synthetic as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(MG.cases().keys())
+
+
+@pytest.fixture(autouse=True)
+def _default_tuning():
+    set_tuning(0, 0)
+    yield
+    set_tuning(0, 0)
+
+
+def _check_binning(s, got, exp_point_list, exp_tile_counts):
+    P, R = s["means3D"].shape[0], got["num_rendered"]
+    img = _layout.image_views(got["img"], P, s["W"], s["H"])
+    rng = img["ranges"].cpu().numpy().astype(np.int64)
+    counts = rng[:, 1] - rng[:, 0]
+    assert (counts == exp_tile_counts.astype(np.int64)).all(), "per-tile instance counts"
+    assert rng[0, 0] == 0 and (rng[1:, 0] == rng[:-1, 1]).all() and rng[-1, 1] == R, "ranges must partition [0,R)"
+    pl = _layout.binning_views(got["binning"], R)["point_list"].cpu().numpy().astype(np.int64)
+    assert (pl == exp_point_list.astype(np.int64)).all(), "sorted per-tile Gaussian id lists"
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_forward_backward(name):
+    s, grads, exp = MG.load(name)
+    got = Hh.hip_run(s, grads)
+    assert (got["radii"] == exp["radii"]).all(), "radii must be bit-exact"
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], exp[k], f"{name}/{k}")
+    ref = {k[5:]: exp[k] for k in exp if k.startswith("grad_")}
+    keys = list(Hh.GRAD_KEYS) + ["dL_dsh", "dL_dcov3D"]
+    Hh.assert_grads_close(got, ref, keys=keys, context=name)
+    assert got["dL_dmeans2D"].shape == (s["means3D"].shape[0], 3) and not got["dL_dmeans2D"][:, 2].any()
+    culled = exp["radii"] <= 0
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        if k in got:
+            assert not got[k][culled].any(), f"{k}: culled Gaussians must get exact zeros (backward.cu:156,369)"
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_binning_is_bit_exact(name):
+    s, _, exp = MG.load(name)
+    got = Hh.hip_run(s, keep_state=True)
+    assert got["num_rendered"] == int(exp["num_rendered"])
+    _check_binning(s, got, exp["point_list"], exp["tile_counts"])
+    img = _layout.image_views(got["img"], s["means3D"].shape[0], s["W"], s["H"])
+    nc = img["n_contrib"].cpu().numpy()
+    assert (nc != exp["n_contrib"].astype(np.int64)).mean() < 1e-3
+
+
+@pytest.mark.parametrize("ppt", [1, 2, 4])
+@pytest.mark.parametrize("name", ["cfg1", "stack", "odd_size"])
+def test_pixels_per_thread_variants(name, ppt):
+    s, grads, exp = MG.load(name)
+    set_tuning(ppt, ppt)
+    got = Hh.hip_run(s, grads)
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], exp[k], f"{name}/ppt{ppt}/{k}")
+    Hh.assert_grads_close(got, {k[5:]: exp[k] for k in exp if k.startswith("grad_")}, context=f"{name}/ppt{ppt}")
+
+
+def test_config1_against_live_oracle():
+    """BASELINE.json config 1 (2k Gaussians @128x128) with the oracle run on this box."""
+    s = S.scene_config1()
+    grads = S.upstream_grads(1, s["W"], s["H"])
+    st = Hh.oracle_forward(s)
+    ref = Hh.oracle_backward(s, st, grads)
+    got = Hh.hip_run(s, grads)
+    assert (got["radii"] == st["radii"]).all()
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k)
+    Hh.assert_grads_close(got, ref, context="config1")
+    g2 = Hh.hip_run(s, keep_state=True)
+    assert g2["num_rendered"] == st["num_rendered"]
+    _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+
+
+@pytest.mark.parametrize("P,W,H,seed", [(60_000, 504, 284, 21), (20_000, 252, 142, 22)])
+def test_slab_scene_against_live_oracle(P, W, H, seed):
+    """Down-scaled config 2/3 generator (the bench workload's distribution), depth + feature heads on."""
+    s = S.scene_slab(seed, P, W, H)
+    grads = S.upstream_grads(seed, W, H)
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    st = Hh.oracle_forward(s, nthreads=nthreads)
+    ref = Hh.oracle_backward(s, st, grads, nthreads=nthreads)
+    got = Hh.hip_run(s, grads)
+    assert (got["radii"] == st["radii"]).all()
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k)
+    Hh.assert_grads_close(got, ref, context=f"slab{P}")
+    g2 = Hh.hip_run(s, keep_state=True)
+    assert g2["num_rendered"] == st["num_rendered"]
+    _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+
+
+@pytest.mark.parametrize("P,W,H,expect_class", [(14_000, 32, 32, "large"), (40_000, 32, 16, "global")])
+def test_long_tile_lists_use_the_big_sort_paths(P, W, H, expect_class):
+    """Tiny image + big cloud: per-tile lists beyond the 4096-entry LDS sort (-> 128 KiB LDS variant) and beyond
+    16384 (-> global-memory variant).  The sorted lists must still equal the oracle's."""
+    s = S.scene_config1(seed=31, P=P, W=W, H=H, lateral=0.3)
+    s["scales"] *= 0.15
+    st = Hh.oracle_forward(s)
+    mx = int((st["ranges"][:, 1] - st["ranges"][:, 0]).max())
+    assert (4096 < mx <= 16384) if expect_class == "large" else (mx > 16384), mx
+    got = Hh.hip_run(s, keep_state=True)
+    assert got["num_rendered"] == st["num_rendered"]
+    _check_binning(s, got, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k, max_outlier_frac=2e-3)
+
+
+def test_filters_match_oracle_and_known_answers():
+    from oracle import oracle as O
+    from gscream_amd import GaussianRasterizer
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "filter_known_answers.npz"))
+    W, H, tfx = int(z["W"]), int(z["H"]), float(z["tanfovx"])
+    s = S.scene_config1(seed=40, P=5, W=W, H=H, tanfovx=tfx)
+    s["means3D"] = z["points"].copy()
+    s["scales"] = np.full((5, 3), float(z["scale"]), np.float32)
+    s["rotations"] = np.tile(np.array([1, 0, 0, 0], np.float32), (5, 1))
+    r = GaussianRasterizer(raster_settings=Hh.hip_settings(s))
+    t = lambda a: torch.from_numpy(a).cuda()
+    radii, x, y = r.position2D_filter(t(s["means3D"]), scales=t(s["scales"]), rotations=t(s["rotations"]))
+    assert radii.dtype == torch.int32 and x.dtype == torch.float32 and radii.is_cuda
+    assert (radii.cpu().numpy() == z["radii"]).all()
+    np.testing.assert_allclose(x.cpu().numpy(), z["x"], atol=2e-3)
+    np.testing.assert_allclose(y.cpu().numpy(), z["y"], atol=2e-3)
+    assert (r.visible_filter(t(s["means3D"]), scales=t(s["scales"]), rotations=t(s["rotations"])).cpu().numpy() == z["radii"]).all()
+    vis = r.markVisible(t(s["means3D"]))
+    assert vis.dtype == torch.bool and (vis.cpu().numpy().astype(np.uint8) == z["visible"]).all()
+
+    # anchor-like cloud with a moved camera; scales passed as the strided slice GScream uses
+    # (gaussian_renderer/__init__.py:297: scales[:, :3] of a [N, 6] tensor)
+    rng = np.random.default_rng(41)
+    s = S.scene_config1(seed=41, P=20_000, W=252, H=142, lateral=0.8, w2c=S.random_w2c(rng), cx=0.03, cy=0.02)
+    kw = Hh.cam_kwargs(s)
+    ro, xo, yo = O.position2D_filter(s["means3D"], s["scales"], s["rotations"], **kw)
+    r = GaussianRasterizer(raster_settings=Hh.hip_settings(s))
+    scal6 = torch.cat([t(s["scales"]), torch.rand(20_000, 3, device="cuda")], 1)
+    radii, x, y = r.position2D_filter(t(s["means3D"]), scales=scal6[:, :3], rotations=t(s["rotations"]))
+    assert (radii.cpu().numpy() == ro).all()
+    assert np.array_equal(x.cpu().numpy(), xo) and np.array_equal(y.cpu().numpy(), yo), "pixel centres are bit-exact"
+    assert (r.visible_filter(t(s["means3D"]), scales=scal6[:, :3], rotations=t(s["rotations"])).cpu().numpy() == ro).all()
+    assert (r.markVisible(t(s["means3D"])).cpu().numpy() == O.mark_visible(s["means3D"], s["viewmatrix"])).all()
+
+
+def test_preprocess_outputs_are_bit_exact():
+    """means2D, conic, depth, rect, tiles, offsets straight out of the geometry records vs the oracle."""
+    rng = np.random.default_rng(50)
+    s = S.scene_config1(seed=50, P=30_000, W=320, H=200, lateral=0.8, w2c=S.random_w2c(rng), cx=-0.02, cy=0.05)
+    st = Hh.oracle_forward(s)
+    got = Hh.hip_run(s, keep_state=True)
+    P = 30_000
+    gv = _layout.geom_views(got["geom"], P)
+    vis = st["radii"] > 0
+    rec = gv["rec_f32"].cpu().numpy()
+    assert (got["radii"] == st["radii"]).all()
+    assert np.array_equal(rec[vis, 0:2], st["means2D"][vis]), "pixel centres"
+    assert np.array_equal(rec[vis, 2:5], st["conic_opacity"][vis, :3]), "conic"
+    assert np.array_equal(rec[vis, 5], st["conic_opacity"][vis, 3]) and np.array_equal(rec[vis, 6], st["depths"][vis])
+    assert np.array_equal(rec[vis, 7], st["unc"][vis]) and np.array_equal(rec[vis, 8:11], s["colors"][vis])
+    tiles = gv["tiles"].cpu().numpy().astype(np.int64)
+    assert (tiles == st["tiles_touched"].astype(np.int64)).all()
+    offs = gv["offsets"].cpu().numpy().astype(np.int64)
+    assert (offs == np.concatenate([[0], np.cumsum(tiles)[:-1]])).all(), "exclusive scan of tiles_touched"
+    assert (gv["rec_i32"].cpu().numpy()[:, 12].astype(np.int64) == offs).all(), "record tail carries the slot offset"
+
+
+def test_empty_and_degenerate_inputs():
+    from gscream_amd import GaussianRasterizer
+    s = S.scene_config1(seed=60, P=0, W=40, H=24)
+    got = Hh.hip_run(s, S.upstream_grads(1, 40, 24))
+    assert got["out_color"].shape == (3, 24, 40) and not got["out_color"].any() and got["radii"].shape == (0,)
+    assert got["dL_dmeans3D"].shape == (0, 3)
+    # all culled: image = background, every gradient exactly zero
+    s, grads, exp = MG.load("all_culled")
+    got = Hh.hip_run(s, grads)
+    assert np.allclose(got["out_color"], s["bg"][:, None, None]) and not got["out_depth"].any()
+    assert not got["dL_dmeans3D"].any() and not got["dL_dcolors"].any()
+    # single Gaussian, single pixel image
+    s = S.scene_config1(seed=61, P=1, W=1, H=1)
+    s["means3D"][:] = [0, 0, 3]
+    got = Hh.hip_run(s, S.upstream_grads(2, 1, 1))
+    st = Hh.oracle_forward(s)
+    Hh.assert_images_close(got["out_color"], st["out_color"], "1x1")
+    r = GaussianRasterizer(raster_settings=Hh.hip_settings(s))
+    assert r.visible_filter(torch.zeros(0, 3, device="cuda"), scales=torch.zeros(0, 3, device="cuda"),
+                            rotations=torch.zeros(0, 4, device="cuda")).shape == (0,)
+
+
+def test_render_call_pattern_of_gaussian_renderer():
+    """Replays gaussian_renderer/__init__.py:120-158: keyword call, screenspace_points = zeros + 0 with
+    retain_grad, settings built the same way; checks shapes / dtypes / devices of everything returned."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    s = S.scene_config1(seed=70, P=3000, W=160, H=96)
+    t = lambda a: torch.from_numpy(a).cuda()
+    xyz = t(s["means3D"]).requires_grad_(True)
+    color, opacity, unc = t(s["colors"]).requires_grad_(True), t(s["opacities"]).requires_grad_(True), t(s["uncertainties"]).requires_grad_(True)
+    scaling, rot = t(s["scales"]).requires_grad_(True), t(s["rotations"]).requires_grad_(True)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device="cuda") + 0
+    screenspace_points.retain_grad()
+    rs = GaussianRasterizationSettings(image_height=int(s["H"]), image_width=int(s["W"]), tanfovx=s["tanfovx"], tanfovy=s["tanfovy"],
+                                       bg=t(s["bg"]), scale_modifier=1.0, viewmatrix=t(s["viewmatrix"]), projmatrix=t(s["projmatrix"]),
+                                       sh_degree=1, campos=t(s["campos"]), prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=rs)
+    rendered_image, rendered_depth, uncer, radii = rasterizer(
+        means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color, opacities=opacity,
+        uncertainties=unc, scales=scaling, rotations=rot, cov3D_precomp=None)
+    assert rendered_image.shape == (3, 96, 160) and rendered_depth.shape == (1, 96, 160) and uncer.shape == (1, 96, 160)
+    assert radii.shape == (3000,) and radii.dtype == torch.int32 and not radii.requires_grad
+    assert all(x.is_cuda and x.dtype == torch.float32 for x in (rendered_image, rendered_depth, uncer))
+    visibility_filter = radii > 0
+    loss = rendered_image.mean() + 0.1 * rendered_depth.mean()  # the uncertainty map is unused by train.py:532
+    loss.backward(retain_graph=True)
+    assert screenspace_points.grad.shape == (3000, 3) and screenspace_points.grad[visibility_filter, :2].abs().sum() > 0
+    assert xyz.grad.shape == (3000, 3) and opacity.grad.shape == (3000, 1) and unc.grad.shape == (3000, 1)
+    assert not unc.grad.any(), "no loss on the feature map -> zero feature gradient"
+    with torch.no_grad():  # eval path, train.py:756-763
+        img2 = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color, opacities=opacity,
+                          uncertainties=unc, scales=scaling, rotations=rot, cov3D_precomp=None)[0]
+    assert torch.equal(img2, rendered_image)
+
+
+def test_debug_mode_and_determinism():
+    s, grads, exp = MG.load("cfg1")
+    a = Hh.hip_run(s, grads, debug=True)
+    b = Hh.hip_run(s, grads)
+    c = Hh.hip_run(s, grads)
+    for k in ("out_color", "out_depth", "out_unc") + Hh.GRAD_KEYS:
+        assert np.array_equal(b[k], c[k]), f"{k}: runs must be bit-identical (no float atomics on global memory)"
+        assert np.array_equal(a[k], b[k]), f"{k}: debug mode must not change results"
+
+
+def test_non_default_stream_and_strided_inputs():
+    s, grads, exp = MG.load("cfg1")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        got = Hh.hip_run(s, grads)
+    st.synchronize()
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], exp[k], k)
+    from gscream_amd import GaussianRasterizer
+    t = lambda a: torch.from_numpy(a).cuda()
+    big = torch.zeros(s["means3D"].shape[0], 7, device="cuda")
+    big[:, 2:5] = t(s["means3D"])
+    r = GaussianRasterizer(raster_settings=Hh.hip_settings(s))
+    img = r(big[:, 2:5], torch.zeros(s["means3D"].shape[0], 3, device="cuda"), t(s["opacities"]), t(s["uncertainties"]),
+            colors_precomp=t(s["colors"]), scales=t(s["scales"]), rotations=t(s["rotations"]))[0]
+    Hh.assert_images_close(img.cpu().numpy(), exp["out_color"], "strided means3D")
