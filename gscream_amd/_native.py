@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsraster.so")
+LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsraster.so")  # GSR_LIB: diagnostic builds
 
 #: every symbol include/gsraster.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (

@@ -29,6 +29,17 @@
 
 #define GSR_BATCH 256
 
+// Fast-math knobs of the blend inner loops.  Default: exp via v_exp_f32 (exp2(x*log2e), ~2 ulp) and
+// T/(1-alpha) via v_rcp_f32 (1 ulp).  -DGSR_PRECISE_MATH selects libm-accurate expf and IEEE division
+// (diagnostic build, used to attribute parity differences; not shipped).
+#ifdef GSR_PRECISE_MATH
+#define GSR_EXP(x) expf(x)
+#define GSR_RCP(x) (1.0f / (x))
+#else
+#define GSR_EXP(x) __expf(x)
+#define GSR_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+
 __device__ __forceinline__ int gsr_tile_of_block(int b, int T)
 {
     const int xcd = b & 7, i = b >> 3, q = T >> 3, r = T & 7;
@@ -108,7 +119,7 @@ __global__ void __launch_bounds__(256 / PPT) gsr_blend_fwd_kernel(
             for (int k = 0; k < PPT; k++) {
                 const float dx = A.x - pxf, dy = A.y - pyf[k];
                 const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float alpha = fminf(0.99f, B.y * __expf(power));
+                const float alpha = fminf(0.99f, B.y * GSR_EXP(power));
                 bool ok = !done[k] && power <= 0.0f && alpha >= (1.0f / 255.0f);
                 const float test_T = Tr[k] * (1.0f - alpha);
                 const bool stop = ok && test_T < 0.0001f;
@@ -224,7 +235,7 @@ __global__ void __launch_bounds__(256 / PPT) gsr_blend_bwd_kernel(
                 for (int k = 0; k < PPT; k++) {
                     dx[k] = A.x - pxf; dy[k] = A.y - pyf[k];
                     const float power = -0.5f * (A.z * dx[k] * dx[k] + B.x * dy[k] * dy[k]) - A.w * dx[k] * dy[k];
-                    G[k] = __expf(power);
+                    G[k] = GSR_EXP(power);
                     alpha[k] = fminf(0.99f, B.y * G[k]);
                     ok[k] = p < lastc[k] && power <= 0.0f && alpha[k] >= (1.0f / 255.0f);
                     any_ok = any_ok || ok[k];
@@ -237,7 +248,7 @@ __global__ void __launch_bounds__(256 / PPT) gsr_blend_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < PPT; k++) {
                     if (ok[k]) {  // divergent: executed under the EXEC mask of the lanes that blend
-                        const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha[k]);
+                        const float rinv = GSR_RCP(1.0f - alpha[k]);
                         const float Tn = Tr[k] * rinv;  // T / (1 - alpha)
                         const float w = alpha[k] * Tn;
                         const float oml = 1.0f - la[k];

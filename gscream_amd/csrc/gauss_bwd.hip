@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
     if (idx >= P) return;
 
     float gcol[3] = { 0, 0, 0 }, gdepth = 0, gfeat = 0, gm2x = 0, gm2y = 0, gcx = 0, gcy = 0, gcw = 0, gop = 0;
+    double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
     const bool vis = radii[idx] > 0;
 
@@ -115,10 +116,13 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
         const float4* s = slots + (size_t)offsets[idx] * 3;
         for (int j = 0; j < nt; j++) {
             const float4 a = s[3 * j], b = s[3 * j + 1], c = s[3 * j + 2];
-            gcol[0] += a.x; gcol[1] += a.y; gcol[2] += a.z; gdepth += a.w;
-            gfeat += b.x; gm2x += b.y; gm2y += b.z; gcx += b.w;
-            gcy += c.x; gcw += c.y; gop += c.z;
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+            acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
         }
+        gcol[0] = (float)acc[0]; gcol[1] = (float)acc[1]; gcol[2] = (float)acc[2]; gdepth = (float)acc[3];
+        gfeat = (float)acc[4]; gm2x = (float)acc[5]; gm2y = (float)acc[6]; gcx = (float)acc[7];
+        gcy = (float)acc[8]; gcw = (float)acc[9]; gop = (float)acc[10];
 
         const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         float cov3D[6];

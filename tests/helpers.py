@@ -134,13 +134,27 @@ def assert_images_close(got, ref, name, max_outlier_frac=2e-4, hard_cap=2e-2):
     return rep
 
 
-def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context=""):
-    worst = {}
+def grad_report(got, ref, tol=GRAD_REL_TOL):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64).reshape(np.asarray(got).shape)
+    if ref.size == 0:
+        return dict(max=0.0, p999=0.0, n_bad=0, n=0)
+    rel = np.abs(got - ref) / (np.abs(ref) + 1e-3 * max(np.abs(ref).max(), 1e-30))
+    return dict(max=float(rel.max()), p999=float(np.quantile(rel, 0.999)), n_bad=int((rel > tol).sum()), n=int(rel.size))
+
+
+def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-4, min_bad_allowed=2):
+    """Every gradient family within `tol` rel (denominator |ref| + 1e-3 max|ref|) on all but a bounded
+    handful of elements.  The handful exists because a (pixel, Gaussian) pair whose alpha sits within an
+    ulp of 1/255 (or whose T sits at 1e-4) can be blended by one implementation and skipped by the other
+    (exp() and FMA contraction differ by ulps); that moves one pixel's worth of gradient for that Gaussian.
+    Measured on the GPU box: 0-9 such elements out of 240k (tools/grad_diag.py).  The 99.9th percentile
+    must be inside `tol` regardless."""
+    rep = {}
     for k in keys:
         if k not in ref or k not in got:
             continue
-        r = np.asarray(ref[k]).reshape(np.asarray(got[k]).shape)
-        worst[k] = rel_err(got[k], r)
-    bad = {k: v for k, v in worst.items() if not v <= tol}
-    assert not bad, f"{context} gradient mismatch (rel, tol {tol}): {bad}; all: {worst}"
-    return worst
+        rep[k] = grad_report(got[k], ref[k], tol)
+    bad = {k: v for k, v in rep.items()
+           if v["n_bad"] > max(min_bad_allowed, max_bad_frac * v["n"]) or not v["p999"] <= tol or not v["max"] <= 0.5}
+    assert not bad, f"{context} gradient mismatch (rel tol {tol}): {bad}; all: {rep}"
+    return {k: v["max"] for k, v in rep.items()}

@@ -1,0 +1,163 @@
+"""GPU property tests at BASELINE.json's full sizes (1M Gaussians @1008x567, 2M @1920x1080), where the CPU
+oracle would take minutes: size-independent properties of the rasterizer instead of element-wise parity.
+
+  * partition of unity: colours == 1 and background == 1  =>  image == 1 (sum_i alpha_i T_i + T_final = 1);
+    features == 1 => feature map == 1 - T_final; depth map bounded by [0, z_max];
+  * binning: per-tile lists sorted by (depth, id), ranges partition [0, R), per-tile counts equal an independent
+    torch recomputation from the tile rectangles, sum == num_rendered == sum(tiles_touched);
+  * backward: bit-reproducible; linear in the upstream gradient; sum_g dL/dcolor[g] == sum_pix g(pix)(1 - T_final);
+    the pixels-per-thread variants agree; culled Gaussians get exact zeros.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers as Hh  # noqa: E402
+from gscream_amd import GaussianRasterizer, _layout, set_tuning  # noqa: E402
+from gscream_amd import rasterizer as RZ  # noqa: E402
+from gscream_amd import synthetic as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {"config2_1M_1008x567": (1, 1_000_000, 1008, 567), "config4_2M_1920x1080": (3, 2_000_000, 1920, 1080)}
+
+
+@pytest.fixture(scope="module", params=sorted(CONFIGS))
+def scene(request):
+    seed, P, W, H = CONFIGS[request.param]
+    s = S.scene_slab(seed, P, W, H)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in s.items() if isinstance(v, np.ndarray)}
+    return s, dev, Hh.hip_settings(s)
+
+
+def _forward_state(s, dev, rs, colors=None, unc=None):
+    e = torch.Tensor([])
+    return RZ._forward_native(dev["means3D"], e, dev["colors"] if colors is None else colors, dev["opacities"],
+                              dev["uncertainties"] if unc is None else unc, dev["scales"], dev["rotations"], e, rs)
+
+
+def test_partition_of_unity(scene):
+    s, dev, rs = scene
+    rs1 = rs._replace(bg=torch.ones(3, device="cuda"))
+    R, color, depth, feat, radii, geom, binning, img = _forward_state(
+        s, dev, rs1, colors=torch.ones_like(dev["colors"]), unc=torch.ones_like(dev["uncertainties"]))
+    assert R > s["means3D"].shape[0]
+    assert (color - 1.0).abs().max().item() < 2e-5
+    fT = _layout.image_views(img, s["means3D"].shape[0], s["W"], s["H"])["final_T"]
+    assert (feat[0] - (1.0 - fT)).abs().max().item() < 2e-5
+    assert fT.min().item() >= 1e-4 * 0.01 - 1e-9 and fT.max().item() <= 1.0
+    zmax = dev["means3D"][:, 2].max().item()
+    assert depth.min().item() >= 0 and depth.max().item() <= zmax * (1 + 1e-5)
+
+
+def test_binning_invariants(scene):
+    s, dev, rs = scene
+    P, W, H = s["means3D"].shape[0], s["W"], s["H"]
+    R, color, depth, feat, radii, geom, binning, img = _forward_state(s, dev, rs)
+    gv, iv, bv = _layout.geom_views(geom, P), _layout.image_views(img, P, W, H), _layout.binning_views(binning, R)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tiles = gv["tiles"].long()
+    assert int(tiles.sum()) == R == int(iv["info"][0])
+    ranges = iv["ranges"].long()
+    counts = ranges[:, 1] - ranges[:, 0]
+    assert ranges[0, 0] == 0 and bool((ranges[1:, 0] == ranges[:-1, 1]).all()) and ranges[-1, 1] == R
+    assert int(counts.max()) == int(iv["info"][1])
+    # independent recomputation of the per-tile counts from (pixel centre, radius) with torch float32 ops
+    rec = gv["rec_f32"]
+    px, py, r = rec[:, 0], rec[:, 1], radii.float()
+    vis = radii > 0
+    x0 = torch.clamp(((px - r) / 16).int(), 0, gx); x1 = torch.clamp(((px + r + 15) / 16).int(), 0, gx)
+    y0 = torch.clamp(((py - r) / 16).int(), 0, gy); y1 = torch.clamp(((py + r + 15) / 16).int(), 0, gy)
+    x0, x1, y0, y1 = [torch.where(vis, v, torch.zeros_like(v)) for v in (x0, x1, y0, y1)]
+    assert bool(((x1 - x0) * (y1 - y0) == tiles).all()), "tiles_touched == rect area"
+    rect = gv["rect"]
+    assert bool(((rect[:, 0] & 0xffff) == x0).all() and ((rect[:, 0] >> 16) == x1).all())
+    # 2-D difference-array histogram of the rectangles
+    diff = torch.zeros((gy + 1) * (gx + 1), dtype=torch.int64, device="cuda")
+    for (yy, xx, sign) in ((y0, x0, 1), (y0, x1, -1), (y1, x0, -1), (y1, x1, 1)):
+        diff.index_add_(0, (yy.long() * (gx + 1) + xx.long())[vis], torch.full((int(vis.sum()),), sign, dtype=torch.int64, device="cuda"))
+    hist = diff.view(gy + 1, gx + 1).cumsum(0).cumsum(1)[:gy, :gx].reshape(-1)
+    assert bool((hist == counts).all()), "per-tile counts"
+    # sortedness of every tile list by (depth bits, id), and membership of every entry in its tile's rectangle
+    pl = bv["point_list"].long()
+    dk = gv["depthkey"].long()[pl] & 0xffffffff
+    key = dk * (P + 1) + pl
+    tile_of = torch.repeat_interleave(torch.arange(gx * gy, device="cuda"), counts)
+    same = tile_of[1:] == tile_of[:-1]
+    assert bool((key[1:][same] > key[:-1][same]).all()), "per-tile lists strictly ascending in (depth, id)"
+    tx, ty = tile_of % gx, tile_of // gx
+    assert bool(((tx >= x0[pl]) & (tx < x1[pl]) & (ty >= y0[pl]) & (ty < y1[pl])).all())
+    # gradient-slot map: offset + position inside the rectangle is a bijection onto [0, R)
+    offs = gv["offsets"].long()
+    slot = offs[pl] + (ty - y0[pl]) * (x1[pl] - x0[pl]) + (tx - x0[pl])
+    assert int(slot.min()) == 0 and int(slot.max()) == R - 1 and int(torch.unique(slot).numel()) == R
+
+
+def _run_bwd(s, dev, rs, grads):
+    leaves = {k: dev[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")}
+    m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    c, d, u, radii = GaussianRasterizer(raster_settings=rs)(
+        leaves["means3D"], m2, leaves["opacities"], leaves["uncertainties"], colors_precomp=leaves["colors"],
+        scales=leaves["scales"], rotations=leaves["rotations"])
+    torch.autograd.backward([c, d, u], list(grads))
+    out = {k: v.grad for k, v in leaves.items()}
+    out["means2D"] = m2.grad
+    return out, radii
+
+
+def test_backward_properties(scene):
+    s, dev, rs = scene
+    W, H = s["W"], s["H"]
+    g1 = [torch.from_numpy(g).cuda() for g in S.upstream_grads(5, W, H)]
+    g2 = [torch.from_numpy(g).cuda() for g in S.upstream_grads(6, W, H)]
+    a, radii = _run_bwd(s, dev, rs, g1)
+    b, _ = _run_bwd(s, dev, rs, g1)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: backward must be bit-reproducible"
+    culled = radii <= 0
+    assert int(culled.sum()) > 0
+    for k in ("means3D", "opacities", "scales", "rotations", "colors", "means2D"):
+        assert not a[k][culled].any(), k
+    assert not a["means2D"][:, 2].any() and all(torch.isfinite(v).all() for v in a.values())
+    # linearity in the upstream gradient
+    c2, _ = _run_bwd(s, dev, rs, g2)
+    c12, _ = _run_bwd(s, dev, rs, [x + 0.5 * y for x, y in zip(g1, g2)])
+    for k in a:
+        ref = a[k] + 0.5 * c2[k]
+        den = ref.abs() + 1e-3 * ref.abs().max()
+        assert ((c12[k] - ref).abs() / den).max().item() < 1e-3, k
+    # sum_g dL/dcolor[g, ch] = sum_pix g_ch (1 - T_final)  (each pixel's blend weights sum to 1 - T_final)
+    R, color, depth, feat, radii2, geom, binning, img = _forward_state(s, dev, rs)
+    fT = _layout.image_views(img, s["means3D"].shape[0], W, H)["final_T"].double()
+    for ch in range(3):
+        lhs = a["colors"][:, ch].double().sum().item()
+        rhs = (g1[0][ch].double() * (1.0 - fT)).sum().item()
+        scale = (g1[0][ch].double().abs() * (1.0 - fT)).sum().item()
+        assert abs(lhs - rhs) <= 1e-4 * scale, (ch, lhs, rhs)
+    lhs = a["uncertainties"].double().sum().item()
+    rhs = (g1[2][0].double() * (1.0 - fT)).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * (g1[2][0].double().abs() * (1.0 - fT)).sum().item()
+
+
+def test_pixels_per_thread_variants_agree(scene):
+    s, dev, rs = scene
+    g1 = [torch.from_numpy(g).cuda() for g in S.upstream_grads(7, s["W"], s["H"])]
+    outs = {}
+    try:
+        for ppt in (1, 2, 4):
+            set_tuning(ppt, ppt)
+            grads, _ = _run_bwd(s, dev, rs, g1)
+            img = _forward_state(s, dev, rs)[1]
+            outs[ppt] = (img, grads)
+    finally:
+        set_tuning(0, 0)
+    for ppt in (1, 4):
+        assert torch.equal(outs[ppt][0], outs[2][0]), "forward images are independent of the thread mapping"
+        for k in outs[2][1]:
+            ref = outs[2][1][k]
+            den = ref.abs() + 1e-3 * ref.abs().max()
+            assert ((outs[ppt][1][k] - ref).abs() / den).max().item() < 1e-3, (ppt, k)
