@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--ppt-fwd", type=int, default=0)
     ap.add_argument("--ppt-bwd", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tile-cull", action="store_true", help="bin every rectangle tile like the reference")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +129,7 @@ def main():
     from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer, _native, set_tuning
     from gscream_amd import synthetic as S
     _native.load()
-    set_tuning(args.ppt_fwd, args.ppt_bwd)
+    set_tuning(args.ppt_fwd, args.ppt_bwd, tile_cull=not args.no_tile_cull)
 
     P, W, H, seed, gsel, desc = WORKLOADS[args.workload]
     s = S.scene_slab(seed + 10 * rank if world > 1 else seed, P, W, H)  # one independent scene per GPU
@@ -171,15 +172,15 @@ def main():
         elapsed = float(tt.item())
 
     # units for the byte model: R from one more (untimed) forward
-    with torch.no_grad():
-        from gscream_amd import rasterizer as RZ
-        e = torch.Tensor([])
-        R = RZ._forward_native(means3D, e, colors, opac, unc, scales, rots, e, rs)[0]
+    from gscream_amd import rasterizer as RZ
+    R = RZ._last_stage1["num_rendered"]          # instances actually binned (after tile culling)
+    R_ref = RZ._last_stage1["num_slots"]         # sum of tiles_touched = the reference's num_rendered
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     visible = int((radii > 0).sum())
 
     if rank == 0:
-        model = stage_algorithmic_bytes(P, R, N, T)
+        model = stage_algorithmic_bytes(P, R, N, T)            # units each launch really processes
+        model_ref = stage_algorithmic_bytes(P, R_ref, N, T)    # the reference algorithm on the same workload
         stages = {}
         for name, (ms, n) in prof.items():
             if n:
@@ -187,7 +188,7 @@ def main():
                 stages[name] = {"avg_ms": round(avg, 4), "launches": n, "algorithmic_GB": round(model[name] / 1e9, 4),
                                 "GBps": round(model[name] / 1e9 / (avg / 1e3), 1)}
         dom = max(stages, key=lambda k: stages[k]["avg_ms"])
-        total_bytes = sum(model.values())
+        total_bytes = sum(model_ref.values())
         ms_per_step = elapsed / args.steps * 1e3
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
@@ -201,13 +202,15 @@ def main():
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "visible": visible,
+            "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,
+                       "visible": visible, "tile_cull": not args.no_tile_cull,
                        "parallelism": f"{world} independent scene(s), one per GPU, barrier only",
                        "pixels_per_thread": [args.ppt_fwd or 2, args.ppt_bwd or 2]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": model[dom], "avg_launch_ms": stages[dom]["avg_ms"]},
-            "whole_iteration": {"algorithmic_GB": round(total_bytes / 1e9, 4),
+            "whole_iteration": {"note": "reference byte model 420P + 304R_ref + 56N over the measured ms_per_step",
+                                "algorithmic_GB": round(total_bytes / 1e9, 4),
                                 "GBps": round(total_bytes / 1e9 / (ms_per_step / 1e3), 1),
                                 "frac_of_hbm_peak": round(total_bytes / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBS, 4),
                                 "kernel_ms_sum": round(sum(v["avg_ms"] for v in stages.values()), 4)},

@@ -24,6 +24,7 @@ def geom_views(buf, P):
     out["depthkey"] = _take(buf, off, p * 4, torch.int32, (p,)); off += _align(p * 4)
     out["tiles"] = _take(buf, off, p * 4, torch.int32, (p,)); off += _align(p * 4)
     out["offsets"] = _take(buf, off, p * 4, torch.int32, (p,)); off += _align(p * 4)
+    out["tmask"] = _take(buf, off, p * 8, torch.int64, (p,)); off += _align(p * 8)
     return {k: v[:P] for k, v in out.items()}
 
 

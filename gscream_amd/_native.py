@@ -20,12 +20,13 @@ NUM_STAGES = 7
 
 
 class Stage1Result(ctypes.Structure):
-    _fields_ = [("num_rendered", ctypes.c_int32), ("max_tile_count", ctypes.c_int32)]
+    _fields_ = [("num_rendered", ctypes.c_int32), ("max_tile_count", ctypes.c_int32),
+                ("num_slots", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Tuning(ctypes.Structure):
     _fields_ = [("pixels_per_thread_fwd", ctypes.c_int32), ("pixels_per_thread_bwd", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 6)]
+                ("disable_tile_cull", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
 
 
 class Profile(ctypes.Structure):
@@ -60,7 +61,7 @@ def load():
     lib.gsr_forward_stage1.restype = _c_int
     lib.gsr_forward_stage1.argtypes = (
         [_c_int] * 5 + [_vp, _vp, _c_float, _vp] + [_vp] * 5 + [_vp, _vp, _vp, _c_float, _c_float, _c_int]
-        + [_vp, _vp, _vp, ctypes.POINTER(Stage1Result), _c_int, _vp])
+        + [_vp, _vp, _vp, ctypes.POINTER(Stage1Result), ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_forward_stage2.restype = _c_int
     lib.gsr_forward_stage2.argtypes = [_c_int] * 5 + [_vp] * 7 + [ctypes.POINTER(Tuning), _c_int, _vp]
     lib.gsr_backward.restype = _c_int

@@ -114,10 +114,10 @@ extern "C" int gsr_device_count(void)
 extern "C" size_t gsr_geom_bytes(int P) { return gsr_carve_geom(nullptr, P).bytes; }
 extern "C" size_t gsr_image_bytes(int P, int W, int H) { return gsr_carve_image(nullptr, P, W, H).bytes; }
 extern "C" size_t gsr_binning_bytes(int R) { return gsr_carve_binning(nullptr, R).bytes; }
-extern "C" size_t gsr_backward_scratch_bytes(int P, int R)
+extern "C" size_t gsr_backward_scratch_bytes(int P, int num_slots)
 {
     (void)P;
-    return gsr_align((size_t)(R > 0 ? R : 1) * GSR_SLOT_FLOATS * sizeof(float));
+    return gsr_align((size_t)(num_slots > 0 ? num_slots : 1) * GSR_SLOT_FLOATS * sizeof(float));
 }
 
 static int gsr_make_cam(GsrCam& cam, int W, int H, const float* view_d, const float* proj_d, const float* campos_d,
@@ -150,8 +150,8 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
                                   const float* features, const float* shs, const float* cov3D_precomp,
                                   const float* colors_precomp, const float* viewmatrix, const float* projmatrix,
                                   const float* campos, float tan_fovx, float tan_fovy, int prefiltered, void* geom_ws,
-                                  void* image_ws, int32_t* radii, gsr_stage1_result* result_host, int debug,
-                                  void* stream_)
+                                  void* image_ws, int32_t* radii, gsr_stage1_result* result_host,
+                                  const gsr_tuning* tuning, int debug, void* stream_)
 {
     (void)prefiltered;  // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
     hipStream_t stream = (hipStream_t)stream_;
@@ -160,6 +160,7 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
     result_host->num_rendered = 0;
     result_host->max_tile_count = 0;
+    result_host->num_slots = 0;
     if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:85
     if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
@@ -177,15 +178,19 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     const int T = cam.gx * cam.gy;
 
     GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(0, P, D, M, cam, means3D, scales, rotations, opacities, features, shs,
-                                    cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr, stream),
+                                    cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr,
+                                    !(tuning && tuning->disable_tile_cull), stream),
               "preprocess");
     GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, stream), "tile count / scans");
-    uint32_t info[2] = { 0, 0 };
+    uint32_t info[2] = { 0, 0 }, nslots = 0;
     GSR_HIP(hipMemcpyAsync(info, image.info, sizeof(info), hipMemcpyDeviceToHost, stream), "read num_rendered");
+    GSR_HIP(hipMemcpyAsync(&nslots, geom.scan_sums + gsr_scan_blocks(P), 4, hipMemcpyDeviceToHost, stream), "read num_slots");
     GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
-    if (info[0] > 0x7fffffffu) return gsr_fail(GSR_ERR_UNSUPPORTED, "num_rendered %u overflows int32", info[0]);
+    if (info[0] > 0x7fffffffu || nslots > 0x7fffffffu)
+        return gsr_fail(GSR_ERR_UNSUPPORTED, "instance count %u / %u overflows int32", info[0], nslots);
     result_host->num_rendered = (int32_t)info[0];
     result_host->max_tile_count = (int32_t)info[1];
+    result_host->num_slots = (int32_t)nslots;
     return GSR_OK;
 }
 
@@ -282,7 +287,7 @@ extern "C" int gsr_filter(int P, int W, int H, const float* means3D, const float
     int rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, nullptr, tan_fovx, tan_fovy, scale_modifier, stream);
     if (rc) return rc;
     GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(px ? 2 : 1, P, 0, 0, cam, means3D, scales, rotations, nullptr, nullptr, nullptr,
-                                    cov3D_precomp, nullptr, nullptr, radii, px, py, stream),
+                                    cov3D_precomp, nullptr, nullptr, radii, px, py, 0, stream),
               "filter preprocess");
     return GSR_OK;
 }

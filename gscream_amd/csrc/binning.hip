@@ -12,7 +12,7 @@
 //
 // HBM traffic: hist reads rect (8 B/G); table NB*T*4 B written, scanned, read; scatter reads
 // 16 B/G and writes 8 B/instance + 16 B/G (record tail); sort reads 8 B and writes 4 B per instance.
-#include "gsr_common.h"
+#include "gsr_math.h"
 
 typedef unsigned long long u64;
 
@@ -100,6 +100,7 @@ __device__ __forceinline__ void gsr_chunk_bounds(int P, int nchunks, int chunk, 
 
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, int T, int gx, int nchunks,
                                                                         const uint2* __restrict__ rect,
+                                                                        const u64* __restrict__ tmask,
                                                                         uint32_t* __restrict__ table)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -110,8 +111,12 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
     for (int g = lo + threadIdx.x; g < hi; g += blockDim.x) {
         const uint2 rc = rect[g];
         const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+        if (x0 == x1 || y0 == y1) continue;
+        const u64 mask = tmask[g];
+        int i = 0;
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) atomicAdd(&hist[y * gx + x], 1u);
+            for (int x = x0; x < x1; x++, i++)
+                if (gsr_mask_bit(mask, i)) atomicAdd(&hist[y * gx + x], 1u);
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -177,7 +182,8 @@ __global__ void __launch_bounds__(256) gsr_tile_scan_kernel(int T, const uint32_
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const uint32_t* __restrict__ depthkey,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const u64* __restrict__ tmask,
+    const uint32_t* __restrict__ table,
     const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, u64* __restrict__ seg_keys)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
@@ -193,8 +199,11 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         if (nt == 0) continue;
         const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
         const u64 key = ((u64)depthkey[g] << 32) | (uint32_t)g;
+        const u64 mask = tmask[g];
+        int i = 0;
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
+            for (int x = x0; x < x1; x++, i++) {
+                if (!gsr_mask_bit(mask, i)) continue;
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
                 seg_keys[slot] = key;
             }
@@ -285,7 +294,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
                                        (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_tile_hist_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, image.table);
+                       geom.rect, geom.tmask, image.table);
     // (3) column scan -> per-(chunk, tile) offsets + tile totals, then tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
                        image.tile_count);
@@ -303,7 +312,7 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
                                        (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.depthkey, geom.offsets, geom.tiles, image.table, image.ranges, geom.rec,
+                       geom.rect, geom.depthkey, geom.offsets, geom.tiles, geom.tmask, image.table, image.ranges, geom.rec,
                        bin.seg_keys);
     return hipGetLastError();
 }

@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
     int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
-    const uint32_t* __restrict__ offsets, const float4* __restrict__ slots, float* __restrict__ dL_dmeans2D,
+    const uint32_t* __restrict__ offsets, const unsigned long long* __restrict__ tmask,
+    const float4* __restrict__ slots, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeatures,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
@@ -114,7 +115,9 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
         const uint2 rc = rect[idx];
         const int nt = (int)(((rc.x >> 16) - (rc.x & 0xffff)) * ((rc.y >> 16) - (rc.y & 0xffff)));
         const float4* s = slots + (size_t)offsets[idx] * 3;
+        const unsigned long long mask = tmask[idx];
         for (int j = 0; j < nt; j++) {
+            if (!gsr_mask_bit(mask, j)) continue;  // culled instances were never binned: their slot is unwritten
             const float4 a = s[3 * j], b = s[3 * j + 1], c = s[3 * j + 2];
             acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
             acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
@@ -251,7 +254,7 @@ hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, con
 {
     if (P <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_gauss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, cam, means3D, radii,
-                       shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets,
+                       shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets, geom.tmask,
                        reinterpret_cast<const float4*>(slots), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures,
                        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
     return hipGetLastError();

@@ -9,6 +9,7 @@
 //           depthkey[P]   4 B  float bits of view-space depth (positive floats sort as uints)
 //           tiles[P]      4 B  tiles touched
 //           offsets[P]    4 B  exclusive scan of tiles = first gradient slot of the Gaussian
+//           tmask[P]      8 B  which tiles of the rectangle the Gaussian can actually change (tile culling)
 //           clamped[P*3]  1 B  SH clamp flags (only with SH colours)
 //           scan block sums
 //   image : ranges[T]     8 B  [start,end) of each tile in the sorted list
@@ -46,6 +47,7 @@ struct GsrGeom {
     uint32_t* depthkey;
     uint32_t* tiles;
     uint32_t* offsets;
+    unsigned long long* tmask;  // survivor bit per tile of the rectangle (row-major, first 64 tiles)
     uint8_t* clamped;
     uint32_t* scan_sums;
     size_t bytes;
@@ -90,6 +92,7 @@ static inline GsrGeom gsr_carve_geom(void* base, int P)
     g.depthkey = (uint32_t*)(b + off); off += gsr_align(p * 4);
     g.tiles = (uint32_t*)(b + off); off += gsr_align(p * 4);
     g.offsets = (uint32_t*)(b + off); off += gsr_align(p * 4);
+    g.tmask = (unsigned long long*)(b + off); off += gsr_align(p * 8);
     g.clamped = (uint8_t*)(b + off); off += gsr_align(p * 3);
     g.scan_sums = (uint32_t*)(b + off); off += gsr_align((size_t)(gsr_scan_blocks((int)p) + 1) * 4);
     g.bytes = off;
@@ -140,7 +143,7 @@ hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& ca
                                  const float* scales, const float* rotations, const float* opacities,
                                  const float* features, const float* shs, const float* cov3D_precomp,
                                  const float* colors_precomp, const GsrGeom* geom, int32_t* radii, float* px, float* py,
-                                 hipStream_t stream);
+                                 int tile_cull, hipStream_t stream);
 hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                    hipStream_t stream);
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream);

@@ -99,6 +99,43 @@ __device__ __forceinline__ void gsr_cov2d(const float3 mean, const GsrCam& cam, 
     o.a = c00 + 0.3f; o.b = c01; o.c = c11 + 0.3f;
 }
 
+// Minimum over the pixel box [bx0,bx1] x [by0,by1] of q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy with
+// d = mean - pixel, i.e. of -power (DGR forward.cu:523): exact for a convex quadratic -- 0 if the mean is
+// inside the box, otherwise the smallest of the four clamped 1-D edge minima.
+__device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, float B, float C, float bx0, float bx1,
+                                               float by0, float by1)
+{
+    const float dx0 = mx - bx1, dx1 = mx - bx0, dy0 = my - by1, dy1 = my - by0;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return 0.f;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const float ex = e ? dx1 : dx0;
+        const float dy = fminf(dy1, fmaxf(dy0, -B * ex / C));
+        best = fminf(best, 0.5f * (A * ex * ex + C * dy * dy) + B * ex * dy);
+        const float ey = e ? dy1 : dy0;
+        const float dx = fminf(dx1, fmaxf(dx0, -B * ey / A));
+        best = fminf(best, 0.5f * (A * dx * dx + C * ey * ey) + B * dx * ey);
+    }
+    return best;
+}
+
+// Tile culling.  A (Gaussian, tile) instance can change a pixel only if alpha = opacity * exp(power) reaches
+// 1/255 somewhere in the tile (DGR forward.cu:534 skips everything below), i.e. iff min q <= ln(255 opacity).
+// Instances that fail the test (with a 0.01 safety margin on q, far above fp32 rounding of `power`) are not
+// binned: images and gradients are unchanged, the lists the blend kernels walk get ~2.5x shorter.
+// NaNs compare false, so a degenerate conic keeps the instance.
+#define GSR_CULL_MARGIN 0.01f
+__device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, float B, float C, float tau, int tx,
+                                                  int ty, int W, int H)
+{
+    const float bx0 = (float)(tx * 16), by0 = (float)(ty * 16);
+    const float bx1 = (float)min(tx * 16 + 15, W - 1), by1 = (float)min(ty * 16 + 15, H - 1);
+    return !(gsr_box_min_q(mx, my, A, B, C, bx0, bx1, by0, by1) > tau + GSR_CULL_MARGIN);
+}
+// survivor bit of rectangle position i (row-major); rectangles larger than 64 tiles keep their tail
+__device__ __forceinline__ bool gsr_mask_bit(unsigned long long mask, int i) { return i >= 64 || ((mask >> i) & 1ull); }
+
 // Spherical-harmonics constants (DGR auxiliary.h:22-39)
 #define GSR_SH_C0 0.28209479177387814f
 #define GSR_SH_C1 0.4886025119029199f

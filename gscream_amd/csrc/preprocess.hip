@@ -48,11 +48,11 @@ __device__ __forceinline__ float3 gsr_sh_to_rgb(int idx, int deg, int M, float3 
 // MODE 0: full preprocess (writes the geometry state)   MODE 1: radii only   MODE 2: radii + px/py
 template <int MODE>
 __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
-    int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const float* __restrict__ scales,
+    int P, int D, int M, int tile_cull, const GsrCam cam, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ features,
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     GsrRec* __restrict__ rec, uint2* __restrict__ rect, uint32_t* __restrict__ depthkey, uint32_t* __restrict__ tiles,
-    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, float* __restrict__ out_px, float* __restrict__ out_py)
+    unsigned long long* __restrict__ tmask, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, float* __restrict__ out_px, float* __restrict__ out_py)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
@@ -116,6 +116,17 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
     rect[idx] = rc;
     tiles[idx] = ntiles;
     depthkey[idx] = __float_as_uint(viewz);
+    unsigned long long mask = ~0ull;
+    if (radius > 0 && tile_cull) {
+        const float tau = logf(255.0f * opacities[idx]);
+        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+        mask = 0ull;
+        int i = 0;
+        for (int y = y0; y < y1 && i < 64; y++)
+            for (int x = x0; x < x1 && i < 64; x++, i++)
+                if (gsr_tile_survives(pix, piy, conx, cony, conz, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
+    }
+    tmask[idx] = mask;
     if (radius > 0) {
         float3 col;
         if (colors_precomp) col = make_float3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
@@ -142,22 +153,22 @@ hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& ca
                                  const float* scales, const float* rotations, const float* opacities,
                                  const float* features, const float* shs, const float* cov3D_precomp,
                                  const float* colors_precomp, const GsrGeom* g, int32_t* radii, float* px, float* py,
-                                 hipStream_t stream)
+                                 int tile_cull, hipStream_t stream)
 {
     if (P <= 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
     if (mode == 0)
-        hipLaunchKernelGGL(gsr_preprocess_kernel<0>, grid, block, 0, stream, P, D, M, cam, means3D, scales, rotations,
+        hipLaunchKernelGGL(gsr_preprocess_kernel<0>, grid, block, 0, stream, P, D, M, tile_cull, cam, means3D, scales, rotations,
                            opacities, features, shs, cov3D_precomp, colors_precomp, g->rec, g->rect, g->depthkey,
-                           g->tiles, g->clamped, radii, nullptr, nullptr);
+                           g->tiles, g->tmask, g->clamped, radii, nullptr, nullptr);
     else if (mode == 1)
-        hipLaunchKernelGGL(gsr_preprocess_kernel<1>, grid, block, 0, stream, P, D, M, cam, means3D, scales, rotations,
+        hipLaunchKernelGGL(gsr_preprocess_kernel<1>, grid, block, 0, stream, P, D, M, 0, cam, means3D, scales, rotations,
                            nullptr, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, radii, nullptr, nullptr);
+                           nullptr, nullptr, radii, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(gsr_preprocess_kernel<2>, grid, block, 0, stream, P, D, M, cam, means3D, scales, rotations,
+        hipLaunchKernelGGL(gsr_preprocess_kernel<2>, grid, block, 0, stream, P, D, M, 0, cam, means3D, scales, rotations,
                            nullptr, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, radii, px, py);
+                           nullptr, nullptr, radii, px, py);
     return hipGetLastError();
 }
 

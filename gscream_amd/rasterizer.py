@@ -22,12 +22,16 @@ import torch.nn as nn
 from . import _native
 
 _tuning = _native.Tuning()
+_last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
-def set_tuning(pixels_per_thread_fwd=0, pixels_per_thread_bwd=0):
-    """Performance knobs of the blend kernels (0 = library default).  Results do not depend on them."""
+def set_tuning(pixels_per_thread_fwd=0, pixels_per_thread_bwd=0, tile_cull=True):
+    """Performance knobs (0 = library default).  Images, radii and gradients do not depend on them;
+    tile_cull=False bins every tile of every rectangle, which makes the internal per-tile lists and
+    num_rendered bit-identical to the reference's."""
     _tuning.pixels_per_thread_fwd = int(pixels_per_thread_fwd)
     _tuning.pixels_per_thread_bwd = int(pixels_per_thread_bwd)
+    _tuning.disable_tile_cull = 0 if tile_cull else 1
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -92,7 +96,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     u8 = dict(dtype=torch.uint8, device=dev)
     if P == 0:
         e = torch.empty((0,), **u8)
-        return 0, color, depth, unc, radii, e, e.clone(), e.clone()
+        return 0, color, depth, unc, radii, e, e.clone(), e.clone(), 0
 
     means3D_c, opac_c, unc_c = _f32c(means3D), _f32c(opacities), _f32c(uncertainties)
     scales_c, rot_c, cov_c = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
@@ -111,7 +115,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
             _native.ptr(rot_c), _native.ptr(opac_c), _native.ptr(unc_c), _native.ptr(sh_c), _native.ptr(cov_c),
             _native.ptr(colors_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos), float(rs.tanfovx),
             float(rs.tanfovy), int(bool(rs.prefiltered)), _native.ptr(geom), _native.ptr(img), _native.ptr(radii),
-            _native.ctypes.byref(res), int(bool(rs.debug)), stream)
+            _native.ctypes.byref(res), _native.ctypes.byref(_tuning), int(bool(rs.debug)), stream)
         _native.check(rc, "gsr_forward_stage1")
         R = int(res.num_rendered)
         binning = torch.empty((lib.gsr_binning_bytes(R),), **u8)
@@ -120,10 +124,11 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
             _native.ptr(binning), _native.ptr(color), _native.ptr(depth), _native.ptr(unc),
             _native.ctypes.byref(_tuning), int(bool(rs.debug)), stream)
         _native.check(rc, "gsr_forward_stage2")
-    return R, color, depth, unc, radii, geom, binning, img
+    _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots))
+    return R, color, depth, unc, radii, geom, binning, img, int(res.num_slots)
 
 
-def _backward_native(rs, num_rendered, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
+def _backward_native(rs, num_rendered, num_slots, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
                      geom, binning, img, g_color, g_depth, g_unc):
     """The work of `_C.rasterize_gaussians_backward` (DGR rasterize_points.cu:124-211)."""
     lib = _native.load()
@@ -150,7 +155,7 @@ def _backward_native(rs, num_rendered, means3D, radii, colors_precomp, sh, scale
     # could hand its block to the next temporary
     means3D_c, colors_c, sh_c = _f32c(means3D), _f32c(colors_precomp, dev), _f32c(sh, dev)
     scales_c, rot_c, cov_c = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
-    scratch = torch.empty((lib.gsr_backward_scratch_bytes(P, num_rendered),), dtype=torch.uint8, device=dev)
+    scratch = torch.empty((lib.gsr_backward_scratch_bytes(P, num_slots),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gsr_backward(
             P, int(rs.sh_degree), M, W, H, int(num_rendered), _native.ptr(bg), _native.ptr(means3D_c),
@@ -185,9 +190,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         else:
             out = _forward_native(*args)
-        num_rendered, color, depth, uncertainty, radii, geom, binning, img = out
+        num_rendered, color, depth, uncertainty, radii, geom, binning, img, num_slots = out
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.num_slots = num_slots
         ctx.opacity_shape, ctx.uncertainty_shape = opacities.shape, uncertainties.shape
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
@@ -197,7 +203,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, grad_out_depth, grad_out_uncertainty, _grad_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        args = (rs, ctx.num_rendered, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
+        args = (rs, ctx.num_rendered, ctx.num_slots, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
                 geom, binning, img, grad_out_color, grad_out_depth, grad_out_uncertainty)
         if rs.debug:
             saved = _snapshot(args)

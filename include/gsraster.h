@@ -44,16 +44,22 @@ typedef enum gsr_status {
 
 /* Result of forward stage 1, written to host memory (pinned memory avoids a staging copy). */
 typedef struct gsr_stage1_result {
-    int32_t num_rendered;  /* R: number of (Gaussian, tile) instances; the reference's return value
-                              of CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:346) */
+    int32_t num_rendered;  /* R: number of binned (Gaussian, tile) instances.  With tile culling disabled this
+                              is the reference's return value of Rasterizer::forward (rasterizer_impl.cu:346) */
     int32_t max_tile_count; /* longest per-tile list; selects the per-tile sort variant */
+    int32_t num_slots;      /* sum of tiles_touched over all Gaussians (every tile of every rectangle):
+                               the number of gradient slots the backward scratch must hold */
+    int32_t reserved;
 } gsr_stage1_result;
 
 /* Tunables; zero-initialise for defaults.  Pure performance knobs: results do not depend on them. */
 typedef struct gsr_tuning {
     int32_t pixels_per_thread_fwd; /* 0 = default; 1, 2 or 4 */
     int32_t pixels_per_thread_bwd; /* 0 = default; 1, 2 or 4 */
-    int32_t reserved[6];
+    int32_t disable_tile_cull;     /* 1 = bin every tile of the rectangle like the reference (lists become
+                                      bit-identical to the reference's; slower).  Default 0: skip tiles the
+                                      Gaussian cannot change (see gsr_math.h) */
+    int32_t reserved[5];
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */
@@ -74,7 +80,7 @@ int gsr_device_count(void);
 size_t gsr_geom_bytes(int P);                 /* per-Gaussian state kept from forward to backward   */
 size_t gsr_image_bytes(int P, int W, int H);  /* per-pixel / per-tile state kept forward -> backward */
 size_t gsr_binning_bytes(int R);              /* per-instance state: sorted point list (+ sort keys)  */
-size_t gsr_backward_scratch_bytes(int P, int R); /* per-instance gradient slots used inside backward  */
+size_t gsr_backward_scratch_bytes(int P, int num_slots); /* per-instance gradient slots used inside backward */
 
 /*
  * Forward, stage 1 of 2: per-Gaussian preprocess + tile histogram + scans.
@@ -93,7 +99,7 @@ int gsr_forward_stage1(int P, int D, int M, int W, int H,
                        const float* viewmatrix, const float* projmatrix, const float* campos,
                        float tan_fovx, float tan_fovy, int prefiltered,
                        void* geom, void* image, int32_t* radii, gsr_stage1_result* result_host,
-                       int debug, void* stream);
+                       const gsr_tuning* tuning, int debug, void* stream);
 
 /*
  * Forward, stage 2 of 2: instance scatter into per-tile segments, per-tile depth sort, blend.

@@ -82,7 +82,7 @@ def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False):
         # same call, but through the internal entry so the opaque workspaces can be decoded
         e = torch.Tensor([])
         g = lambda k: kw[k].detach() if k in kw else e
-        R, color, depth, unc, radii, geom, binning, img = RZ._forward_native(
+        R, color, depth, unc, radii, geom, binning, img, _ns = RZ._forward_native(
             inp["means3D"].detach(), g("shs"), g("colors_precomp"), inp["opacities"].detach(),
             inp["uncertainties"].detach(), g("scales"), g("rotations"), g("cov3D_precomp"), rs)
         out.update(num_rendered=R, geom=geom, binning=binning, img=img)

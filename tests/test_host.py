@@ -49,16 +49,16 @@ def test_argument_validation_without_gpu(native_lib):
     from gscream_amd import _native
     res = _native.Stage1Result()
     rc = native_lib.gsr_forward_stage1(-1, 0, 0, 64, 64, None, None, 1.0, None, None, None, None, None, None, None, None,
-                                       None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), 0, None)
+                                       None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
     assert rc == -1 and b"P must be" in native_lib.gsr_last_error()
     rc = native_lib.gsr_forward_stage1(10, 0, 0, 0, 64, None, None, 1.0, None, None, None, None, None, None, None, None,
-                                       None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), 0, None)
+                                       None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
     assert rc == -1
     rc = native_lib.gsr_forward_stage1(10, 0, 0, 16 * 4000, 16 * 4000, None, None, 1.0, None, None, None, None, None, None,
-                                       None, None, None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), 0, None)
+                                       None, None, None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
     assert rc == -3  # unsupported: more tiles than the LDS histogram holds
     rc = native_lib.gsr_forward_stage1(0, 0, 0, 64, 64, None, None, 1.0, None, None, None, None, None, None, None, None,
-                                       None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), 0, None)
+                                       None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
     assert rc == 0 and res.num_rendered == 0  # P == 0 short-circuits (DGR rasterize_points.cu:85)
     with pytest.raises(RuntimeError, match="native call"):
         _native.check(-1, "x")
