@@ -205,7 +205,7 @@ def main():
             "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,
                        "visible": visible, "tile_cull": not args.no_tile_cull,
                        "parallelism": f"{world} independent scene(s), one per GPU, barrier only",
-                       "pixels_per_thread": [args.ppt_fwd or 2, args.ppt_bwd or 2]},
+                       "pixels_per_thread": [args.ppt_fwd or 1, args.ppt_bwd or 1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": model[dom], "avg_launch_ms": stages[dom]["avg_ms"]},

@@ -218,7 +218,7 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, R, max_tile_count, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth, out_feature,
-                                       gsr_pick_ppt(tuning, 0, 2), stream),
+                                       gsr_pick_ppt(tuning, 0, 1), stream),
               "forward blend");
     return GSR_OK;
 }
@@ -261,7 +261,7 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const floa
     float* slots = (float*)scratch;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
-                                            dL_dout_feature, slots, gsr_pick_ppt(tuning, 1, 2), stream),
+                                            dL_dout_feature, slots, gsr_pick_ppt(tuning, 1, 1), stream),
                   "backward blend");
     GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots,
                                         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures, dL_dmeans3D, dL_dcov3D,
