@@ -107,8 +107,6 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--ppt-fwd", type=int, default=0)
-    ap.add_argument("--ppt-bwd", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tile-cull", action="store_true", help="bin every rectangle tile like the reference")
     args = ap.parse_args()
@@ -129,7 +127,7 @@ def main():
     from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer, _native, set_tuning
     from gscream_amd import synthetic as S
     _native.load()
-    set_tuning(args.ppt_fwd, args.ppt_bwd, tile_cull=not args.no_tile_cull)
+    set_tuning(tile_cull=not args.no_tile_cull)
 
     P, W, H, seed, gsel, desc = WORKLOADS[args.workload]
     s = S.scene_slab(seed + 10 * rank if world > 1 else seed, P, W, H)  # one independent scene per GPU
@@ -147,7 +145,9 @@ def main():
 
     def step():
         color, depth, feat, radii = rast(means3D, means2D, opac, unc, colors_precomp=colors, scales=scales, rotations=rots)
-        torch.autograd.grad([color, depth, feat], inputs, [gc, gd, gu])
+        outs = [o for o, use in zip((color, depth, feat), gsel) if use]
+        gos = [g for g, use in zip((gc, gd, gu), gsel) if use]
+        torch.autograd.grad(outs, inputs, gos)  # maps the loss does not use get no gradient, as in training
         return radii
 
     def barrier():
@@ -204,8 +204,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,
                        "visible": visible, "tile_cull": not args.no_tile_cull,
-                       "parallelism": f"{world} independent scene(s), one per GPU, barrier only",
-                       "pixels_per_thread": [args.ppt_fwd or 1, args.ppt_bwd or 1]},
+                       "parallelism": f"{world} independent scene(s), one per GPU, barrier only"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": model[dom], "avg_launch_ms": stages[dom]["avg_ms"]},

@@ -25,8 +25,7 @@ class Stage1Result(ctypes.Structure):
 
 
 class Tuning(ctypes.Structure):
-    _fields_ = [("pixels_per_thread_fwd", ctypes.c_int32), ("pixels_per_thread_bwd", ctypes.c_int32),
-                ("disable_tile_cull", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+    _fields_ = [("disable_tile_cull", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
 
 
 class Profile(ctypes.Structure):

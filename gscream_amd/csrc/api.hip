@@ -194,12 +194,6 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     return GSR_OK;
 }
 
-static int gsr_pick_ppt(const gsr_tuning* t, int which, int dflt)
-{
-    int v = t ? (which ? t->pixels_per_thread_bwd : t->pixels_per_thread_fwd) : 0;
-    return (v == 1 || v == 2 || v == 4) ? v : dflt;
-}
-
 extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const float* background,
                                   void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                                   float* out_feature, const gsr_tuning* tuning, int debug, void* stream_)
@@ -217,8 +211,7 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     const GsrBinning bin = gsr_carve_binning(binning_ws, R);
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, R, max_tile_count, image, bin, stream), "tile sort");
-    GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth, out_feature,
-                                       gsr_pick_ppt(tuning, 0, 1), stream),
+    GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth, out_feature, stream),
               "forward blend");
     return GSR_OK;
 }
@@ -239,8 +232,7 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const floa
     int rc = gsr_check_dims(P, W, H);
     if (rc) return rc;
     if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:172
-    if (!background || !means3D || !radii || !viewmatrix || !projmatrix || !dL_dout_color || !dL_dout_depth ||
-        !dL_dout_feature || !geom_ws || !image_ws || !binning_ws || !scratch || !dL_dmeans2D || !dL_dcolors ||
+    if (!background || !means3D || !radii || !viewmatrix || !projmatrix || !dL_dout_color || !geom_ws || !image_ws || !binning_ws || !scratch || !dL_dmeans2D || !dL_dcolors ||
         !dL_dopacity || !dL_dfeatures || !dL_dmeans3D)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if ((!scales || !rotations) == (cov3D_precomp == nullptr))
@@ -261,7 +253,7 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const floa
     float* slots = (float*)scratch;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
-                                            dL_dout_feature, slots, gsr_pick_ppt(tuning, 1, 1), stream),
+                                            dL_dout_feature, slots, stream),
                   "backward blend");
     GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots,
                                         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures, dL_dmeans3D, dL_dcov3D,

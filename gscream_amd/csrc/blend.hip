@@ -2,30 +2,34 @@
 //
 // Replaces DGR forward.cu:441-568 renderCUDA (fwd) and backward.cu:409-604 renderCUDA (bwd).
 //
-// Mapping onto CDNA4.  One workgroup per 16x16 screen tile.  PPT = pixels per thread (1, 2 or 4):
-// the workgroup has 256/PPT threads = 4/2/1 wavefronts of 64; lane l of wave w owns column
-// (l & 15) and rows  4w + (l >> 4) + k * (16/PPT),  k < PPT.  So one DPP "row" of 16 lanes is one
-// pixel row of the tile, and a wavefront owns whole pixel rows.
-//   * Tile lists are consumed in batches of 256 instances.  Each thread gathers the 64-byte record
-//     of its instance(s) with three (fwd) / four (bwd) 16-byte loads and parks it in LDS as three
-//     float4 SoA arrays; the inner loop reads them back as same-address (broadcast) ds_read_b128,
-//     conflict-free.  The reference re-reads colour and depth from global memory for every
-//     (pixel, Gaussian) contribution (forward.cu:545-546).
-//   * Early-out is wave-granular: a wave leaves the batch loop when all of its pixels are done
-//     (__all), and in the backward a wave skips gradient math + reduction for an instance none of
-//     its pixels sees (__any); the block leaves when every wave is done (__syncthreads_and).
-//   * Backward gradient scatter: the reference issues 11 global atomicAdd per (pixel, Gaussian)
-//     contribution (backward.cu:554-601).  Here the 11 partials are summed over the PPT pixels of a
-//     lane in registers, over the 16 lanes of a row with 4 DPP adds, and the 4 row leaders of a wave
-//     add into an LDS accumulator [256][12] (ds_add_f32).  After the batch every thread stores the
-//     12 floats of its instance with three plain 16-byte stores into that instance's private
-//     gradient slot (slot = Gaussian's scan offset + tile position inside its rectangle).  The
-//     per-Gaussian kernel (gauss_bwd.hip) then sums each Gaussian's contiguous slots in a fixed
-//     order: no global atomics at all, and gradients are bit-reproducible.
-//   * XCD awareness: workgroup b runs on XCD b % 8 (observed dispatch rule); the block->tile map
-//     hands each XCD a contiguous band of tile rows so neighbouring tiles, which share most of their
-//     Gaussians, hit the same 4 MiB L2.  Pure speed: any placement gives the same result.
-#include "gsr_common.h"
+// Mapping onto CDNA4.  One 256-thread workgroup (4 wavefronts of 64) per 16x16 screen tile; wavefront w owns
+// the 8x8 pixel QUADRANT (w & 1, w >> 1) of the tile, lane l the pixel (l & 7, l >> 3) inside it.
+//   * Tile lists are consumed in batches of 256 instances.  Thread i gathers the 64-byte record of instance i
+//     (three 16-byte loads fwd, four bwd) into LDS as float4 SoA arrays, and -- once per instance, not once per
+//     pixel -- tests the Gaussian's alpha >= 1/255 ellipse against the four quadrant boxes (gsr_box_min_q).
+//     Each wave then compacts, with ballot + mbcnt, the indices of the instances that can reach ITS quadrant
+//     into a private LDS list and walks only those: a typical splat touches 1-2 of the 4 quadrants, so the
+//     per-pixel test loop shrinks accordingly and the hit rate of what remains goes up.  The reference tests
+//     every instance of the tile against all 256 pixels (forward.cu:513-553).
+//   * Per-Gaussian operands are read back from LDS with same-address (broadcast) ds_read_b128: conflict-free.
+//     The reference re-reads colour and depth from GLOBAL memory per contribution (forward.cu:545-546).
+//   * Early-out: a wave leaves the batch when all its pixels are done (__all); in the backward a wave skips
+//     gradient math + reduction when none of its pixels blends the instance (__any); the block leaves when
+//     every wave is done (__syncthreads_and).
+//   * Backward gradient scatter: the reference issues 11 global atomicAdd per (pixel, Gaussian) contribution
+//     (backward.cu:554-601).  Here the 11 partials are summed over the 16 lanes of a DPP row with 4 DPP adds
+//     and the 4 row leaders of a wave add them into an LDS accumulator [256][12] with ONE ds_add_f32 each
+//     (built with -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch,
+//     thread i stores the 12 floats of instance i with three plain 16-byte stores into that instance's private
+//     gradient slot (slot = Gaussian's scan offset + tile position inside its rectangle); gauss_bwd.hip sums
+//     each Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a tile's <= 16 row leaders
+//     are unordered, so two runs agree to rounding, not bit for bit.)
+//   * AUX = false specialises the backward for "no gradient flows into the depth and feature maps" (GScream's
+//     RGB-only iterations): 9 instead of 11 reductions and no depth/feature recurrences.
+//   * XCD awareness: workgroup b runs on XCD b % 8 (observed dispatch rule); the block->tile map hands each
+//     XCD a contiguous band of tile rows so neighbouring tiles, which share most of their Gaussians, hit the
+//     same 4 MiB L2.  Pure speed: any placement gives the same result.
+#include "gsr_math.h"
 
 #define GSR_BATCH 256
 
@@ -62,230 +66,241 @@ __device__ __forceinline__ float gsr_row_sum16(float v)
     return v;
 }
 
+// 4-bit mask of the 8x8 quadrants of tile (tx, ty) in which the Gaussian can reach alpha >= 1/255.
+__device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const float4 B, const float tau, int tx, int ty,
+                                                      int W, int H)
+{
+    const float rA = GSR_RCP(A.z), rC = GSR_RCP(B.x);
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x0 = tx * 16 + (q & 1) * 8, y0 = ty * 16 + (q >> 1) * 8;
+        const float bx1 = (float)min(x0 + 7, W - 1), by1 = (float)min(y0 + 7, H - 1);
+        const bool hit = x0 < W && y0 < H &&
+                         !(gsr_box_min_q(A.x, A.y, A.z, A.w, B.x, rA, rC, (float)x0, bx1, (float)y0, by1) > tau);
+        m |= hit ? (1u << q) : 0u;
+    }
+    return m;
+}
+
+// Wave-private compaction: indices i < cnt with bit `wave` set in sQ[i] and pred(i), in ascending order.
+template <typename Pred>
+__device__ __forceinline__ int gsr_compact(const uint32_t* sQ, uint16_t* list, int cnt, int wave, int lane, Pred pred)
+{
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < GSR_BATCH / 64; c++) {
+        const int i = c * 64 + lane;
+        const bool hit = i < cnt && ((sQ[i] >> wave) & 1u) && pred(i);
+        const unsigned long long bal = __ballot(hit);
+        if (hit) list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)i;
+        n += __popcll(bal);
+    }
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------
-template <int PPT>
-__global__ void __launch_bounds__(256 / PPT) gsr_blend_fwd_kernel(
+__global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
-    constexpr int NT = 256 / PPT, ROWS = 16 / PPT;
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
+    __shared__ uint32_t sQ[GSR_BATCH];
+    __shared__ uint16_t sList[4][GSR_BATCH];
 
     const int tile = gsr_tile_of_block(blockIdx.x, T);
     const int tx = tile % gx, ty = tile / gx;
-    const int t = threadIdx.x;
-    const int px = tx * 16 + (t & 15);
-    const float pxf = (float)px;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
+    const bool inside = px < W && py < H;
 
-    int py[PPT];
-    float pyf[PPT], Tr[PPT], C0[PPT], C1[PPT], C2[PPT], Dp[PPT], Uf[PPT];
-    uint32_t last[PPT];
-    bool done[PPT], inside[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        py[k] = ty * 16 + (t >> 4) + k * ROWS;
-        pyf[k] = (float)py[k];
-        inside[k] = px < W && py[k] < H;
-        done[k] = !inside[k];
-        Tr[k] = 1.0f; C0[k] = C1[k] = C2[k] = Dp[k] = Uf[k] = 0.f; last[k] = 0;
-    }
+    bool done = !inside;
+    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Uf = 0.f;
+    uint32_t last = 0;
+    uint16_t* mylist = sList[wave];
 
     for (int base = 0; base < n; base += GSR_BATCH) {
-        bool all_done = true;
-#pragma unroll
-        for (int k = 0; k < PPT; k++) all_done = all_done && done[k];
-        if (__syncthreads_and(all_done)) break;  // also fences the previous batch's LDS reads
-
-        for (int i = t; i < GSR_BATCH; i += NT) {
-            const int p = base + i;
-            if (p < n) {
-                const float4* r = reinterpret_cast<const float4*>(rec + point_list[rg.x + p]);
-                sA[i] = r[0]; sB[i] = r[1]; sC[i] = r[2];
-            }
+        if (__syncthreads_and(done)) break;  // also fences the previous batch's LDS reads
+        const int cnt = min(GSR_BATCH, n - base);
+        if (t < cnt) {
+            const float4* r = reinterpret_cast<const float4*>(rec + point_list[rg.x + base + t]);
+            const float4 a = r[0], b = r[1], c = r[2];
+            sA[t] = a; sB[t] = b; sC[t] = c;
+            sQ[t] = gsr_quadrant_mask(a, b, c.w, tx, ty, W, H);
         }
         __syncthreads();
+        const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [](int) { return true; });
+        __builtin_amdgcn_wave_barrier();
 
-        const int cnt = min(GSR_BATCH, n - base);
-        for (int j = 0; j < cnt; j++) {
-            if (__all(all_done)) break;  // wave-uniform
+        for (int k = 0; k < nw; k++) {
+            if (__all(done)) break;  // wave-uniform
+            const int j = mylist[k];
             const float4 A = sA[j], B = sB[j], C = sC[j];
-            all_done = true;
-#pragma unroll
-            for (int k = 0; k < PPT; k++) {
-                const float dx = A.x - pxf, dy = A.y - pyf[k];
-                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float alpha = fminf(0.99f, B.y * GSR_EXP(power));
-                bool ok = !done[k] && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                const float test_T = Tr[k] * (1.0f - alpha);
-                const bool stop = ok && test_T < 0.0001f;
-                done[k] = done[k] || stop;
-                ok = ok && !stop;
-                const float w = ok ? alpha * Tr[k] : 0.0f;
-                C0[k] += C.x * w; C1[k] += C.y * w; C2[k] += C.z * w;
-                Dp[k] += B.z * w; Uf[k] += B.w * w;
-                Tr[k] = ok ? test_T : Tr[k];
-                last[k] = ok ? (uint32_t)(base + j + 1) : last[k];
-                all_done = all_done && done[k];
-            }
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float alpha = fminf(0.99f, B.y * GSR_EXP(power));
+            bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
+            const float test_T = Tr * (1.0f - alpha);
+            const bool stop = ok && test_T < 0.0001f;
+            done = done || stop;
+            ok = ok && !stop;
+            const float w = ok ? alpha * Tr : 0.0f;
+            C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
+            Dp += B.z * w; Uf += B.w * w;
+            Tr = ok ? test_T : Tr;
+            last = ok ? (uint32_t)(base + j + 1) : last;
         }
     }
 
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const size_t HW = (size_t)H * W;
-#pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        if (inside[k]) {
-            const size_t pid = (size_t)py[k] * W + px;
-            final_T[pid] = Tr[k];
-            n_contrib[pid] = last[k];
-            out_color[pid] = C0[k] + Tr[k] * bg0;
-            out_color[HW + pid] = C1[k] + Tr[k] * bg1;
-            out_color[2 * HW + pid] = C2[k] + Tr[k] * bg2;
-            out_depth[pid] = Dp[k];
-            out_feature[pid] = Uf[k];
-        }
+    if (inside) {
+        const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
+        final_T[pid] = Tr;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + Tr * bg[0];
+        out_color[HW + pid] = C1 + Tr * bg[1];
+        out_color[2 * HW + pid] = C2 + Tr * bg[2];
+        out_depth[pid] = Dp;
+        out_feature[pid] = Uf;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward
 // ---------------------------------------------------------------------------------------------
-template <int PPT>
-__global__ void __launch_bounds__(256 / PPT) gsr_blend_bwd_kernel(
+template <bool AUX>
+__global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dfeature, float4* __restrict__ slots)
 {
-    constexpr int NT = 256 / PPT, ROWS = 16 / PPT;
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ __attribute__((aligned(16))) float acc[GSR_BATCH * GSR_SLOT_FLOATS];
-    __shared__ uint32_t sSlot[GSR_BATCH];
+    __shared__ uint32_t sSlot[GSR_BATCH], sQ[GSR_BATCH];
+    __shared__ uint16_t sList[4][GSR_BATCH];
     __shared__ int sMax;
 
     const int tile = gsr_tile_of_block(blockIdx.x, T);
     const int tx = tile % gx, ty = tile / gx;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     if (n == 0) return;
 
-    const int px = tx * 16 + (t & 15);
-    const float pxf = (float)px;
+    const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
+    const bool inside = px < W && py < H;
+    const size_t pid = inside ? (size_t)py * W + px : 0;
 
-    float pyf[PPT], Tf[PPT], Tr[PPT], g0[PPT], g1[PPT], g2[PPT], gd[PPT], gu[PPT], bgdot[PPT];
-    float ar0[PPT], ar1[PPT], ar2[PPT], ard[PPT], aru[PPT], la[PPT], lc0[PPT], lc1[PPT], lc2[PPT], lcd[PPT], lcu[PPT];
-    int lastc[PPT];
-    int mymax = 0;
+    const float Tf = inside ? final_T[pid] : 0.f;
+    float Tr = Tf;
+    const int lastc = inside ? (int)n_contrib[pid] : 0;
+    const float g0 = inside ? dL_dcolor[pid] : 0.f, g1 = inside ? dL_dcolor[HW + pid] : 0.f;
+    const float g2 = inside ? dL_dcolor[2 * HW + pid] : 0.f;
+    float gd = 0.f, gu = 0.f;
+    if (AUX && inside) { gd = dL_ddepth[pid]; gu = dL_dfeature[pid]; }
+    const float bgdot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, ard = 0.f, aru = 0.f;
+    float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcd = 0.f, lcu = 0.f;
+
+    // wave-level and block-level maxima of the last contributor: nothing at a position >= them is blended
+    int wmax = lastc;
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        const int py = ty * 16 + (t >> 4) + k * ROWS;
-        pyf[k] = (float)py;
-        const bool inside = px < W && py < H;
-        const size_t pid = inside ? (size_t)py * W + px : 0;
-        Tf[k] = inside ? final_T[pid] : 0.f;
-        Tr[k] = Tf[k];
-        lastc[k] = inside ? (int)n_contrib[pid] : 0;
-        g0[k] = inside ? dL_dcolor[pid] : 0.f;
-        g1[k] = inside ? dL_dcolor[HW + pid] : 0.f;
-        g2[k] = inside ? dL_dcolor[2 * HW + pid] : 0.f;
-        gd[k] = inside ? dL_ddepth[pid] : 0.f;
-        gu[k] = inside ? dL_dfeature[pid] : 0.f;
-        bgdot[k] = bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k];
-        ar0[k] = ar1[k] = ar2[k] = ard[k] = aru[k] = 0.f;
-        la[k] = lc0[k] = lc1[k] = lc2[k] = lcd[k] = lcu[k] = 0.f;
-        mymax = max(mymax, lastc[k]);
-    }
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
     if (t == 0) sMax = 0;
-    for (int i = t; i < GSR_BATCH * GSR_SLOT_FLOATS; i += NT) acc[i] = 0.f;
+    for (int i = t; i < GSR_BATCH * GSR_SLOT_FLOATS; i += 256) acc[i] = 0.f;
     __syncthreads();
-    atomicMax(&sMax, mymax);
+    if (lane == 0) atomicMax(&sMax, wmax);
     __syncthreads();
-    const int nproc = min(n, sMax);  // instances at positions >= nproc contributed to no pixel of this tile
+    const int nproc = min(n, sMax);
+    uint16_t* mylist = sList[wave];
 
     // back to front, in batches of 256 instances; local j = 0 is the backmost instance of the batch
     for (int hi = n; hi > 0; hi -= GSR_BATCH) {
         const int lo = max(0, hi - GSR_BATCH), cnt = hi - lo;
         const bool active = lo < nproc;
-        for (int i = t; i < cnt; i += NT) {
-            const GsrRec* r = rec + point_list[rg.x + (hi - 1 - i)];
+        if (t < cnt) {
+            const GsrRec* r = rec + point_list[rg.x + (hi - 1 - t)];
             const uint4 d = r->d;
             const int x0 = d.y & 0xffff, x1 = d.y >> 16, y0 = d.z & 0xffff;
-            sSlot[i] = d.x + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-            if (active) { sA[i] = r->a; sB[i] = r->b; sC[i] = r->c; }
+            sSlot[t] = d.x + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            if (active) {
+                const float4 a = r->a, b = r->b, c = r->c;
+                sA[t] = a; sB[t] = b; sC[t] = c;
+                sQ[t] = gsr_quadrant_mask(a, b, c.w, tx, ty, W, H);
+            }
         }
         __syncthreads();
 
         if (active) {
-            for (int j = 0; j < cnt; j++) {
+            // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
+            const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [=](int i) { return hi - 1 - i < wmax; });
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < nw; k++) {
+                const int j = mylist[k];
                 const int p = hi - 1 - j;
-                if (p >= nproc) continue;  // block-uniform
                 const float4 A = sA[j], B = sB[j], C = sC[j];
-                float dx[PPT], dy[PPT], G[PPT], alpha[PPT];
-                bool ok[PPT], any_ok = false;
-#pragma unroll
-                for (int k = 0; k < PPT; k++) {
-                    dx[k] = A.x - pxf; dy[k] = A.y - pyf[k];
-                    const float power = -0.5f * (A.z * dx[k] * dx[k] + B.x * dy[k] * dy[k]) - A.w * dx[k] * dy[k];
-                    G[k] = GSR_EXP(power);
-                    alpha[k] = fminf(0.99f, B.y * G[k]);
-                    ok[k] = p < lastc[k] && power <= 0.0f && alpha[k] >= (1.0f / 255.0f);
-                    any_ok = any_ok || ok[k];
-                }
-                if (!__any(any_ok)) continue;  // wave-uniform: no pixel of this wave sees the instance
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                const float G = GSR_EXP(power);
+                const float alpha = fminf(0.99f, B.y * G);
+                const bool ok = p < lastc && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                if (!__any(ok)) continue;  // wave-uniform: no pixel of this quadrant blends the instance
 
                 float s[11];
 #pragma unroll
                 for (int v = 0; v < 11; v++) s[v] = 0.f;
-#pragma unroll
-                for (int k = 0; k < PPT; k++) {
-                    if (ok[k]) {  // divergent: executed under the EXEC mask of the lanes that blend
-                        const float rinv = GSR_RCP(1.0f - alpha[k]);
-                        const float Tn = Tr[k] * rinv;  // T / (1 - alpha)
-                        const float w = alpha[k] * Tn;
-                        const float oml = 1.0f - la[k];
-                        ar0[k] = la[k] * lc0[k] + oml * ar0[k]; ar1[k] = la[k] * lc1[k] + oml * ar1[k];
-                        ar2[k] = la[k] * lc2[k] + oml * ar2[k]; ard[k] = la[k] * lcd[k] + oml * ard[k];
-                        aru[k] = la[k] * lcu[k] + oml * aru[k];
-                        float dL_dalpha = (C.x - ar0[k]) * g0[k] + (C.y - ar1[k]) * g1[k] + (C.z - ar2[k]) * g2[k]
-                                        + (B.z - ard[k]) * gd[k] + (B.w - aru[k]) * gu[k];
-                        dL_dalpha *= Tn;
-                        dL_dalpha += (-Tf[k] * rinv) * bgdot[k];
-                        const float dL_dG = B.y * dL_dalpha;
-                        const float gdx = G[k] * dx[k], gdy = G[k] * dy[k];
-                        const float dG_ddelx = -gdx * A.z - gdy * A.w;
-                        const float dG_ddely = -gdy * B.x - gdx * A.w;
-                        s[0] += w * g0[k]; s[1] += w * g1[k]; s[2] += w * g2[k];
-                        s[3] += w * gd[k]; s[4] += w * gu[k];
-                        s[5] += dL_dG * dG_ddelx * ddelx_dx; s[6] += dL_dG * dG_ddely * ddely_dy;
-                        s[7] += -0.5f * gdx * dx[k] * dL_dG; s[8] += -0.5f * gdx * dy[k] * dL_dG;
-                        s[9] += -0.5f * gdy * dy[k] * dL_dG;
-                        s[10] += G[k] * dL_dalpha;
-                        Tr[k] = Tn; la[k] = alpha[k];
-                        lc0[k] = C.x; lc1[k] = C.y; lc2[k] = C.z; lcd[k] = B.z; lcu[k] = B.w;
+                if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
+                    const float rinv = GSR_RCP(1.0f - alpha);
+                    const float Tn = Tr * rinv;  // T / (1 - alpha)
+                    const float w = alpha * Tn;
+                    const float oml = 1.0f - la;
+                    ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
+                    float dL_dalpha = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
+                    if (AUX) {
+                        ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
+                        dL_dalpha += (B.z - ard) * gd + (B.w - aru) * gu;
+                        s[3] = w * gd; s[4] = w * gu;
+                        lcd = B.z; lcu = B.w;
                     }
+                    dL_dalpha *= Tn;
+                    dL_dalpha += (-Tf * rinv) * bgdot;
+                    const float dL_dG = B.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * A.z - gdy * A.w;
+                    const float dG_ddely = -gdy * B.x - gdx * A.w;
+                    s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
+                    s[5] = dL_dG * dG_ddelx * ddelx_dx; s[6] = dL_dG * dG_ddely * ddely_dy;
+                    s[7] = -0.5f * gdx * dx * dL_dG; s[8] = -0.5f * gdx * dy * dL_dG; s[9] = -0.5f * gdy * dy * dL_dG;
+                    s[10] = G * dL_dalpha;
+                    Tr = Tn; la = alpha;
+                    lc0 = C.x; lc1 = C.y; lc2 = C.z;
                 }
 #pragma unroll
-                for (int v = 0; v < 11; v++) s[v] = gsr_row_sum16(s[v]);
-                if ((t & 15) == 0) {
+                for (int v = 0; v < 11; v++)
+                    if (AUX || (v != 3 && v != 4)) s[v] = gsr_row_sum16(s[v]);
+                if ((lane & 15) == 0) {
                     float* a = acc + j * GSR_SLOT_FLOATS;
 #pragma unroll
-                    for (int v = 0; v < 11; v++) atomicAdd(a + v, s[v]);
+                    for (int v = 0; v < 11; v++)
+                        if (AUX || (v != 3 && v != 4)) atomicAdd(a + v, s[v]);
                 }
             }
         }
         __syncthreads();
-        for (int i = t; i < cnt; i += NT) {
-            float4* a4 = reinterpret_cast<float4*>(acc + i * GSR_SLOT_FLOATS);
-            float4* dst = slots + (size_t)sSlot[i] * 3;
+        if (t < cnt) {
+            float4* a4 = reinterpret_cast<float4*>(acc + t * GSR_SLOT_FLOATS);
+            float4* dst = slots + (size_t)sSlot[t] * 3;
             dst[0] = a4[0]; dst[1] = a4[1]; dst[2] = a4[2];
             if (active) { a4[0] = a4[1] = a4[2] = make_float4(0.f, 0.f, 0.f, 0.f); }
         }
@@ -296,32 +311,25 @@ __global__ void __launch_bounds__(256 / PPT) gsr_blend_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int ppt, hipStream_t stream)
+                                    float* out_feature, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
-#define GSR_FWD(PPT_)                                                                                               \
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel<PPT_>, dim3(T), dim3(256 / PPT_), 0, stream, image.ranges, bin.point_list, \
-                       geom.rec, W, H, gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib)
-    if (ppt == 1) GSR_FWD(1);
-    else if (ppt == 4) GSR_FWD(4);
-    else GSR_FWD(2);
-#undef GSR_FWD
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
+                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib);
     return hipGetLastError();
 }
 
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
-                                     const float* dL_ddepth, const float* dL_dfeature, float* slots, int ppt,
-                                     hipStream_t stream)
+                                     const float* dL_ddepth, const float* dL_dfeature, float* slots, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
-#define GSR_BWD(PPT_)                                                                                               \
-    hipLaunchKernelGGL(gsr_blend_bwd_kernel<PPT_>, dim3(T), dim3(256 / PPT_), 0, stream, image.ranges, bin.point_list, \
-                       geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature,  \
-                       reinterpret_cast<float4*>(slots))
-    if (ppt == 1) GSR_BWD(1);
-    else if (ppt == 4) GSR_BWD(4);
-    else GSR_BWD(2);
-#undef GSR_BWD
+    float4* s4 = reinterpret_cast<float4*>(slots);
+    if (dL_ddepth && dL_dfeature)
+        hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
+                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature, s4);
+    else
+        hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
+                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, nullptr, nullptr, s4);
     return hipGetLastError();
 }

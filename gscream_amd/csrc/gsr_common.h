@@ -4,7 +4,8 @@
 //
 //   geom  : rec[P]       64 B  one cache line per Gaussian, gathered by the blend kernels
 //                              a = {px, py, conA, conB}   b = {conC, opacity, depth, feature}
-//                              c = {r, g, b, -}           d = {offset, x0|x1<<16, y0|y1<<16, tiles}
+//                              c = {r, g, b, tau}         d = {offset, x0|x1<<16, y0|y1<<16, tiles}
+//                              (tau = ln(255 opacity) + margin: the blend kernels' quadrant-cull threshold)
 //           rect[P]       8 B  {x0|x1<<16, y0|y1<<16} tile rectangle (0,0 = culled)
 //           depthkey[P]   4 B  float bits of view-space depth (positive floats sort as uints)
 //           tiles[P]      4 B  tiles touched
@@ -153,10 +154,10 @@ hipError_t gsr_launch_tile_sort(int T, int R, int max_tile_count, const GsrImage
                                 hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int ppt, hipStream_t stream);
+                                    float* out_feature, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
-                                     const float* dL_ddepth, const float* dL_dfeature, float* slots, int ppt,
+                                     const float* dL_ddepth, const float* dL_dfeature, float* slots,
                                      hipStream_t stream);
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,

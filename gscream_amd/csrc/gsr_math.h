@@ -101,9 +101,11 @@ __device__ __forceinline__ void gsr_cov2d(const float3 mean, const GsrCam& cam, 
 
 // Minimum over the pixel box [bx0,bx1] x [by0,by1] of q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy with
 // d = mean - pixel, i.e. of -power (DGR forward.cu:523): exact for a convex quadratic -- 0 if the mean is
-// inside the box, otherwise the smallest of the four clamped 1-D edge minima.
-__device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, float B, float C, float bx0, float bx1,
-                                               float by0, float by1)
+// inside the box, otherwise the smallest of the four clamped 1-D edge minima.  rA = 1/A, rC = 1/C are
+// passed in (computed once per Gaussian); an approximate reciprocal only moves the evaluation point off
+// the edge optimum by an ulp, which changes q by O(ulp^2).
+__device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, float B, float C, float rA, float rC,
+                                               float bx0, float bx1, float by0, float by1)
 {
     const float dx0 = mx - bx1, dx1 = mx - bx0, dy0 = my - by1, dy1 = my - by0;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return 0.f;
@@ -111,27 +113,30 @@ __device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, floa
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const float ex = e ? dx1 : dx0;
-        const float dy = fminf(dy1, fmaxf(dy0, -B * ex / C));
+        const float dy = fminf(dy1, fmaxf(dy0, -B * ex * rC));
         best = fminf(best, 0.5f * (A * ex * ex + C * dy * dy) + B * ex * dy);
         const float ey = e ? dy1 : dy0;
-        const float dx = fminf(dx1, fmaxf(dx0, -B * ey / A));
+        const float dx = fminf(dx1, fmaxf(dx0, -B * ey * rA));
         best = fminf(best, 0.5f * (A * dx * dx + C * ey * ey) + B * dx * ey);
     }
     return best;
 }
 
-// Tile culling.  A (Gaussian, tile) instance can change a pixel only if alpha = opacity * exp(power) reaches
-// 1/255 somewhere in the tile (DGR forward.cu:534 skips everything below), i.e. iff min q <= ln(255 opacity).
-// Instances that fail the test (with a 0.01 safety margin on q, far above fp32 rounding of `power`) are not
-// binned: images and gradients are unchanged, the lists the blend kernels walk get ~2.5x shorter.
-// NaNs compare false, so a degenerate conic keeps the instance.
+// Culling threshold.  A (Gaussian, pixel) pair is blended only if alpha = opacity * exp(power) >= 1/255
+// (DGR forward.cu:534 skips everything below), i.e. iff q = -power <= ln(255 opacity).  tau adds a 0.01
+// safety margin on q -- orders of magnitude above fp32 rounding of `power` -- so a box (a 16x16 tile at
+// binning time, an 8x8 quadrant inside the blend kernels) is skipped only when no pixel in it can pass.
+// Skipped work contributes exactly nothing: images and gradients are unchanged.  NaNs compare false, so
+// a degenerate conic or a non-positive opacity keeps the instance.
 #define GSR_CULL_MARGIN 0.01f
-__device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, float B, float C, float tau, int tx,
-                                                  int ty, int W, int H)
+__device__ __forceinline__ float gsr_cull_tau(float opacity) { return logf(255.0f * opacity) + GSR_CULL_MARGIN; }
+
+__device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, float B, float C, float rA, float rC,
+                                                  float tau, int tx, int ty, int W, int H)
 {
     const float bx0 = (float)(tx * 16), by0 = (float)(ty * 16);
     const float bx1 = (float)min(tx * 16 + 15, W - 1), by1 = (float)min(ty * 16 + 15, H - 1);
-    return !(gsr_box_min_q(mx, my, A, B, C, bx0, bx1, by0, by1) > tau + GSR_CULL_MARGIN);
+    return !(gsr_box_min_q(mx, my, A, B, C, rA, rC, bx0, bx1, by0, by1) > tau);
 }
 // survivor bit of rectangle position i (row-major); rectangles larger than 64 tiles keep their tail
 __device__ __forceinline__ bool gsr_mask_bit(unsigned long long mask, int i) { return i >= 64 || ((mask >> i) & 1ull); }

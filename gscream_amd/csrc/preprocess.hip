@@ -117,14 +117,18 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
     tiles[idx] = ntiles;
     depthkey[idx] = __float_as_uint(viewz);
     unsigned long long mask = ~0ull;
-    if (radius > 0 && tile_cull) {
-        const float tau = logf(255.0f * opacities[idx]);
-        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-        mask = 0ull;
-        int i = 0;
-        for (int y = y0; y < y1 && i < 64; y++)
-            for (int x = x0; x < x1 && i < 64; x++, i++)
-                if (gsr_tile_survives(pix, piy, conx, cony, conz, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
+    float tau = 0.f;
+    if (radius > 0) {
+        tau = gsr_cull_tau(opacities[idx]);
+        if (tile_cull) {
+            const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+            const float rA = 1.0f / conx, rC = 1.0f / conz;
+            mask = 0ull;
+            int i = 0;
+            for (int y = y0; y < y1 && i < 64; y++)
+                for (int x = x0; x < x1 && i < 64; x++, i++)
+                    if (gsr_tile_survives(pix, piy, conx, cony, conz, rA, rC, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
+        }
     }
     tmask[idx] = mask;
     if (radius > 0) {
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         GsrRec* r = rec + idx;
         r->a = make_float4(pix, piy, conx, cony);
         r->b = make_float4(conz, opacities[idx], viewz, features[idx]);
-        r->c = make_float4(col.x, col.y, col.z, 0.f);
+        r->c = make_float4(col.x, col.y, col.z, tau);
     }
 }
 

@@ -25,12 +25,9 @@ _tuning = _native.Tuning()
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
-def set_tuning(pixels_per_thread_fwd=0, pixels_per_thread_bwd=0, tile_cull=True):
-    """Performance knobs (0 = library default).  Images, radii and gradients do not depend on them;
-    tile_cull=False bins every tile of every rectangle, which makes the internal per-tile lists and
-    num_rendered bit-identical to the reference's."""
-    _tuning.pixels_per_thread_fwd = int(pixels_per_thread_fwd)
-    _tuning.pixels_per_thread_bwd = int(pixels_per_thread_bwd)
+def set_tuning(tile_cull=True):
+    """Performance knob.  Images, radii and gradients do not depend on it; tile_cull=False bins every tile of
+    every rectangle, which makes the internal per-tile lists and num_rendered bit-identical to the reference's."""
     _tuning.disable_tile_cull = 0 if tile_cull else 1
 
 
@@ -150,7 +147,15 @@ def _backward_native(rs, num_rendered, num_slots, means3D, radii, colors_precomp
         return g_means2D, g_colors, g_opac, g_feat, g_means3D, g_cov, g_sh, g_scales, g_rot
     view, proj, campos = _cam(rs, dev)
     bg = _f32c(rs.bg, dev)
-    gc, gd, gu = _f32c(g_color, dev), _f32c(g_depth, dev), _f32c(g_unc, dev)
+    # set_materialize_grads(False): an output the loss never touched arrives as None.  GScream's loss never uses
+    # the uncertainty map (train.py:532) and early iterations use no depth either -> cheaper kernel variant.
+    H_, W_ = int(rs.image_height), int(rs.image_width)
+    gc = _f32c(g_color, dev) if g_color is not None else torch.zeros((3, H_, W_), **f32)
+    if g_depth is None and g_unc is None:
+        gd = gu = None
+    else:
+        gd = _f32c(g_depth, dev) if g_depth is not None else torch.zeros((1, H_, W_), **f32)
+        gu = _f32c(g_unc, dev) if g_unc is not None else torch.zeros((1, H_, W_), **f32)
     # keep every converted tensor referenced until the launches are enqueued: a temporary freed early
     # could hand its block to the next temporary
     means3D_c, colors_c, sh_c = _f32c(means3D), _f32c(colors_precomp, dev), _f32c(sh, dev)
@@ -195,6 +200,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.num_slots = num_slots
         ctx.opacity_shape, ctx.uncertainty_shape = opacities.shape, uncertainties.shape
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, depth, uncertainty, radii
@@ -202,6 +208,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, grad_out_depth, grad_out_uncertainty, _grad_radii):
         rs = ctx.raster_settings
+        if grad_out_color is None and grad_out_depth is None and grad_out_uncertainty is None:
+            return (None,) * 10
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         args = (rs, ctx.num_rendered, ctx.num_slots, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
                 geom, binning, img, grad_out_color, grad_out_depth, grad_out_uncertainty)

@@ -52,14 +52,13 @@ typedef struct gsr_stage1_result {
     int32_t reserved;
 } gsr_stage1_result;
 
-/* Tunables; zero-initialise for defaults.  Pure performance knobs: results do not depend on them. */
+/* Tunables; zero-initialise for defaults.  Pure performance knobs: images, radii and gradients do not
+ * depend on them. */
 typedef struct gsr_tuning {
-    int32_t pixels_per_thread_fwd; /* 0 = default; 1, 2 or 4 */
-    int32_t pixels_per_thread_bwd; /* 0 = default; 1, 2 or 4 */
-    int32_t disable_tile_cull;     /* 1 = bin every tile of the rectangle like the reference (lists become
-                                      bit-identical to the reference's; slower).  Default 0: skip tiles the
-                                      Gaussian cannot change (see gsr_math.h) */
-    int32_t reserved[5];
+    int32_t disable_tile_cull; /* 1 = bin every tile of the rectangle like the reference (the internal per-tile
+                                  lists and num_rendered become bit-identical to the reference's; slower).
+                                  Default 0: skip tiles the Gaussian cannot change (gsr_math.h) */
+    int32_t reserved[7];
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */
@@ -119,7 +118,8 @@ int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const flo
  * caller need not zero-fill.  Optional outputs may be NULL: dL_dcov3D[P,6], dL_dsh[P,M,3].
  *   dL_dmeans2D[P,3] (z = 0)  dL_dcolors[P,3]  dL_dopacity[P]  dL_dfeatures[P]
  *   dL_dmeans3D[P,3]  dL_dscales[P,3]  dL_drotations[P,4]
- * Gradients are bit-reproducible run to run (no floating-point atomics on global memory).
+ * dL_dout_depth and dL_dout_feature may both be NULL (= no gradient flows into those maps; a cheaper
+ * kernel variant runs).  No floating-point atomics on global memory are used.
  */
 int gsr_backward(int P, int D, int M, int W, int H, int R, const float* background,
                  const float* means3D, const int32_t* radii, const float* colors_precomp, const float* shs,

@@ -22,9 +22,9 @@ GOLDEN = sorted(MG.cases().keys())
 
 @pytest.fixture(autouse=True)
 def _default_tuning():
-    set_tuning(0, 0)
+    set_tuning()
     yield
-    set_tuning(0, 0)
+    set_tuning()
 
 
 def _check_binning(s, got, exp_point_list, exp_tile_counts):
@@ -120,17 +120,6 @@ def test_golden_binning_is_bit_exact(name):
     img = _layout.image_views(got["img"], s["means3D"].shape[0], s["W"], s["H"])
     nc = img["n_contrib"].cpu().numpy()
     assert (nc != exp["n_contrib"].astype(np.int64)).mean() < 1e-3
-
-
-@pytest.mark.parametrize("ppt", [1, 2, 4])
-@pytest.mark.parametrize("name", ["cfg1", "stack", "odd_size"])
-def test_pixels_per_thread_variants(name, ppt):
-    s, grads, exp = MG.load(name)
-    set_tuning(ppt, ppt)
-    got = Hh.hip_run(s, grads)
-    for k in ("out_color", "out_depth", "out_unc"):
-        Hh.assert_images_close(got[k], exp[k], f"{name}/ppt{ppt}/{k}")
-    Hh.assert_grads_close(got, {k[5:]: exp[k] for k in exp if k.startswith("grad_")}, context=f"{name}/ppt{ppt}")
 
 
 def test_config1_against_live_oracle():
