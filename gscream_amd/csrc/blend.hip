@@ -11,18 +11,22 @@
 //     into a private LDS list and walks only those: a typical splat touches 1-2 of the 4 quadrants, so the
 //     per-pixel test loop shrinks accordingly and the hit rate of what remains goes up.  The reference tests
 //     every instance of the tile against all 256 pixels (forward.cu:513-553).
-//   * Per-Gaussian operands are read back from LDS with same-address (broadcast) ds_read_b128: conflict-free.
-//     The reference re-reads colour and depth from GLOBAL memory per contribution (forward.cu:545-546).
+//   * Per-Gaussian operands reach the per-pixel math as SCALAR operands: each lane pulls ONE instance of its
+//     wave's list out of LDS (3 ds_read_b128 serve 64 instances) and the inner loop broadcasts lane k's values
+//     with v_readlane_b32 into SGPRs -- no LDS round trip per instance (measured: the broadcast ds_reads +
+//     4-lane LDS atomics kept the LDS 66 % busy with the VALU at 34 %).  The reference re-reads colour and
+//     depth from GLOBAL memory per contribution (forward.cu:545-546).
 //   * Early-out: a wave leaves the batch when all its pixels are done (__all); in the backward a wave skips
 //     gradient math + reduction when none of its pixels blends the instance (__any); the block leaves when
 //     every wave is done (__syncthreads_and).
 //   * Backward gradient scatter: the reference issues 11 global atomicAdd per (pixel, Gaussian) contribution
-//     (backward.cu:554-601).  Here the 11 partials are summed over the 16 lanes of a DPP row with 4 DPP adds
-//     and the 4 row leaders of a wave add them into an LDS accumulator [256][12] with ONE ds_add_f32 each
-//     (built with -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch,
+//     (backward.cu:554-601).  Here the 11 partials are summed over the wave's 64 lanes with 6 DPP adds
+//     (quad_perm x2, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31) and lane 63 adds the wave total
+//     into an LDS accumulator [256][12] with one single-lane ds_add_f32 per value (built with
+//     -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch,
 //     thread i stores the 12 floats of instance i with three plain 16-byte stores into that instance's private
 //     gradient slot (slot = Gaussian's scan offset + tile position inside its rectangle); gauss_bwd.hip sums
-//     each Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a tile's <= 16 row leaders
+//     each Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a tile's 4 wavefronts
 //     are unordered, so two runs agree to rounding, not bit for bit.)
 //   * AUX = false specialises the backward for "no gradient flows into the depth and feature maps" (GScream's
 //     RGB-only iterations): 9 instead of 11 reductions and no depth/feature recurrences.
@@ -64,6 +68,23 @@ __device__ __forceinline__ float gsr_row_sum16(float v)
     v = gsr_dpp_add<0x141>(v);  // row_half_mirror
     v = gsr_dpp_add<0x140>(v);  // row_mirror
     return v;
+}
+
+// Sum over all 64 lanes; the total lands in the last DPP row (lanes 48..63).
+__device__ __forceinline__ float gsr_wave_sum_to_row3(float v)
+{
+    v = gsr_row_sum16(v);
+    // row_bcast:15 into rows 1,3 then row_bcast:31 into rows 2,3 (lanes outside the row mask add 0)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// Broadcast lane k's value to the whole wave through an SGPR (v_readlane_b32): per-Gaussian operands then
+// enter the per-pixel math as scalar operands -- no LDS round trip and no VGPRs per operand.
+__device__ __forceinline__ float gsr_bcast(float v, int k)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
 }
 
 // 4-bit mask of the 8x8 quadrants of tile (tx, ty) in which the Gaussian can reach alpha >= 1/255.
@@ -139,23 +160,33 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
         const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [](int) { return true; });
         __builtin_amdgcn_wave_barrier();
 
-        for (int k = 0; k < nw; k++) {
+        // Each lane fetches ONE instance of the wave's list from LDS (3 x ds_read_b128 serve 64 instances);
+        // the k-loop then broadcasts lane k's operands with v_readlane instead of re-reading LDS per instance.
+        for (int c0 = 0; c0 < nw; c0 += 64) {
             if (__all(done)) break;  // wave-uniform
-            const int j = mylist[k];
-            const float4 A = sA[j], B = sB[j], C = sC[j];
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-            const float alpha = fminf(0.99f, B.y * GSR_EXP(power));
-            bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-            const float test_T = Tr * (1.0f - alpha);
-            const bool stop = ok && test_T < 0.0001f;
-            done = done || stop;
-            ok = ok && !stop;
-            const float w = ok ? alpha * Tr : 0.0f;
-            C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
-            Dp += B.z * w; Uf += B.w * w;
-            Tr = ok ? test_T : Tr;
-            last = ok ? (uint32_t)(base + j + 1) : last;
+            const int mine = min(c0 + lane, nw - 1);
+            const int jj = mylist[mine];
+            const float4 a = sA[jj], b = sB[jj], c = sC[jj];
+            const int m = min(64, nw - c0);
+            for (int k = 0; k < m; k++) {
+                if (__all(done)) break;  // wave-uniform
+                const float mx = gsr_bcast(a.x, k), my = gsr_bcast(a.y, k);
+                const float cA = gsr_bcast(a.z, k), cB = gsr_bcast(a.w, k), cC = gsr_bcast(b.x, k), op = gsr_bcast(b.y, k);
+                const float dx = mx - pxf, dy = my - pyf;
+                const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+                const float alpha = fminf(0.99f, op * GSR_EXP(power));
+                bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                if (!__any(ok)) continue;  // wave-uniform
+                const float test_T = Tr * (1.0f - alpha);
+                const bool stop = ok && test_T < 0.0001f;
+                done = done || stop;
+                ok = ok && !stop;
+                const float w = ok ? alpha * Tr : 0.0f;
+                C0 += gsr_bcast(c.x, k) * w; C1 += gsr_bcast(c.y, k) * w; C2 += gsr_bcast(c.z, k) * w;
+                Dp += gsr_bcast(b.z, k) * w; Uf += gsr_bcast(b.w, k) * w;
+                Tr = ok ? test_T : Tr;
+                last = ok ? (uint32_t)(base + __builtin_amdgcn_readlane(jj, k) + 1) : last;
+            }
         }
     }
 
@@ -246,54 +277,65 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
             const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [=](int i) { return hi - 1 - i < wmax; });
             __builtin_amdgcn_wave_barrier();
-            for (int k = 0; k < nw; k++) {
-                const int j = mylist[k];
-                const int p = hi - 1 - j;
-                const float4 A = sA[j], B = sB[j], C = sC[j];
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float G = GSR_EXP(power);
-                const float alpha = fminf(0.99f, B.y * G);
-                const bool ok = p < lastc && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                if (!__any(ok)) continue;  // wave-uniform: no pixel of this quadrant blends the instance
+            for (int c0 = 0; c0 < nw; c0 += 64) {
+                const int mine = min(c0 + lane, nw - 1);
+                const int jj = mylist[mine];
+                const float4 a = sA[jj], b = sB[jj], c = sC[jj];
+                const int m = min(64, nw - c0);
+                for (int k = 0; k < m; k++) {
+                    const int j = __builtin_amdgcn_readlane(jj, k);
+                    const int p = hi - 1 - j;
+                    const float mx = gsr_bcast(a.x, k), my = gsr_bcast(a.y, k);
+                    const float cA = gsr_bcast(a.z, k), cB = gsr_bcast(a.w, k), cC = gsr_bcast(b.x, k), op = gsr_bcast(b.y, k);
+                    const float dx = mx - pxf, dy = my - pyf;
+                    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+                    const float G = GSR_EXP(power);
+                    const float alpha = fminf(0.99f, op * G);
+                    const bool ok = p < lastc && power <= 0.0f && alpha >= (1.0f / 255.0f);
+                    if (!__any(ok)) continue;  // wave-uniform: no pixel of this quadrant blends the instance
 
-                float s[11];
+                    float s[11];
 #pragma unroll
-                for (int v = 0; v < 11; v++) s[v] = 0.f;
-                if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
-                    const float rinv = GSR_RCP(1.0f - alpha);
-                    const float Tn = Tr * rinv;  // T / (1 - alpha)
-                    const float w = alpha * Tn;
-                    const float oml = 1.0f - la;
-                    ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
-                    float dL_dalpha = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
-                    if (AUX) {
-                        ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
-                        dL_dalpha += (B.z - ard) * gd + (B.w - aru) * gu;
-                        s[3] = w * gd; s[4] = w * gu;
-                        lcd = B.z; lcu = B.w;
+                    for (int v = 0; v < 11; v++) s[v] = 0.f;
+                    if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
+                        const float c0r = gsr_bcast(c.x, k), c1r = gsr_bcast(c.y, k), c2r = gsr_bcast(c.z, k);
+                        const float rinv = GSR_RCP(1.0f - alpha);
+                        const float Tn = Tr * rinv;  // T / (1 - alpha)
+                        const float w = alpha * Tn;
+                        const float oml = 1.0f - la;
+                        ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
+                        float dL_dalpha = (c0r - ar0) * g0 + (c1r - ar1) * g1 + (c2r - ar2) * g2;
+                        if (AUX) {
+                            const float cdr = gsr_bcast(b.z, k), cur = gsr_bcast(b.w, k);
+                            ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
+                            dL_dalpha += (cdr - ard) * gd + (cur - aru) * gu;
+                            s[3] = w * gd; s[4] = w * gu;
+                            lcd = cdr; lcu = cur;
+                        }
+                        dL_dalpha *= Tn;
+                        dL_dalpha += (-Tf * rinv) * bgdot;
+                        const float dL_dG = op * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * cA - gdy * cB;
+                        const float dG_ddely = -gdy * cC - gdx * cB;
+                        s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
+                        s[5] = dL_dG * dG_ddelx * ddelx_dx; s[6] = dL_dG * dG_ddely * ddely_dy;
+                        s[7] = -0.5f * gdx * dx * dL_dG; s[8] = -0.5f * gdx * dy * dL_dG; s[9] = -0.5f * gdy * dy * dL_dG;
+                        s[10] = G * dL_dalpha;
+                        Tr = Tn; la = alpha;
+                        lc0 = c0r; lc1 = c1r; lc2 = c2r;
                     }
-                    dL_dalpha *= Tn;
-                    dL_dalpha += (-Tf * rinv) * bgdot;
-                    const float dL_dG = B.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * A.z - gdy * A.w;
-                    const float dG_ddely = -gdy * B.x - gdx * A.w;
-                    s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
-                    s[5] = dL_dG * dG_ddelx * ddelx_dx; s[6] = dL_dG * dG_ddely * ddely_dy;
-                    s[7] = -0.5f * gdx * dx * dL_dG; s[8] = -0.5f * gdx * dy * dL_dG; s[9] = -0.5f * gdy * dy * dL_dG;
-                    s[10] = G * dL_dalpha;
-                    Tr = Tn; la = alpha;
-                    lc0 = C.x; lc1 = C.y; lc2 = C.z;
-                }
-#pragma unroll
-                for (int v = 0; v < 11; v++)
-                    if (AUX || (v != 3 && v != 4)) s[v] = gsr_row_sum16(s[v]);
-                if ((lane & 15) == 0) {
-                    float* a = acc + j * GSR_SLOT_FLOATS;
+                    // 6 DPP adds per value put the wave total in lane 63, which issues ONE single-lane ds_add_f32
+                    // per value (a 4-lane same-address LDS atomic costs ~13 LDS cycles; measured, profiles/)
 #pragma unroll
                     for (int v = 0; v < 11; v++)
-                        if (AUX || (v != 3 && v != 4)) atomicAdd(a + v, s[v]);
+                        if (AUX || (v != 3 && v != 4)) s[v] = gsr_wave_sum_to_row3(s[v]);
+                    if (lane == 63) {
+                        float* ac = acc + j * GSR_SLOT_FLOATS;
+#pragma unroll
+                        for (int v = 0; v < 11; v++)
+                            if (AUX || (v != 3 && v != 4)) atomicAdd(ac + v, s[v]);
+                    }
                 }
             }
         }

@@ -158,3 +158,12 @@ def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", m
            if v["n_bad"] > max(min_bad_allowed, max_bad_frac * v["n"]) or not v["p999"] <= tol or not v["max"] <= 0.5}
     assert not bad, f"{context} gradient mismatch (rel tol {tol}): {bad}; all: {rep}"
     return {k: v["max"] for k, v in rep.items()}
+
+
+def assert_grads_nearly_equal(a, b, keys=GRAD_KEYS, context=""):
+    """Two HIP runs of the same math in a different summation order (other batch composition, unordered LDS adds):
+    equal to rounding.  dL/dscale and dL/drot amplify rounding through the covariance chain, hence the loose max."""
+    for k in keys:
+        if k in a and k in b:
+            rep = grad_report(a[k], b[k], tol=1e-4)
+            assert rep["p999"] < 1e-4 and rep["max"] < 5e-3, f"{context} {k}: {rep}"
