@@ -255,7 +255,7 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const floa
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
                                             dL_dout_feature, slots, stream),
                   "backward blend");
-    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots,
+    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots, R,
                                         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures, dL_dmeans3D, dL_dcov3D,
                                         dL_dsh, dL_dscales, dL_drotations, stream),
               "per-Gaussian backward");

@@ -195,11 +195,11 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     for (int g = lo + threadIdx.x; g < hi; g += blockDim.x) {
         const uint2 rc = rect[g];
         const uint32_t nt = tiles[g];
-        rec[g].d = make_uint4(offsets[g], rc.x, rc.y, nt);
         if (nt == 0) continue;
         const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
         const u64 key = ((u64)depthkey[g] << 32) | (uint32_t)g;
         const u64 mask = tmask[g];
+        rec[g].d = make_uint4(offsets[g], (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
         int i = 0;
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++, i++) {

@@ -87,6 +87,23 @@ __device__ __forceinline__ float gsr_bcast(float v, int k)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
 }
 
+// ---- A/B switches (compile-time; defaults chosen from measurements, see profiles/) ----
+//   GSR_{FWD,BWD}_READLANE = 1 : per-instance operands via v_readlane from a per-lane copy (else LDS broadcast reads)
+//   GSR_RED_MODE 0: 4-step row reduce per value, 4 row leaders issue one ds_add_f32 per value (9-11 LDS atomics)
+//                1: 6-step wave reduce per value, lane 63 issues one ds_add_f32 per value
+//                2: 4-step row reduce per value, pack value i into lane i of each row, 2 lane-aligned cross-row adds
+//                   (v_permlane32_swap / v_permlane16_swap) on the packed register, lanes 0..10 issue ONE ds_add_f32
+//                3: like 2 without the cross-row step: all four rows add (one instruction, 4 lanes per address)
+#ifndef GSR_FWD_READLANE
+#define GSR_FWD_READLANE 0
+#endif
+#ifndef GSR_BWD_READLANE
+#define GSR_BWD_READLANE 0
+#endif
+#ifndef GSR_RED_MODE
+#define GSR_RED_MODE 2
+#endif
+
 // 4-bit mask of the 8x8 quadrants of tile (tx, ty) in which the Gaussian can reach alpha >= 1/255.
 __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const float4 B, const float tau, int tx, int ty,
                                                       int W, int H)
@@ -154,12 +171,13 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
             const float4* r = reinterpret_cast<const float4*>(rec + point_list[rg.x + base + t]);
             const float4 a = r[0], b = r[1], c = r[2];
             sA[t] = a; sB[t] = b; sC[t] = c;
-            sQ[t] = gsr_quadrant_mask(a, b, c.w, tx, ty, W, H);
+            sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y), tx, ty, W, H);
         }
         __syncthreads();
         const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [](int) { return true; });
         __builtin_amdgcn_wave_barrier();
 
+#if GSR_FWD_READLANE
         // Each lane fetches ONE instance of the wave's list from LDS (3 x ds_read_b128 serve 64 instances);
         // the k-loop then broadcasts lane k's operands with v_readlane instead of re-reading LDS per instance.
         for (int c0 = 0; c0 < nw; c0 += 64) {
@@ -170,8 +188,19 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
             const int m = min(64, nw - c0);
             for (int k = 0; k < m; k++) {
                 if (__all(done)) break;  // wave-uniform
+                const int j = __builtin_amdgcn_readlane(jj, k);
                 const float mx = gsr_bcast(a.x, k), my = gsr_bcast(a.y, k);
                 const float cA = gsr_bcast(a.z, k), cB = gsr_bcast(a.w, k), cC = gsr_bcast(b.x, k), op = gsr_bcast(b.y, k);
+#define GSR_FWD_C(i_) gsr_bcast(i_ == 0 ? c.x : i_ == 1 ? c.y : i_ == 2 ? c.z : i_ == 3 ? b.z : b.w, k)
+#else
+        {
+            for (int k = 0; k < nw; k++) {
+                if (__all(done)) break;  // wave-uniform
+                const int j = mylist[k];
+                const float4 A = sA[j], B = sB[j];
+                const float mx = A.x, my = A.y, cA = A.z, cB = A.w, cC = B.x, op = B.y;
+#define GSR_FWD_C(i_) (i_ == 0 ? sC[j].x : i_ == 1 ? sC[j].y : i_ == 2 ? sC[j].z : i_ == 3 ? B.z : B.w)
+#endif
                 const float dx = mx - pxf, dy = my - pyf;
                 const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
                 const float alpha = fminf(0.99f, op * GSR_EXP(power));
@@ -182,12 +211,13 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
                 done = done || stop;
                 ok = ok && !stop;
                 const float w = ok ? alpha * Tr : 0.0f;
-                C0 += gsr_bcast(c.x, k) * w; C1 += gsr_bcast(c.y, k) * w; C2 += gsr_bcast(c.z, k) * w;
-                Dp += gsr_bcast(b.z, k) * w; Uf += gsr_bcast(b.w, k) * w;
+                C0 += GSR_FWD_C(0) * w; C1 += GSR_FWD_C(1) * w; C2 += GSR_FWD_C(2) * w;
+                Dp += GSR_FWD_C(3) * w; Uf += GSR_FWD_C(4) * w;
                 Tr = ok ? test_T : Tr;
-                last = ok ? (uint32_t)(base + __builtin_amdgcn_readlane(jj, k) + 1) : last;
+                last = ok ? (uint32_t)(base + j + 1) : last;
             }
         }
+#undef GSR_FWD_C
     }
 
     if (inside) {
@@ -263,12 +293,16 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
         if (t < cnt) {
             const GsrRec* r = rec + point_list[rg.x + (hi - 1 - t)];
             const uint4 d = r->d;
-            const int x0 = d.y & 0xffff, x1 = d.y >> 16, y0 = d.z & 0xffff;
-            sSlot[t] = d.x + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            const float4 c = r->c;
+            // gradient slot = Gaussian's scan offset + rank of this tile among the surviving tiles of its rectangle
+            const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)__float_as_uint(c.w);
+            const int pos = (ty - y0) * wd + (tx - x0);
+            const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
+            sSlot[t] = d.x + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
             if (active) {
-                const float4 a = r->a, b = r->b, c = r->c;
+                const float4 a = r->a, b = r->b;
                 sA[t] = a; sB[t] = b; sC[t] = c;
-                sQ[t] = gsr_quadrant_mask(a, b, c.w, tx, ty, W, H);
+                sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y), tx, ty, W, H);
             }
         }
         __syncthreads();
@@ -277,6 +311,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
             const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [=](int i) { return hi - 1 - i < wmax; });
             __builtin_amdgcn_wave_barrier();
+#if GSR_BWD_READLANE
             for (int c0 = 0; c0 < nw; c0 += 64) {
                 const int mine = min(c0 + lane, nw - 1);
                 const int jj = mylist[mine];
@@ -284,9 +319,18 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                 const int m = min(64, nw - c0);
                 for (int k = 0; k < m; k++) {
                     const int j = __builtin_amdgcn_readlane(jj, k);
-                    const int p = hi - 1 - j;
                     const float mx = gsr_bcast(a.x, k), my = gsr_bcast(a.y, k);
                     const float cA = gsr_bcast(a.z, k), cB = gsr_bcast(a.w, k), cC = gsr_bcast(b.x, k), op = gsr_bcast(b.y, k);
+#define GSR_BWD_C(i_) gsr_bcast(i_ == 0 ? c.x : i_ == 1 ? c.y : i_ == 2 ? c.z : i_ == 3 ? b.z : b.w, k)
+#else
+            {
+                for (int k = 0; k < nw; k++) {
+                    const int j = mylist[k];
+                    const float4 A = sA[j], B = sB[j];
+                    const float mx = A.x, my = A.y, cA = A.z, cB = A.w, cC = B.x, op = B.y;
+#define GSR_BWD_C(i_) (i_ == 0 ? sC[j].x : i_ == 1 ? sC[j].y : i_ == 2 ? sC[j].z : i_ == 3 ? B.z : B.w)
+#endif
+                    const int p = hi - 1 - j;
                     const float dx = mx - pxf, dy = my - pyf;
                     const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
                     const float G = GSR_EXP(power);
@@ -297,8 +341,8 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                     float s[11];
 #pragma unroll
                     for (int v = 0; v < 11; v++) s[v] = 0.f;
+                    const float c0r = GSR_BWD_C(0), c1r = GSR_BWD_C(1), c2r = GSR_BWD_C(2);
                     if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
-                        const float c0r = gsr_bcast(c.x, k), c1r = gsr_bcast(c.y, k), c2r = gsr_bcast(c.z, k);
                         const float rinv = GSR_RCP(1.0f - alpha);
                         const float Tn = Tr * rinv;  // T / (1 - alpha)
                         const float w = alpha * Tn;
@@ -306,7 +350,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                         ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
                         float dL_dalpha = (c0r - ar0) * g0 + (c1r - ar1) * g1 + (c2r - ar2) * g2;
                         if (AUX) {
-                            const float cdr = gsr_bcast(b.z, k), cur = gsr_bcast(b.w, k);
+                            const float cdr = GSR_BWD_C(3), cur = GSR_BWD_C(4);
                             ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
                             dL_dalpha += (cdr - ard) * gd + (cur - aru) * gu;
                             s[3] = w * gd; s[4] = w * gu;
@@ -325,19 +369,40 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                         Tr = Tn; la = alpha;
                         lc0 = c0r; lc1 = c1r; lc2 = c2r;
                     }
-                    // 6 DPP adds per value put the wave total in lane 63, which issues ONE single-lane ds_add_f32
-                    // per value (a 4-lane same-address LDS atomic costs ~13 LDS cycles; measured, profiles/)
+#if GSR_RED_MODE == 0 || GSR_RED_MODE == 1
 #pragma unroll
                     for (int v = 0; v < 11; v++)
-                        if (AUX || (v != 3 && v != 4)) s[v] = gsr_wave_sum_to_row3(s[v]);
-                    if (lane == 63) {
+                        if (AUX || (v != 3 && v != 4)) s[v] = GSR_RED_MODE == 1 ? gsr_wave_sum_to_row3(s[v]) : gsr_row_sum16(s[v]);
+                    if (GSR_RED_MODE == 1 ? lane == 63 : (lane & 15) == 0) {
                         float* ac = acc + j * GSR_SLOT_FLOATS;
 #pragma unroll
                         for (int v = 0; v < 11; v++)
                             if (AUX || (v != 3 && v != 4)) atomicAdd(ac + v, s[v]);
                     }
+#else
+                    // Row totals of every value (4 DPP adds each), then lane i of each row keeps value i, so that
+                    // ONE ds_add_f32 with 11 distinct addresses replaces 9-11 LDS atomics (an LDS atomic
+                    // instruction costs ~13 LDS cycles whatever its lane count -- measured, profiles/).
+                    float x = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 11; v++)
+                        if (AUX || (v != 3 && v != 4)) {
+                            const float rs = gsr_row_sum16(s[v]);
+                            x = (lane & 15) == v ? rs : x;
+                        }
+#if GSR_RED_MODE == 2
+                    // lane-aligned cross-row adds (DPP cannot move a lane across rows): v_permlane32_swap brings
+                    // lanes 32..63 under lanes 0..31, v_permlane16_swap brings row 1 under row 0 (gfx950)
+                    x += __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+                    x += __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+                    if (lane < 11) atomicAdd(acc + j * GSR_SLOT_FLOATS + lane, x);
+#else
+                    if ((lane & 15) < 11) atomicAdd(acc + j * GSR_SLOT_FLOATS + (lane & 15), x);
+#endif
+#endif
                 }
             }
+#undef GSR_BWD_C
         }
         __syncthreads();
         if (t < cnt) {

@@ -10,7 +10,7 @@
 // gradient tensors need no memset (the reference zero-fills 116 B/Gaussian, rasterize_points.cu:160-170).
 // Built with -ffp-contract=off: same evaluation order and rounding as oracle/gs_oracle.c.
 //
-// HBM traffic per Gaussian: read 48 B x tiles_touched (contiguous slots) + 12 + 12 + 16 + 4 + 12;
+// HBM traffic per Gaussian: read 48 B x surviving tiles (contiguous, coalesced through LDS) + 12 + 12 + 16 + 4 + 12;
 // write 12 + 12 + 4 + 4 + 12 + 12 + 16 = 72 B.
 #include "gsr_math.h"
 
@@ -97,36 +97,47 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
     int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
-    const uint32_t* __restrict__ offsets, const unsigned long long* __restrict__ tmask,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, int num_slots,
     const float4* __restrict__ slots, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeatures,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-
-    float gcol[3] = { 0, 0, 0 }, gdepth = 0, gfeat = 0, gm2x = 0, gm2y = 0, gcx = 0, gcy = 0, gcw = 0, gop = 0;
+    // The gradient slots of the block's 256 consecutive Gaussians are one contiguous range of `slots`
+    // (offsets[] is the exclusive scan of the per-Gaussian slot counts).  The block streams that range through
+    // LDS with fully coalesced 16-byte loads; each thread then sums its own few slots out of LDS.
+    constexpr int CH = 512;  // slots per chunk: 512 * 48 B = 24 KiB
+    __shared__ float4 stage[CH * 3];
+    const int g0 = blockIdx.x * blockDim.x;
+    const int idx = g0 + threadIdx.x;
+    const bool live = idx < P;
+    const uint32_t off = live ? offsets[idx] : 0u;
+    const uint32_t cnt = live ? tiles[idx] : 0u;
+    const uint32_t S0 = offsets[g0];
+    const uint32_t S1 = (g0 + 256 < P) ? offsets[g0 + 256] : (uint32_t)num_slots;
     double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
-    float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
-    const bool vis = radii[idx] > 0;
-
-    if (vis) {
-        const uint2 rc = rect[idx];
-        const int nt = (int)(((rc.x >> 16) - (rc.x & 0xffff)) * ((rc.y >> 16) - (rc.y & 0xffff)));
-        const float4* s = slots + (size_t)offsets[idx] * 3;
-        const unsigned long long mask = tmask[idx];
-        for (int j = 0; j < nt; j++) {
-            if (!gsr_mask_bit(mask, j)) continue;  // culled instances were never binned: their slot is unwritten
-            const float4 a = s[3 * j], b = s[3 * j + 1], c = s[3 * j + 2];
+    for (uint32_t c0 = S0; c0 < S1; c0 += CH) {
+        const uint32_t n4 = (min(S1, c0 + CH) - c0) * 3;
+        for (uint32_t i = threadIdx.x; i < n4; i += 256) stage[i] = slots[(size_t)c0 * 3 + i];
+        __syncthreads();
+        const uint32_t lo = max(off, c0), hi = min(off + cnt, c0 + CH);
+        for (uint32_t j = lo; j < hi; j++) {
+            const float4 a = stage[(j - c0) * 3], b = stage[(j - c0) * 3 + 1], c = stage[(j - c0) * 3 + 2];
             acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
             acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
             acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
         }
-        gcol[0] = (float)acc[0]; gcol[1] = (float)acc[1]; gcol[2] = (float)acc[2]; gdepth = (float)acc[3];
-        gfeat = (float)acc[4]; gm2x = (float)acc[5]; gm2y = (float)acc[6]; gcx = (float)acc[7];
-        gcy = (float)acc[8]; gcw = (float)acc[9]; gop = (float)acc[10];
+        __syncthreads();
+    }
+    if (!live) return;
 
+    float gcol[3] = { (float)acc[0], (float)acc[1], (float)acc[2] }, gdepth = (float)acc[3], gfeat = (float)acc[4];
+    float gm2x = (float)acc[5], gm2y = (float)acc[6], gcx = (float)acc[7], gcy = (float)acc[8], gcw = (float)acc[9];
+    float gop = (float)acc[10];
+    float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
+    const bool vis = radii[idx] > 0;
+
+    if (vis) {
         const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         float cov3D[6];
         float3 sc = make_float3(0.f, 0.f, 0.f);
@@ -247,14 +258,14 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
 
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
-                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
+                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots, int num_slots,
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream)
 {
     if (P <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_gauss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, cam, means3D, radii,
-                       shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets, geom.tmask,
+                       shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets, geom.tiles, num_slots,
                        reinterpret_cast<const float4*>(slots), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures,
                        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
     return hipGetLastError();

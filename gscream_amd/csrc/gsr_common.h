@@ -4,11 +4,10 @@
 //
 //   geom  : rec[P]       64 B  one cache line per Gaussian, gathered by the blend kernels
 //                              a = {px, py, conA, conB}   b = {conC, opacity, depth, feature}
-//                              c = {r, g, b, tau}         d = {offset, x0|x1<<16, y0|y1<<16, tiles}
-//                              (tau = ln(255 opacity) + margin: the blend kernels' quadrant-cull threshold)
+//                              c = {r, g, b, rect width}  d = {offset, x0|y0<<16, tile mask lo, hi}
 //           rect[P]       8 B  {x0|x1<<16, y0|y1<<16} tile rectangle (0,0 = culled)
 //           depthkey[P]   4 B  float bits of view-space depth (positive floats sort as uints)
-//           tiles[P]      4 B  tiles touched
+//           tiles[P]      4 B  surviving tiles of the rectangle = gradient slots of the Gaussian
 //           offsets[P]    4 B  exclusive scan of tiles = first gradient slot of the Gaussian
 //           tmask[P]      8 B  which tiles of the rectangle the Gaussian can actually change (tile culling)
 //           clamped[P*3]  1 B  SH clamp flags (only with SH colours)
@@ -161,7 +160,7 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
                                      hipStream_t stream);
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
-                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
+                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots, int num_slots,
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream);

@@ -130,6 +130,8 @@ __device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, floa
 // a degenerate conic or a non-positive opacity keeps the instance.
 #define GSR_CULL_MARGIN 0.01f
 __device__ __forceinline__ float gsr_cull_tau(float opacity) { return logf(255.0f * opacity) + GSR_CULL_MARGIN; }
+// v_log_f32 version for the blend kernels' quadrant test (1 ulp: irrelevant next to the margin)
+__device__ __forceinline__ float gsr_cull_tau_fast(float opacity) { return __logf(255.0f * opacity) + GSR_CULL_MARGIN; }
 
 __device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, float B, float C, float rA, float rC,
                                                   float tau, int tx, int ty, int W, int H)
@@ -140,6 +142,11 @@ __device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, f
 }
 // survivor bit of rectangle position i (row-major); rectangles larger than 64 tiles keep their tail
 __device__ __forceinline__ bool gsr_mask_bit(unsigned long long mask, int i) { return i >= 64 || ((mask >> i) & 1ull); }
+// number of surviving tiles of a rectangle with `area` tiles
+__device__ __forceinline__ int gsr_survivors(unsigned long long mask, int area)
+{
+    return area >= 64 ? __popcll(mask) + (area - 64) : __popcll(mask & ((1ull << area) - 1ull));
+}
 
 // Spherical-harmonics constants (DGR auxiliary.h:22-39)
 #define GSR_SH_C0 0.28209479177387814f

@@ -114,7 +114,6 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         return;
     }
     rect[idx] = rc;
-    tiles[idx] = ntiles;
     depthkey[idx] = __float_as_uint(viewz);
     unsigned long long mask = ~0ull;
     float tau = 0.f;
@@ -131,6 +130,7 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         }
     }
     tmask[idx] = mask;
+    tiles[idx] = radius > 0 ? (uint32_t)gsr_survivors(mask, (int)ntiles) : 0u;  // gradient slots of this Gaussian
     if (radius > 0) {
         float3 col;
         if (colors_precomp) col = make_float3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         GsrRec* r = rec + idx;
         r->a = make_float4(pix, piy, conx, cony);
         r->b = make_float4(conz, opacities[idx], viewz, features[idx]);
-        r->c = make_float4(col.x, col.y, col.z, tau);
+        r->c = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));  // .w = rectangle width
     }
 }
 

@@ -60,33 +60,38 @@ def test_binning_invariants(scene):
     R, color, depth, feat, radii, geom, binning, img, _ns = _forward_state(s, dev, rs)
     gv, iv, bv = _layout.geom_views(geom, P), _layout.image_views(img, P, W, H), _layout.binning_views(binning, R)
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    tiles = gv["tiles"].long()
-    assert R == int(iv["info"][0]) and int(tiles.sum()) == _ns
+    tiles = gv["tiles"].long()   # per-Gaussian gradient-slot count = surviving tiles of its rectangle
+    assert R == int(iv["info"][0]) == _ns and int(tiles.sum()) == R
     ranges = iv["ranges"].long()
     counts = ranges[:, 1] - ranges[:, 0]
     assert ranges[0, 0] == 0 and bool((ranges[1:, 0] == ranges[:-1, 1]).all()) and ranges[-1, 1] == R
     assert int(counts.max()) == int(iv["info"][1])
-    # independent recomputation of the per-tile counts from (pixel centre, radius) with torch float32 ops
+    # independent recomputation of the tile rectangles from (pixel centre, radius) with torch float32 ops
     rec = gv["rec_f32"]
     px, py, r = rec[:, 0], rec[:, 1], radii.float()
     vis = radii > 0
     x0 = torch.clamp(((px - r) / 16).int(), 0, gx); x1 = torch.clamp(((px + r + 15) / 16).int(), 0, gx)
     y0 = torch.clamp(((py - r) / 16).int(), 0, gy); y1 = torch.clamp(((py + r + 15) / 16).int(), 0, gy)
     x0, x1, y0, y1 = [torch.where(vis, v, torch.zeros_like(v)) for v in (x0, x1, y0, y1)]
-    assert bool(((x1 - x0) * (y1 - y0) == tiles).all()), "tiles_touched == rect area"
     rect = gv["rect"]
     assert bool(((rect[:, 0] & 0xffff) == x0).all() and ((rect[:, 0] >> 16) == x1).all())
+    assert bool(((rect[:, 1] & 0xffff) == y0).all() and ((rect[:, 1] >> 16) == y1).all())
     # expand every (Gaussian, tile-of-rectangle) pair, keep the survivors of the tile-cull mask, histogram them
-    offs = gv["offsets"].long()
-    nslots = int(tiles.sum())
-    g_of = torch.repeat_interleave(torch.arange(P, device="cuda"), tiles)
-    pos = torch.arange(nslots, device="cuda") - offs[g_of]
+    area = ((x1 - x0) * (y1 - y0)).long()
+    offs_exp = torch.cumsum(area, 0) - area
+    nexp = int(area.sum())
+    g_of = torch.repeat_interleave(torch.arange(P, device="cuda"), area)
+    pos = torch.arange(nexp, device="cuda") - offs_exp[g_of]
     wdt = (x1 - x0).long()[g_of]
     etx, ety = x0.long()[g_of] + pos % wdt, y0.long()[g_of] + pos // wdt
     alive = (pos >= 64) | (((gv["tmask"][g_of] >> pos.clamp(max=63)) & 1) == 1)
     hist = torch.bincount((ety * gx + etx)[alive], minlength=gx * gy)
     assert bool((hist == counts).all()), "per-tile counts == surviving (Gaussian, tile) pairs"
-    assert int(alive.sum()) == R and R < nslots, "tile culling must drop something on this workload"
+    assert int(alive.sum()) == R and R < nexp, "tile culling must drop something on this workload"
+    surv = torch.zeros(P, dtype=torch.int64, device="cuda").index_add_(0, g_of, alive.long())
+    assert bool((surv == tiles).all()), "slot count per Gaussian == surviving tiles"
+    offs = gv["offsets"].long()
+    assert bool((offs == torch.cumsum(tiles, 0) - tiles).all()), "offsets = exclusive scan of the slot counts"
     # sortedness of every tile list by (depth bits, id), and membership of every entry in its tile's rectangle
     pl = bv["point_list"].long()
     dk = gv["depthkey"].long()[pl] & 0xffffffff
@@ -96,10 +101,13 @@ def test_binning_invariants(scene):
     assert bool((key[1:][same] > key[:-1][same]).all()), "per-tile lists strictly ascending in (depth, id)"
     tx, ty = tile_of % gx, tile_of // gx
     assert bool(((tx >= x0[pl]) & (tx < x1[pl]) & (ty >= y0[pl]) & (ty < y1[pl])).all())
-    # gradient-slot map: offset + position inside the rectangle hits exactly the surviving slots, once each
-    slot = offs[pl] + (ty - y0[pl]) * (x1[pl] - x0[pl]).long() + (tx - x0[pl])
-    assert int(slot.min()) >= 0 and int(slot.max()) < nslots
-    assert bool((torch.sort(slot).values == torch.nonzero(alive).reshape(-1)).all())
+    # gradient-slot map of the backward blend: offset + rank of the tile among the survivors of its rectangle must
+    # be a bijection from the binned instances onto [0, R)
+    csum = torch.cumsum(alive.long(), 0) - alive.long()
+    e = offs_exp[pl] + (ty - y0[pl]) * (x1[pl] - x0[pl]).long() + (tx - x0[pl])
+    slot = offs[pl] + (csum[e] - csum[offs_exp[pl]])
+    assert bool(alive[e].all())
+    assert bool((torch.sort(slot).values == torch.arange(R, device="cuda")).all())
 
 
 def _rel_stats(got, ref):
