@@ -11,18 +11,18 @@
 //     into a private LDS list and walks only those: a typical splat touches 1-2 of the 4 quadrants, so the
 //     per-pixel test loop shrinks accordingly and the hit rate of what remains goes up.  The reference tests
 //     every instance of the tile against all 256 pixels (forward.cu:513-553).
-//   * Per-Gaussian operands reach the per-pixel math as SCALAR operands: each lane pulls ONE instance of its
-//     wave's list out of LDS (3 ds_read_b128 serve 64 instances) and the inner loop broadcasts lane k's values
-//     with v_readlane_b32 into SGPRs -- no LDS round trip per instance (measured: the broadcast ds_reads +
-//     4-lane LDS atomics kept the LDS 66 % busy with the VALU at 34 %).  The reference re-reads colour and
-//     depth from GLOBAL memory per contribution (forward.cu:545-546).
+//   * Per-Gaussian operands are read back from LDS with same-address (broadcast) ds_read_b128, conflict-free,
+//     software-pipelined one instance ahead; the list index comes from a per-lane copy via v_readlane (no
+//     dependent LDS read).  The reference re-reads colour and depth from GLOBAL memory per contribution
+//     (forward.cu:545-546).  (Broadcasting the operands themselves with v_readlane was measured slower.)
 //   * Early-out: a wave leaves the batch when all its pixels are done (__all); in the backward a wave skips
 //     gradient math + reduction when none of its pixels blends the instance (__any); the block leaves when
 //     every wave is done (__syncthreads_and).
 //   * Backward gradient scatter: the reference issues 11 global atomicAdd per (pixel, Gaussian) contribution
-//     (backward.cu:554-601).  Here the 11 partials are summed over the wave's 64 lanes with 6 DPP adds
-//     (quad_perm x2, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31) and lane 63 adds the wave total
-//     into an LDS accumulator [256][12] with one single-lane ds_add_f32 per value (built with
+//     (backward.cu:554-601).  Here each lane forms 11 partials (colour, depth, feature and six moments of
+//     G dL/dalpha), every partial is summed over the 16 lanes of a DPP row with 4 DPP adds, value i is kept in
+//     lane i, two lane-aligned cross-row adds (v_permlane32_swap / v_permlane16_swap) finish the wave sum, and
+//     lanes 0..10 add into an LDS accumulator [256][12] with ONE ds_add_f32 (built with
 //     -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch,
 //     thread i stores the 12 floats of instance i with three plain 16-byte stores into that instance's private
 //     gradient slot (slot = Gaussian's scan offset + tile position inside its rectangle); gauss_bwd.hip sums
@@ -70,38 +70,12 @@ __device__ __forceinline__ float gsr_row_sum16(float v)
     return v;
 }
 
-// Sum over all 64 lanes; the total lands in the last DPP row (lanes 48..63).
-__device__ __forceinline__ float gsr_wave_sum_to_row3(float v)
-{
-    v = gsr_row_sum16(v);
-    // row_bcast:15 into rows 1,3 then row_bcast:31 into rows 2,3 (lanes outside the row mask add 0)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
-    return v;
-}
-
-// Broadcast lane k's value to the whole wave through an SGPR (v_readlane_b32): per-Gaussian operands then
-// enter the per-pixel math as scalar operands -- no LDS round trip and no VGPRs per operand.
-__device__ __forceinline__ float gsr_bcast(float v, int k)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
-}
-
-// ---- A/B switches (compile-time; defaults chosen from measurements, see profiles/) ----
-//   GSR_{FWD,BWD}_READLANE = 1 : per-instance operands via v_readlane from a per-lane copy (else LDS broadcast reads)
-//   GSR_RED_MODE 0: 4-step row reduce per value, 4 row leaders issue one ds_add_f32 per value (9-11 LDS atomics)
-//                1: 6-step wave reduce per value, lane 63 issues one ds_add_f32 per value
-//                2: 4-step row reduce per value, pack value i into lane i of each row, 2 lane-aligned cross-row adds
-//                   (v_permlane32_swap / v_permlane16_swap) on the packed register, lanes 0..10 issue ONE ds_add_f32
-//                3: like 2 without the cross-row step: all four rows add (one instruction, 4 lanes per address)
-#ifndef GSR_FWD_READLANE
-#define GSR_FWD_READLANE 0
-#endif
-#ifndef GSR_BWD_READLANE
-#define GSR_BWD_READLANE 0
-#endif
-#ifndef GSR_RED_MODE
-#define GSR_RED_MODE 2
+// ---- A/B switch (compile-time; the default is the measured winner, see profiles/) ----
+//   GSR_PREFETCH = 1 : software-pipeline the instance loop: the wave's list indices sit one per lane (v_readlane
+//                      instead of a dependent LDS read) and the operands of instance k+1 are in flight while
+//                      instance k is computed.
+#ifndef GSR_PREFETCH
+#define GSR_PREFETCH 1
 #endif
 
 // 4-bit mask of the 8x8 quadrants of tile (tx, ty) in which the Gaussian can reach alpha >= 1/255.
@@ -177,47 +151,44 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
         const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [](int) { return true; });
         __builtin_amdgcn_wave_barrier();
 
-#if GSR_FWD_READLANE
-        // Each lane fetches ONE instance of the wave's list from LDS (3 x ds_read_b128 serve 64 instances);
-        // the k-loop then broadcasts lane k's operands with v_readlane instead of re-reading LDS per instance.
         for (int c0 = 0; c0 < nw; c0 += 64) {
             if (__all(done)) break;  // wave-uniform
-            const int mine = min(c0 + lane, nw - 1);
-            const int jj = mylist[mine];
-            const float4 a = sA[jj], b = sB[jj], c = sC[jj];
             const int m = min(64, nw - c0);
+#if GSR_PREFETCH
+            const int jj = mylist[min(c0 + lane, nw - 1)];
+            int j = __builtin_amdgcn_readlane(jj, 0);
+            float4 A = sA[j], B = sB[j];
+#endif
             for (int k = 0; k < m; k++) {
                 if (__all(done)) break;  // wave-uniform
-                const int j = __builtin_amdgcn_readlane(jj, k);
-                const float mx = gsr_bcast(a.x, k), my = gsr_bcast(a.y, k);
-                const float cA = gsr_bcast(a.z, k), cB = gsr_bcast(a.w, k), cC = gsr_bcast(b.x, k), op = gsr_bcast(b.y, k);
-#define GSR_FWD_C(i_) gsr_bcast(i_ == 0 ? c.x : i_ == 1 ? c.y : i_ == 2 ? c.z : i_ == 3 ? b.z : b.w, k)
+#if GSR_PREFETCH
+                const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
+                const float4 An = sA[jn], Bn = sB[jn];
 #else
-        {
-            for (int k = 0; k < nw; k++) {
-                if (__all(done)) break;  // wave-uniform
-                const int j = mylist[k];
+                const int j = mylist[c0 + k];
                 const float4 A = sA[j], B = sB[j];
-                const float mx = A.x, my = A.y, cA = A.z, cB = A.w, cC = B.x, op = B.y;
-#define GSR_FWD_C(i_) (i_ == 0 ? sC[j].x : i_ == 1 ? sC[j].y : i_ == 2 ? sC[j].z : i_ == 3 ? B.z : B.w)
 #endif
-                const float dx = mx - pxf, dy = my - pyf;
-                const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-                const float alpha = fminf(0.99f, op * GSR_EXP(power));
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                const float alpha = fminf(0.99f, B.y * GSR_EXP(power));
                 bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                if (!__any(ok)) continue;  // wave-uniform
-                const float test_T = Tr * (1.0f - alpha);
-                const bool stop = ok && test_T < 0.0001f;
-                done = done || stop;
-                ok = ok && !stop;
-                const float w = ok ? alpha * Tr : 0.0f;
-                C0 += GSR_FWD_C(0) * w; C1 += GSR_FWD_C(1) * w; C2 += GSR_FWD_C(2) * w;
-                Dp += GSR_FWD_C(3) * w; Uf += GSR_FWD_C(4) * w;
-                Tr = ok ? test_T : Tr;
-                last = ok ? (uint32_t)(base + j + 1) : last;
+                if (__any(ok)) {  // wave-uniform
+                    const float test_T = Tr * (1.0f - alpha);
+                    const bool stop = ok && test_T < 0.0001f;
+                    done = done || stop;
+                    ok = ok && !stop;
+                    const float w = ok ? alpha * Tr : 0.0f;
+                    const float4 C = sC[j];
+                    C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
+                    Dp += B.z * w; Uf += B.w * w;
+                    Tr = ok ? test_T : Tr;
+                    last = ok ? (uint32_t)(base + j + 1) : last;
+                }
+#if GSR_PREFETCH
+                j = jn; A = An; B = Bn;
+#endif
             }
         }
-#undef GSR_FWD_C
     }
 
     if (inside) {
@@ -311,105 +282,95 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
             const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [=](int i) { return hi - 1 - i < wmax; });
             __builtin_amdgcn_wave_barrier();
-#if GSR_BWD_READLANE
             for (int c0 = 0; c0 < nw; c0 += 64) {
-                const int mine = min(c0 + lane, nw - 1);
-                const int jj = mylist[mine];
-                const float4 a = sA[jj], b = sB[jj], c = sC[jj];
                 const int m = min(64, nw - c0);
+#if GSR_PREFETCH
+                const int jj = mylist[min(c0 + lane, nw - 1)];
+                int j = __builtin_amdgcn_readlane(jj, 0);
+                float4 A = sA[j], B = sB[j];
+#endif
                 for (int k = 0; k < m; k++) {
-                    const int j = __builtin_amdgcn_readlane(jj, k);
-                    const float mx = gsr_bcast(a.x, k), my = gsr_bcast(a.y, k);
-                    const float cA = gsr_bcast(a.z, k), cB = gsr_bcast(a.w, k), cC = gsr_bcast(b.x, k), op = gsr_bcast(b.y, k);
-#define GSR_BWD_C(i_) gsr_bcast(i_ == 0 ? c.x : i_ == 1 ? c.y : i_ == 2 ? c.z : i_ == 3 ? b.z : b.w, k)
+#if GSR_PREFETCH
+                    const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
+                    const float4 An = sA[jn], Bn = sB[jn];
 #else
-            {
-                for (int k = 0; k < nw; k++) {
-                    const int j = mylist[k];
+                    const int j = mylist[c0 + k];
                     const float4 A = sA[j], B = sB[j];
-                    const float mx = A.x, my = A.y, cA = A.z, cB = A.w, cC = B.x, op = B.y;
-#define GSR_BWD_C(i_) (i_ == 0 ? sC[j].x : i_ == 1 ? sC[j].y : i_ == 2 ? sC[j].z : i_ == 3 ? B.z : B.w)
 #endif
                     const int p = hi - 1 - j;
-                    const float dx = mx - pxf, dy = my - pyf;
-                    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
                     const float G = GSR_EXP(power);
-                    const float alpha = fminf(0.99f, op * G);
+                    const float alpha = fminf(0.99f, B.y * G);
                     const bool ok = p < lastc && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                    if (!__any(ok)) continue;  // wave-uniform: no pixel of this quadrant blends the instance
-
-                    float s[11];
+                    if (__any(ok)) {  // wave-uniform: some pixel of this quadrant blends the instance
+                        // per-lane partials: s0-2 colour, s3 depth, s4 feature, s5.. moments of g = G * dL/dalpha:
+                        // sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The per-Gaussian factors
+                        // (conic, opacity, -1/2, viewport scale) are applied once per instance at flush time.
+                        float s[11];
 #pragma unroll
-                    for (int v = 0; v < 11; v++) s[v] = 0.f;
-                    const float c0r = GSR_BWD_C(0), c1r = GSR_BWD_C(1), c2r = GSR_BWD_C(2);
-                    if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
-                        const float rinv = GSR_RCP(1.0f - alpha);
-                        const float Tn = Tr * rinv;  // T / (1 - alpha)
-                        const float w = alpha * Tn;
-                        const float oml = 1.0f - la;
-                        ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
-                        float dL_dalpha = (c0r - ar0) * g0 + (c1r - ar1) * g1 + (c2r - ar2) * g2;
-                        if (AUX) {
-                            const float cdr = GSR_BWD_C(3), cur = GSR_BWD_C(4);
-                            ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
-                            dL_dalpha += (cdr - ard) * gd + (cur - aru) * gu;
-                            s[3] = w * gd; s[4] = w * gu;
-                            lcd = cdr; lcu = cur;
+                        for (int v = 0; v < 11; v++) s[v] = 0.f;
+                        const float4 C = sC[j];
+                        if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
+                            const float rinv = GSR_RCP(1.0f - alpha);
+                            const float Tn = Tr * rinv;  // T / (1 - alpha)
+                            const float w = alpha * Tn;
+                            const float oml = 1.0f - la;
+                            ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
+                            float dL_dalpha = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
+                            if (AUX) {
+                                ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
+                                dL_dalpha += (B.z - ard) * gd + (B.w - aru) * gu;
+                                s[3] = w * gd; s[4] = w * gu;
+                                lcd = B.z; lcu = B.w;
+                            }
+                            dL_dalpha *= Tn;
+                            dL_dalpha += (-Tf * rinv) * bgdot;
+                            const float g = G * dL_dalpha;
+                            const float gdx = g * dx, gdy = g * dy;
+                            s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
+                            s[5] = gdx; s[6] = gdy; s[7] = gdx * dx; s[8] = gdx * dy; s[9] = gdy * dy; s[10] = g;
+                            Tr = Tn; la = alpha;
+                            lc0 = C.x; lc1 = C.y; lc2 = C.z;
                         }
-                        dL_dalpha *= Tn;
-                        dL_dalpha += (-Tf * rinv) * bgdot;
-                        const float dL_dG = op * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * cA - gdy * cB;
-                        const float dG_ddely = -gdy * cC - gdx * cB;
-                        s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
-                        s[5] = dL_dG * dG_ddelx * ddelx_dx; s[6] = dL_dG * dG_ddely * ddely_dy;
-                        s[7] = -0.5f * gdx * dx * dL_dG; s[8] = -0.5f * gdx * dy * dL_dG; s[9] = -0.5f * gdy * dy * dL_dG;
-                        s[10] = G * dL_dalpha;
-                        Tr = Tn; la = alpha;
-                        lc0 = c0r; lc1 = c1r; lc2 = c2r;
-                    }
-#if GSR_RED_MODE == 0 || GSR_RED_MODE == 1
-#pragma unroll
-                    for (int v = 0; v < 11; v++)
-                        if (AUX || (v != 3 && v != 4)) s[v] = GSR_RED_MODE == 1 ? gsr_wave_sum_to_row3(s[v]) : gsr_row_sum16(s[v]);
-                    if (GSR_RED_MODE == 1 ? lane == 63 : (lane & 15) == 0) {
-                        float* ac = acc + j * GSR_SLOT_FLOATS;
+                        // Row totals of every value (4 DPP adds each); lane i of each row keeps value i; two
+                        // lane-aligned cross-row adds (v_permlane32_swap / v_permlane16_swap, gfx950) bring the wave
+                        // totals to lanes 0..10, which issue ONE ds_add_f32 with 11 distinct addresses instead
+                        // of 9-11 LDS atomics (an LDS atomic costs ~13 LDS cycles whatever its lane count).
+                        float x = 0.f;
 #pragma unroll
                         for (int v = 0; v < 11; v++)
-                            if (AUX || (v != 3 && v != 4)) atomicAdd(ac + v, s[v]);
+                            if (AUX || (v != 3 && v != 4)) {
+                                const float rs = gsr_row_sum16(s[v]);
+                                x = (lane & 15) == v ? rs : x;
+                            }
+                        x += __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+                        x += __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+                        if (lane < 11) atomicAdd(acc + j * GSR_SLOT_FLOATS + lane, x);
                     }
-#else
-                    // Row totals of every value (4 DPP adds each), then lane i of each row keeps value i, so that
-                    // ONE ds_add_f32 with 11 distinct addresses replaces 9-11 LDS atomics (an LDS atomic
-                    // instruction costs ~13 LDS cycles whatever its lane count -- measured, profiles/).
-                    float x = 0.f;
-#pragma unroll
-                    for (int v = 0; v < 11; v++)
-                        if (AUX || (v != 3 && v != 4)) {
-                            const float rs = gsr_row_sum16(s[v]);
-                            x = (lane & 15) == v ? rs : x;
-                        }
-#if GSR_RED_MODE == 2
-                    // lane-aligned cross-row adds (DPP cannot move a lane across rows): v_permlane32_swap brings
-                    // lanes 32..63 under lanes 0..31, v_permlane16_swap brings row 1 under row 0 (gfx950)
-                    x += __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-                    x += __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-                    if (lane < 11) atomicAdd(acc + j * GSR_SLOT_FLOATS + lane, x);
-#else
-                    if ((lane & 15) < 11) atomicAdd(acc + j * GSR_SLOT_FLOATS + (lane & 15), x);
-#endif
+#if GSR_PREFETCH
+                    j = jn; A = An; B = Bn;
 #endif
                 }
             }
-#undef GSR_BWD_C
         }
         __syncthreads();
         if (t < cnt) {
             float4* a4 = reinterpret_cast<float4*>(acc + t * GSR_SLOT_FLOATS);
             float4* dst = slots + (size_t)sSlot[t] * 3;
-            dst[0] = a4[0]; dst[1] = a4[1]; dst[2] = a4[2];
-            if (active) { a4[0] = a4[1] = a4[2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            float4 o0 = a4[0], o1 = a4[1], o2 = a4[2];
+            if (active) {
+                // moments -> the reference's per-instance sums (DGR backward.cu:586-601):
+                //   dL/dmean2D = -o (cA Mx + cB My) W/2, -o (cC My + cB Mx) H/2;  dL/dconic = -o/2 (Mxx, Mxy, Myy);
+                //   dL/dopacity = M0            with M* = sum over pixels of G dL/dalpha {dx, dy, dx^2, dx dy, dy^2, 1}
+                const float4 A = sA[t], B = sB[t];
+                const float op = B.y, Mx = o1.y, My = o1.z, Mxx = o1.w, Mxy = o2.x, Myy = o2.y;
+                o1.y = -op * (A.z * Mx + A.w * My) * ddelx_dx;
+                o1.z = -op * (B.x * My + A.w * Mx) * ddely_dy;
+                o1.w = -0.5f * op * Mxx; o2.x = -0.5f * op * Mxy; o2.y = -0.5f * op * Myy;
+                a4[0] = a4[1] = a4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            dst[0] = o0; dst[1] = o1; dst[2] = o2;
         }
         __syncthreads();
     }
