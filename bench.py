@@ -111,18 +111,13 @@ def main():
     ap.add_argument("--no-tile-cull", action="store_true", help="bin every rectangle tile like the reference")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from gscream_amd import multi
+    rank, local_rank, world = multi.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path (the CPU oracle is only the baseline leg)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+    dist = multi.init("nccl", dev)  # nccl == RCCL on ROCm; None when WORLD_SIZE == 1
 
     from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer, _native, set_tuning
     from gscream_amd import synthetic as S
@@ -130,7 +125,7 @@ def main():
     set_tuning(tile_cull=not args.no_tile_cull)
 
     P, W, H, seed, gsel, desc = WORKLOADS[args.workload]
-    s = S.scene_slab(seed + 10 * rank if world > 1 else seed, P, W, H)  # one independent scene per GPU
+    s = S.scene_slab(multi.scene_seed(seed, rank, world), P, W, H)  # one independent scene per GPU
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     leaves = [t(s[k]).requires_grad_(True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")]
     means3D, opac, unc, colors, scales, rots = leaves
@@ -151,9 +146,7 @@ def main():
         return radii
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        multi.barrier(dist, dev)
 
     for _ in range(max(args.warmup, 1)):
         radii = step()
@@ -166,15 +159,17 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _native.profile_end()
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    total_steps, elapsed, rate = multi.aggregate_throughput(dist, args.steps, elapsed, dev)
 
-    # units for the byte model: R from one more (untimed) forward
+    # units for the byte model (untimed): instances actually binned, and the reference's num_rendered = every
+    # tile of every 3-sigma rectangle (one forward with tile culling off)
     from gscream_amd import rasterizer as RZ
-    R = RZ._last_stage1["num_rendered"]          # instances actually binned (after tile culling)
-    R_ref = RZ._last_stage1["num_slots"]         # sum of tiles_touched = the reference's num_rendered
+    R = RZ._last_stage1["num_rendered"]
+    with torch.no_grad():
+        set_tuning(tile_cull=False)
+        e = torch.Tensor([])
+        R_ref = RZ._forward_native(means3D, e, colors, opac, unc, scales, rots, e, rs)[0]
+        set_tuning(tile_cull=not args.no_tile_cull)
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     visible = int((radii > 0).sum())
 
@@ -199,7 +194,7 @@ def main():
                 traffic = None
         out = {
             "metric": "train iters/sec (fwd+bwd raster) @ 1M Gaussians, 1008x567",
-            "value": round(world * args.steps / elapsed, 3), "unit": "iters/s",
+            "value": round(rate, 3), "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,

@@ -1,0 +1,61 @@
+"""world_size-2 `gloo` tests of the multi-GPU plumbing (CPU): scene sharding and the throughput reduction that
+bench.py prints.  The raster path itself has no collective (one scene per GPU)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gscream_amd import multi  # noqa: E402
+
+
+def test_scene_assignment_covers_every_scene_once():
+    shares = multi.assign_scenes(10, 8)  # BASELINE.json config 5
+    assert len(shares) == 8 and sorted(sum(shares, [])) == list(range(10))
+    assert [len(s) for s in shares] == [2, 2, 1, 1, 1, 1, 1, 1]
+    assert multi.assign_scenes(3, 1) == [[0, 1, 2]] and multi.assign_scenes(1, 4) == [[0], [], [], []]
+    assert multi.scene_seed(1, 0, 1) == 1 and len({multi.scene_seed(1, r, 8) for r in range(8)}) == 8
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = multi.init("gloo")
+    assert dist is not None and dist.get_world_size() == world
+    multi.barrier(dist)
+    # rank r "rasterizes" its share of 5 scenes, 10 steps each, and is slower the higher its rank
+    my_scenes = multi.assign_scenes(5, world)[rank]
+    units, elapsed = 10 * len(my_scenes), 1.0 + 0.5 * rank
+    total, tmax, rate = multi.aggregate_throughput(dist, units, elapsed)
+    multi.barrier(dist)
+    out[rank] = (my_scenes, total, tmax, rate, multi.scene_seed(7, rank, world))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_throughput_reduction():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out[0][0] == [0, 2, 4] and out[1][0] == [1, 3]
+    for r in range(world):
+        _, total, tmax, rate, seed = out[r]
+        assert total == 50.0 and tmax == 1.5 and abs(rate - 50.0 / 1.5) < 1e-9  # all units / slowest rank
+    assert out[0][4] != out[1][4]
+
+
+def test_single_process_needs_no_process_group():
+    os.environ.pop("WORLD_SIZE", None)
+    assert multi.init("gloo") is None
+    total, tmax, rate = multi.aggregate_throughput(None, 20, 0.5)
+    assert (total, tmax, rate) == (20.0, 0.5, 40.0)

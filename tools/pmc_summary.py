@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Summarises the rocprofv3 --pmc passes written by tools/pmc_run.sh:
+   * prints a markdown table of the counters per gsr_* kernel (averages per dispatch), and
+   * writes profiles/pmc_latest.json = {workload: {stage: HBM bytes per launch}} which bench.py reports as
+     roofline.traffic.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB and come from
+separate passes; on gfx950 FETCH_SIZE reports HALF of the bytes of wide (16 B/lane) reads, so the read side is doubled
+(our kernels read with 16-byte loads); WRITE_SIZE is used as reported (uncalibrated).
+
+usage: python tools/pmc_summary.py gpurun_out/pmc config2 > profiles/rNN_pmc.md
+"""
+import collections
+import json
+import os
+import sqlite3
+import sys
+
+STAGE_OF = {
+    "gsr_preprocess_kernel<0>": "preprocess", "gsr_scan_reduce_kernel": "count_scan", "gsr_scan_sums_kernel": "count_scan",
+    "gsr_scan_apply_kernel": "count_scan", "gsr_tile_hist_kernel": "count_scan", "gsr_table_colscan_kernel": "count_scan",
+    "gsr_tile_scan_kernel": "count_scan", "gsr_scatter_kernel": "scatter", "gsr_tile_sort_lds_kernel": "tile_sort",
+    "gsr_tile_sort_global_kernel": "tile_sort", "gsr_blend_fwd_kernel": "blend_forward",
+    "gsr_blend_bwd_kernel<false>": "blend_backward", "gsr_blend_bwd_kernel<true>": "blend_backward",
+    "gsr_gauss_bwd_kernel": "gauss_backward",
+}
+
+
+def load(db):
+    cur = sqlite3.connect(db).cursor()
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name, cn, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+        short = name.split("(")[0].replace("void ", "")
+        if short.startswith("gsr_"):
+            out[short][cn].append(val)
+    return out
+
+
+def main():
+    d, workload = sys.argv[1], sys.argv[2]
+    res = collections.defaultdict(dict)
+    for f in sorted(os.listdir(d)):
+        if f.endswith("_results.db"):
+            for k, v in load(os.path.join(d, f)).items():
+                for c, vals in v.items():
+                    res[k][c] = sum(vals) / len(vals)
+    counters = sorted({c for v in res.values() for c in v})
+    print("| kernel | " + " | ".join(counters) + " |")
+    print("|---|" + "---:|" * len(counters))
+    for k in sorted(res):
+        print(f"| `{k}` | " + " | ".join(f"{res[k].get(c, float('nan')):.4g}" for c in counters) + " |")
+    traffic = collections.defaultdict(float)
+    for k, v in res.items():
+        st = STAGE_OF.get(k)
+        if st and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            traffic[st] += 2.0 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
+    print("\nHBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B):")
+    for st, b in traffic.items():
+        print(f"  {st:16s} {b / 1e6:9.1f} MB")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[workload] = {k: round(v) for k, v in traffic.items()}
+    json.dump(cur, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
