@@ -108,15 +108,27 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
     __syncthreads();
     int lo, hi;
     gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
-    for (int g = lo + threadIdx.x; g < hi; g += blockDim.x) {
-        const uint2 rc = rect[g];
-        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-        if (x0 == x1 || y0 == y1) continue;
-        const u64 mask = tmask[g];
-        int i = 0;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++, i++)
-                if (gsr_mask_bit(mask, i)) atomicAdd(&hist[y * gx + x], 1u);
+    // four Gaussians per thread per trip, loads issued together (the kernel is latency-bound: 8 waves per CU)
+    constexpr int U = 4;
+    for (int gb = lo + threadIdx.x; gb < hi; gb += blockDim.x * U) {
+        uint2 rcs[U];
+        u64 mks[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int g = gb + k * blockDim.x;
+            rcs[k] = g < hi ? rect[g] : make_uint2(0u, 0u);
+            mks[k] = g < hi ? tmask[g] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint2 rc = rcs[k];
+            const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+            const u64 mask = mks[k];
+            int i = 0;
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++, i++)
+                    if (gsr_mask_bit(mask, i)) atomicAdd(&hist[y * gx + x], 1u);
+        }
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -192,21 +204,38 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     __syncthreads();
     int lo, hi;
     gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
-    for (int g = lo + threadIdx.x; g < hi; g += blockDim.x) {
-        const uint2 rc = rect[g];
-        const uint32_t nt = tiles[g];
-        if (nt == 0) continue;
-        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-        const u64 key = ((u64)depthkey[g] << 32) | (uint32_t)g;
-        const u64 mask = tmask[g];
-        rec[g].d = make_uint4(offsets[g], (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
-        int i = 0;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++, i++) {
-                if (!gsr_mask_bit(mask, i)) continue;
-                const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                seg_keys[slot] = key;
-            }
+    constexpr int U = 4;
+    for (int gb = lo + threadIdx.x; gb < hi; gb += blockDim.x * U) {
+        uint2 rcs[U];
+        u64 mks[U];
+        uint32_t nts[U], dks[U], ofs[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int g = gb + k * blockDim.x;
+            const bool v = g < hi;
+            nts[k] = v ? tiles[g] : 0u;
+            rcs[k] = v ? rect[g] : make_uint2(0u, 0u);
+            mks[k] = v ? tmask[g] : 0ull;
+            dks[k] = v ? depthkey[g] : 0u;
+            ofs[k] = v ? offsets[g] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (nts[k] == 0) continue;
+            const int g = gb + k * blockDim.x;
+            const uint2 rc = rcs[k];
+            const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+            const u64 key = ((u64)dks[k] << 32) | (uint32_t)g;
+            const u64 mask = mks[k];
+            rec[g].d = make_uint4(ofs[k], (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+            int i = 0;
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++, i++) {
+                    if (!gsr_mask_bit(mask, i)) continue;
+                    const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
+                    seg_keys[slot] = key;
+                }
+        }
     }
 }
 

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
     const float projx = hx * p_w, projy = hy * p_w;
     const float viewz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
 
-    float conx = 0.f, cony = 0.f, conz = 0.f;
+    float conx = 0.f, cony = 0.f, conz = 0.f, cova = 0.f, covc = 0.f;
     if (viewz > 0.2f) {
         float cov3D[6];
         if (cov3D_precomp) {
@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         if (det != 0.0f) {
             const float det_inv = 1.f / det;
             conx = c2.c * det_inv; cony = -c2.b * det_inv; conz = c2.a * det_inv;
+            cova = c2.a; covc = c2.c;
             const float mid = 0.5f * (c2.a + c2.c);
             const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
             const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -122,11 +123,23 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         if (tile_cull) {
             const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
             const float rA = 1.0f / conx, rC = 1.0f / conz;
+            // Tiles outside the axis-aligned bounding box of the alpha >= 1/255 ellipse {q <= tau} cannot
+            // survive: |dx| <= sqrt(2 tau cov_xx), |dy| <= sqrt(2 tau cov_yy) (cov = inverse conic).  Only the
+            // tiles inside box & rectangle run the exact test; for a typical splat that is 1-4 of the 4-16
+            // rectangle tiles, and it bounds the trip count of the slowest lane of the wave.
+            const float t2 = 2.0f * fmaxf(tau, 0.0f);
+            const float ex = sqrtf(t2 * cova) + 1.0f, ey = sqrtf(t2 * covc) + 1.0f;  // +1 px slack
+            const int bx0 = max(x0, gsr_f2i((pix - ex) * 0.0625f)), bx1 = min(x1, gsr_f2i((pix + ex) * 0.0625f) + 1);
+            const int by0 = max(y0, gsr_f2i((piy - ey) * 0.0625f)), by1 = min(y1, gsr_f2i((piy + ey) * 0.0625f) + 1);
+            const int wd = x1 - x0;
             mask = 0ull;
-            int i = 0;
-            for (int y = y0; y < y1 && i < 64; y++)
-                for (int x = x0; x < x1 && i < 64; x++, i++)
-                    if (gsr_tile_survives(pix, piy, conx, cony, conz, rA, rC, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
+            if (!(tau == tau)) mask = ~0ull;  // NaN tau (non-positive opacity): keep everything, like the box test would
+            else
+                for (int y = by0; y < by1; y++)
+                    for (int x = bx0; x < bx1; x++) {
+                        const int i = (y - y0) * wd + (x - x0);
+                        if (i < 64 && gsr_tile_survives(pix, piy, conx, cony, conz, rA, rC, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
+                    }
         }
     }
     tmask[idx] = mask;

@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import _native
 
 _tuning = _native.Tuning()
+_pinned = {}  # per-device pinned int32[4] that receives gsr_stage1_result (truly asynchronous D2H copy)
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
@@ -89,7 +90,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     color = torch.zeros((3, H, W), **f32) if P == 0 else torch.empty((3, H, W), **f32)
     depth = torch.zeros((1, H, W), **f32) if P == 0 else torch.empty((1, H, W), **f32)
     unc = torch.zeros((1, H, W), **f32) if P == 0 else torch.empty((1, H, W), **f32)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev) if P == 0 else torch.empty((P,), dtype=torch.int32, device=dev)
     u8 = dict(dtype=torch.uint8, device=dev)
     if P == 0:
         e = torch.empty((0,), **u8)
@@ -104,7 +105,10 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
 
     geom = torch.empty((lib.gsr_geom_bytes(P),), **u8)
     img = torch.empty((lib.gsr_image_bytes(P, W, H),), **u8)
-    res = _native.Stage1Result()
+    pin = _pinned.get(dev.index)
+    if pin is None:
+        pin = _pinned[dev.index] = torch.zeros(4, dtype=torch.int32).pin_memory()
+    res = _native.ctypes.cast(pin.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result))
     with torch.cuda.device(dev):
         stream = _stream()
         rc = lib.gsr_forward_stage1(
@@ -112,8 +116,9 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
             _native.ptr(rot_c), _native.ptr(opac_c), _native.ptr(unc_c), _native.ptr(sh_c), _native.ptr(cov_c),
             _native.ptr(colors_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos), float(rs.tanfovx),
             float(rs.tanfovy), int(bool(rs.prefiltered)), _native.ptr(geom), _native.ptr(img), _native.ptr(radii),
-            _native.ctypes.byref(res), _native.ctypes.byref(_tuning), int(bool(rs.debug)), stream)
+            res, _native.ctypes.byref(_tuning), int(bool(rs.debug)), stream)
         _native.check(rc, "gsr_forward_stage1")
+        res = res.contents
         R = int(res.num_rendered)
         binning = torch.empty((lib.gsr_binning_bytes(R),), **u8)
         rc = lib.gsr_forward_stage2(
