@@ -121,13 +121,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            const uint2 rc = rcs[k];
-            const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-            const u64 mask = mks[k];
-            int i = 0;
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++, i++)
-                    if (gsr_mask_bit(mask, i)) atomicAdd(&hist[y * gx + x], 1u);
+            gsr_for_each_tile(rcs[k], mks[k], [&](int x, int y) { atomicAdd(&hist[y * gx + x], 1u); });
         }
     }
     __syncthreads();
@@ -224,17 +218,13 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             if (nts[k] == 0) continue;
             const int g = gb + k * blockDim.x;
             const uint2 rc = rcs[k];
-            const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
             const u64 key = ((u64)dks[k] << 32) | (uint32_t)g;
             const u64 mask = mks[k];
-            rec[g].d = make_uint4(ofs[k], (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
-            int i = 0;
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++, i++) {
-                    if (!gsr_mask_bit(mask, i)) continue;
-                    const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                    seg_keys[slot] = key;
-                }
+            rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+            gsr_for_each_tile(rc, mask, [&](int x, int y) {
+                const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
+                seg_keys[slot] = key;
+            });
         }
     }
 }

@@ -142,6 +142,29 @@ __device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, f
 }
 // survivor bit of rectangle position i (row-major); rectangles larger than 64 tiles keep their tail
 __device__ __forceinline__ bool gsr_mask_bit(unsigned long long mask, int i) { return i >= 64 || ((mask >> i) & 1ull); }
+// Calls f(x, y) for every surviving tile of the rectangle, in row-major order.  Walks the SET BITS of the
+// mask (a typical Gaussian keeps 1-4 of its 4-16 rectangle tiles), one row at a time so that no integer
+// division is needed; positions >= 64 (rectangles larger than 64 tiles) always survive.
+template <typename F>
+__device__ __forceinline__ void gsr_for_each_tile(const uint2 rc, unsigned long long mask, F f)
+{
+    const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+    const int w = x1 - x0;
+    if (w <= 0) return;
+    int base = 0;
+    for (int y = y0; y < y1 && base < 64; y++, base += w) {
+        unsigned long long rm = mask >> base;
+        if (w < 64) rm &= (1ull << w) - 1ull;
+        while (rm) {
+            const int b = __builtin_ctzll(rm);
+            rm &= rm - 1ull;
+            f(x0 + b, y);
+        }
+    }
+    const int area = w * (y1 - y0);
+    for (int i = 64; i < area; i++) f(x0 + i % w, y0 + i / w);
+}
+
 // number of surviving tiles of a rectangle with `area` tiles
 __device__ __forceinline__ int gsr_survivors(unsigned long long mask, int area)
 {
