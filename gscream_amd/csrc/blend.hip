@@ -70,6 +70,20 @@ __device__ __forceinline__ float gsr_row_sum16(float v)
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float gsr_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// One step of the transposing butterfly: lanes with `hi` clear keep value a, lanes with it set keep value b, and
+// each adds its partner's copy of the value it keeps.  Two registers become one: 3 VALU ops instead of 2 DPP adds.
+template <int CTRL>
+__device__ __forceinline__ float gsr_pair_step(float a, float b, bool hi)
+{
+    const float keep = hi ? b : a, send = hi ? a : b;
+    return keep + gsr_dpp<CTRL>(send);
+}
+
 // ---- A/B switch (compile-time; the default is the measured winner, see profiles/) ----
 //   GSR_PREFETCH = 1 : software-pipeline the instance loop: the wave's list indices sit one per lane (v_readlane
 //                      instead of a dependent LDS read) and the operands of instance k+1 are in flight while
@@ -333,20 +347,36 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                             Tr = Tn; la = alpha;
                             lc0 = C.x; lc1 = C.y; lc2 = C.z;
                         }
-                        // Row totals of every value (4 DPP adds each); lane i of each row keeps value i; two
-                        // lane-aligned cross-row adds (v_permlane32_swap / v_permlane16_swap, gfx950) bring the wave
-                        // totals to lanes 0..10, which issue ONE ds_add_f32 with 11 distinct addresses instead
-                        // of 9-11 LDS atomics (an LDS atomic costs ~13 LDS cycles whatever its lane count).
-                        float x = 0.f;
-#pragma unroll
-                        for (int v = 0; v < 11; v++)
-                            if (AUX || (v != 3 && v != 4)) {
-                                const float rs = gsr_row_sum16(s[v]);
-                                x = (lane & 15) == v ? rs : x;
-                            }
+                        // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly: the xor-1 and xor-2 steps
+                        // merge registers pairwise (lane l of a quad ends up owning value l & 3 of each group of
+                        // four), two row_ror steps sum the four quads of a DPP row, two lane-aligned cross-row adds
+                        // (v_permlane32_swap / v_permlane16_swap, gfx950) finish the wave sum, and lanes 0..8 (0..10)
+                        // issue ONE ds_add_f32 with distinct addresses.  26-31 VALU ops instead of 45-55 for nine to
+                        // eleven independent 4-step DPP reductions, and one LDS atomic instead of 9-11 (an LDS
+                        // atomic instruction costs ~13 LDS cycles whatever its lane count; measured, profiles/).
+                        const bool p1 = lane & 1, p2 = lane & 2;
+                        float q0, q1, q2;
+                        if (AUX) {
+                            const float r0 = gsr_pair_step<0xB1>(s[0], s[1], p1), r1 = gsr_pair_step<0xB1>(s[2], s[3], p1);
+                            const float r2 = gsr_pair_step<0xB1>(s[4], s[5], p1), r3 = gsr_pair_step<0xB1>(s[6], s[7], p1);
+                            const float r4 = gsr_pair_step<0xB1>(s[8], s[9], p1), r5 = s[10] + gsr_dpp<0xB1>(s[10]);
+                            q0 = gsr_pair_step<0x4E>(r0, r1, p2); q1 = gsr_pair_step<0x4E>(r2, r3, p2);
+                            q2 = gsr_pair_step<0x4E>(r4, r5, p2);  // quad lanes: s8, s9, s10, s10
+                        } else {
+                            const float r0 = gsr_pair_step<0xB1>(s[0], s[1], p1), r1 = gsr_pair_step<0xB1>(s[2], s[5], p1);
+                            const float r2 = gsr_pair_step<0xB1>(s[6], s[7], p1), r3 = gsr_pair_step<0xB1>(s[8], s[9], p1);
+                            const float r4 = s[10] + gsr_dpp<0xB1>(s[10]);
+                            q0 = gsr_pair_step<0x4E>(r0, r1, p2); q1 = gsr_pair_step<0x4E>(r2, r3, p2);
+                            q2 = r4 + gsr_dpp<0x4E>(r4);
+                        }
+                        q0 += gsr_dpp<0x124>(q0); q1 += gsr_dpp<0x124>(q1); q2 += gsr_dpp<0x124>(q2);  // row_ror:4
+                        q0 += gsr_dpp<0x128>(q0); q1 += gsr_dpp<0x128>(q1); q2 += gsr_dpp<0x128>(q2);  // row_ror:8
+                        const int li = lane & 15;
+                        float x = li < 4 ? q0 : (li < 8 ? q1 : q2);
                         x += __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
                         x += __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-                        if (lane < 11) atomicAdd(acc + j * GSR_SLOT_FLOATS + lane, x);
+                        // lane -> accumulator field: AUX: identity (0..10); else {0,1,2,5,6,7,8,9,10}
+                        if (lane < (AUX ? 11 : 9)) atomicAdd(acc + j * GSR_SLOT_FLOATS + (AUX || lane < 3 ? lane : lane + 2), x);
                     }
 #if GSR_PREFETCH
                     j = jn; A = An; B = Bn;
