@@ -37,16 +37,20 @@
 
 #define GSR_BATCH 256
 
-// Fast-math knobs of the blend inner loops.  Default: exp via v_exp_f32 (exp2(x*log2e), ~2 ulp) and
+// Fast-math knobs of the blend inner loops.  Default: exp via v_exp_f32 (the records hold the quadratic form
+// pre-multiplied by log2 e, so the exponent goes straight into the instruction; ~1 ulp) and
 // T/(1-alpha) via v_rcp_f32 (1 ulp).  -DGSR_PRECISE_MATH selects libm-accurate expf and IEEE division
 // (diagnostic build, used to attribute parity differences; not shipped).
 #ifdef GSR_PRECISE_MATH
-#define GSR_EXP(x) expf(x)
+#define GSR_EXP2(x) exp2f(x)
 #define GSR_RCP(x) (1.0f / (x))
 #else
-#define GSR_EXP(x) __expf(x)
+#define GSR_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define GSR_RCP(x) __builtin_amdgcn_rcpf(x)
 #endif
+// wave votes on lane masks the compiler already holds (HIP's __all/__any materialise a 0/1 VGPR first)
+#define GSR_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
+#define GSR_ALL(p) (__builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true))
 
 __device__ __forceinline__ int gsr_tile_of_block(int b, int T)
 {
@@ -96,14 +100,17 @@ __device__ __forceinline__ float gsr_pair_step(float a, float b, bool hi)
 __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const float4 B, const float tau, int tx, int ty,
                                                       int W, int H)
 {
-    const float rA = GSR_RCP(A.z), rC = GSR_RCP(B.x);
+    // records hold (hA, hB, hC) = -log2(e) (conA/2, conB, conC/2): q2 = log2(e) q = 0.5 (a dx^2 + c dy^2) + b dx dy with
+    // a = -2 hA, b = -hB, c = -2 hC; the threshold scales the same way
+    const float ca = -2.0f * A.z, cb = -A.w, cc = -2.0f * B.x;
+    const float rA = GSR_RCP(ca), rC = GSR_RCP(cc);
     uint32_t m = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int x0 = tx * 16 + (q & 1) * 8, y0 = ty * 16 + (q >> 1) * 8;
         const float bx1 = (float)min(x0 + 7, W - 1), by1 = (float)min(y0 + 7, H - 1);
         const bool hit = x0 < W && y0 < H &&
-                         !(gsr_box_min_q(A.x, A.y, A.z, A.w, B.x, rA, rC, (float)x0, bx1, (float)y0, by1) > tau);
+                         !(gsr_box_min_q(A.x, A.y, ca, cb, cc, rA, rC, (float)x0, bx1, (float)y0, by1) > tau);
         m |= hit ? (1u << q) : 0u;
     }
     return m;
@@ -159,14 +166,14 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
             const float4* r = reinterpret_cast<const float4*>(rec + point_list[rg.x + base + t]);
             const float4 a = r[0], b = r[1], c = r[2];
             sA[t] = a; sB[t] = b; sC[t] = c;
-            sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y), tx, ty, W, H);
+            sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
         }
         __syncthreads();
         const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [](int) { return true; });
         __builtin_amdgcn_wave_barrier();
 
         for (int c0 = 0; c0 < nw; c0 += 64) {
-            if (__all(done)) break;  // wave-uniform
+            if (GSR_ALL(done)) break;  // wave-uniform
             const int m = min(64, nw - c0);
 #if GSR_PREFETCH
             const int jj = mylist[min(c0 + lane, nw - 1)];
@@ -174,7 +181,7 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
             float4 A = sA[j], B = sB[j];
 #endif
             for (int k = 0; k < m; k++) {
-                if (__all(done)) break;  // wave-uniform
+                if (GSR_ALL(done)) break;  // wave-uniform
 #if GSR_PREFETCH
                 const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
                 const float4 An = sA[jn], Bn = sB[jn];
@@ -183,10 +190,10 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
                 const float4 A = sA[j], B = sB[j];
 #endif
                 const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                const float alpha = fminf(0.99f, B.y * GSR_EXP(power));
+                const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the Gaussian falloff
+                const float alpha = fminf(0.99f, B.y * GSR_EXP2(power));
                 bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                if (__any(ok)) {  // wave-uniform
+                if (GSR_ANY(ok)) {  // wave-uniform
                     const float test_T = Tr * (1.0f - alpha);
                     const bool stop = ok && test_T < 0.0001f;
                     done = done || stop;
@@ -287,7 +294,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             if (active) {
                 const float4 a = r->a, b = r->b;
                 sA[t] = a; sB[t] = b; sC[t] = c;
-                sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y), tx, ty, W, H);
+                sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
             }
         }
         __syncthreads();
@@ -313,11 +320,11 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
 #endif
                     const int p = hi - 1 - j;
                     const float dx = A.x - pxf, dy = A.y - pyf;
-                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                    const float G = GSR_EXP(power);
+                    const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the falloff
+                    const float G = GSR_EXP2(power);
                     const float alpha = fminf(0.99f, B.y * G);
                     const bool ok = p < lastc && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                    if (__any(ok)) {  // wave-uniform: some pixel of this quadrant blends the instance
+                    if (GSR_ANY(ok)) {  // wave-uniform: some pixel of this quadrant blends the instance
                         // per-lane partials: s0-2 colour, s3 depth, s4 feature, s5.. moments of g = G * dL/dalpha:
                         // sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The per-Gaussian factors
                         // (conic, opacity, -1/2, viewport scale) are applied once per instance at flush time.
@@ -395,8 +402,10 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                 //   dL/dopacity = M0            with M* = sum over pixels of G dL/dalpha {dx, dy, dx^2, dx dy, dy^2, 1}
                 const float4 A = sA[t], B = sB[t];
                 const float op = B.y, Mx = o1.y, My = o1.z, Mxx = o1.w, Mxy = o2.x, Myy = o2.y;
-                o1.y = -op * (A.z * Mx + A.w * My) * ddelx_dx;
-                o1.z = -op * (B.x * My + A.w * Mx) * ddely_dy;
+                const float k = -1.0f / GSR_LOG2E;  // back from the pre-scaled form to the conic (A, B, C)
+                const float cA = 2.0f * k * A.z, cB = k * A.w, cC = 2.0f * k * B.x;
+                o1.y = -op * (cA * Mx + cB * My) * ddelx_dx;
+                o1.z = -op * (cC * My + cB * Mx) * ddely_dy;
                 o1.w = -0.5f * op * Mxx; o2.x = -0.5f * op * Mxy; o2.y = -0.5f * op * Myy;
                 a4[0] = a4[1] = a4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }

@@ -3,7 +3,9 @@
 // HBM layout (P Gaussians, T = gx*gy 16x16 tiles, N = W*H pixels, R instances):
 //
 //   geom  : rec[P]       64 B  one cache line per Gaussian, gathered by the blend kernels
-//                              a = {px, py, conA, conB}   b = {conC, opacity, depth, feature}
+//                              a = {px, py, hA, hB}       b = {hC, opacity, depth, feature}
+//                              (hA,hB,hC) = -log2(e) * (conA/2, conB, conC/2): exponent of the Gaussian in
+//                              base 2 = dx (hA dx + hB dy) + hC dy^2, fed straight to v_exp_f32
 //                              c = {r, g, b, rect width}  d = {offset, x0|y0<<16, tile mask lo, hi}
 //           rect[P]       8 B  {x0|x1<<16, y0|y1<<16} tile rectangle (0,0 = culled)
 //           depthkey[P]   4 B  float bits of view-space depth (positive floats sort as uints)
@@ -32,6 +34,7 @@
 #define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
 #define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path
 #define GSR_SLOT_FLOATS 12
+#define GSR_LOG2E 1.4426950408889634f
 
 struct GsrRec {
     float4 a, b, c;

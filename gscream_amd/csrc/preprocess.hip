@@ -149,8 +149,9 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         if (colors_precomp) col = make_float3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
         else col = gsr_sh_to_rgb(idx, D, M, p, cam, shs, clamped);
         GsrRec* r = rec + idx;
-        r->a = make_float4(pix, piy, conx, cony);
-        r->b = make_float4(conz, opacities[idx], viewz, features[idx]);
+        // quadratic form pre-scaled for the blend loops: log2(alpha/opacity) = dx (hA dx + hB dy) + hC dy^2
+        r->a = make_float4(pix, piy, conx * (-0.5f * GSR_LOG2E), cony * (-GSR_LOG2E));
+        r->b = make_float4(conz * (-0.5f * GSR_LOG2E), opacities[idx], viewz, features[idx]);
         r->c = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));  // .w = rectangle width
     }
 }

@@ -223,7 +223,12 @@ def test_preprocess_outputs_are_bit_exact():
     rec = gv["rec_f32"].cpu().numpy()
     assert (got["radii"] == st["radii"]).all()
     assert np.array_equal(rec[vis, 0:2], st["means2D"][vis]), "pixel centres"
-    assert np.array_equal(rec[vis, 2:5], st["conic_opacity"][vis, :3]), "conic"
+    # the record stores the conic pre-scaled for v_exp_f32: (hA, hB, hC) = -log2(e) * (conA/2, conB, conC/2), one fp32
+    # multiply each, so the expected bits follow from the oracle's conic
+    L2E = np.float32(1.4426950408889634)
+    con = st["conic_opacity"][vis, :3]
+    exp_h = np.stack([con[:, 0] * (np.float32(-0.5) * L2E), con[:, 1] * (-L2E), con[:, 2] * (np.float32(-0.5) * L2E)], 1)
+    assert np.array_equal(rec[vis, 2:5], exp_h.astype(np.float32)), "conic (pre-scaled)"
     assert np.array_equal(rec[vis, 5], st["conic_opacity"][vis, 3]) and np.array_equal(rec[vis, 6], st["depths"][vis])
     assert np.array_equal(rec[vis, 7], st["unc"][vis]) and np.array_equal(rec[vis, 8:11], s["colors"][vis])
     tiles = gv["tiles"].cpu().numpy().astype(np.int64)
