@@ -151,13 +151,29 @@ def main():
     for _ in range(max(args.warmup, 1)):
         radii = step()
     barrier()
+    # Timed region: exactly K steps.  Only the dominant kernel (the backward blend, established by the warm-up
+    # profile below) is bracketed by HIP events here -- timing every stage inserts ~10 event markers per step and
+    # measurably stretches the step; the full per-stage profile is taken over K more steps afterwards.
     _native.profile_begin()
+    for _ in range(3):
+        step()
+    barrier()
+    wprof = _native.profile_end()
+    dom_stage = max(wprof, key=lambda k: wprof[k][0] / max(wprof[k][1], 1))
+    barrier()
+    _native.profile_begin([dom_stage])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    dom_prof = _native.profile_end()
+    _native.profile_begin()
+    for _ in range(args.steps):
+        step()
+    barrier()
     prof = _native.profile_end()
+    prof[dom_stage] = dom_prof[dom_stage]  # the roofline kernel's duration is the one measured in the timed region
 
     total_steps, elapsed, rate = multi.aggregate_throughput(dist, args.steps, elapsed, dev)
 

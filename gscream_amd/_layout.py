@@ -43,8 +43,9 @@ def image_views(buf, P, W, H):
     return out
 
 
-def binning_views(buf, R):
-    r = max(R, 1)
+def binning_views(buf, R, capacity=None):
+    """`capacity` = what the workspace was sized for (>= R after a speculative forward)."""
+    r = max(R if capacity is None else capacity, 1)
     off = 0
     out = {}
     out["seg_keys"] = _take(buf, off, r * 8, torch.int64, (r,))[:R]; off += _align(r * 8)

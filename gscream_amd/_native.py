@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsraster.so")  #
 #: every symbol include/gsraster.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "gsr_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
-    "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2",
+    "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
 )
 NUM_STAGES = 7
@@ -25,7 +25,8 @@ class Stage1Result(ctypes.Structure):
 
 
 class Tuning(ctypes.Structure):
-    _fields_ = [("disable_tile_cull", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
+    _fields_ = [("disable_tile_cull", ctypes.c_int32), ("disable_speculation", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 6)]
 
 
 class Profile(ctypes.Structure):
@@ -63,15 +64,20 @@ def load():
         + [_vp, _vp, _vp, ctypes.POINTER(Stage1Result), ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_forward_stage2.restype = _c_int
     lib.gsr_forward_stage2.argtypes = [_c_int] * 5 + [_vp] * 7 + [ctypes.POINTER(Tuning), _c_int, _vp]
+    lib.gsr_forward.restype = _c_int
+    lib.gsr_forward.argtypes = (
+        [_c_int] * 5 + [_vp, _vp, _c_float, _vp] + [_vp] * 5 + [_vp, _vp, _vp, _c_float, _c_float, _c_int]
+        + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, ctypes.POINTER(Stage1Result), ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_backward.restype = _c_int
     lib.gsr_backward.argtypes = (
-        [_c_int] * 6 + [_vp] * 6 + [_c_float] + [_vp] * 5 + [_c_float, _c_float] + [_vp] * 3 + [_vp] * 4
+        [_c_int] * 7 + [_vp] * 6 + [_c_float] + [_vp] * 5 + [_c_float, _c_float] + [_vp] * 3 + [_vp] * 4
         + [_vp] * 9 + [ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_filter.restype = _c_int
     lib.gsr_filter.argtypes = [_c_int] * 3 + [_vp, _vp, _c_float] + [_vp] * 4 + [_c_float, _c_float, _c_int] + [_vp] * 3 + [_c_int, _vp]
     lib.gsr_mark_visible.restype = _c_int
     lib.gsr_mark_visible.argtypes = [_c_int] + [_vp] * 5
     lib.gsr_profile_begin.restype = _c_int
+    lib.gsr_profile_begin.argtypes = [ctypes.c_uint]
     lib.gsr_profile_end.restype = _c_int
     lib.gsr_profile_end.argtypes = [ctypes.POINTER(Profile)]
     lib.gsr_stage_name.restype = ctypes.c_char_p
@@ -80,8 +86,14 @@ def load():
     return lib
 
 
-def profile_begin():
-    check(load().gsr_profile_begin(), "gsr_profile_begin")
+STAGE_NAMES = ("preprocess", "count_scan", "scatter", "tile_sort", "blend_forward", "blend_backward", "gauss_backward")
+NEED_CAPACITY = 1
+
+
+def profile_begin(stages=None):
+    """Start timing stages with HIP events (all stages, or only the named ones to keep the stream undisturbed)."""
+    mask = 0 if not stages else sum(1 << STAGE_NAMES.index(s) for s in stages)
+    check(load().gsr_profile_begin(mask), "gsr_profile_begin")
 
 
 def profile_end():

@@ -34,6 +34,7 @@ static const char* const g_stage_names[GSR_NUM_STAGES] = { "preprocess", "count_
 struct GsrProfRec { int stage; hipEvent_t t0, t1; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static unsigned g_prof_mask = 0xffffffffu;
 static std::vector<GsrProfRec> g_prof;
 
 struct GsrStageTimer {
@@ -43,7 +44,7 @@ struct GsrStageTimer {
     GsrStageTimer(int stage, hipStream_t s) : stream(s)
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (!g_prof_on) return;
+        if (!g_prof_on || !((g_prof_mask >> stage) & 1u)) return;
         if (hipEventCreate(&rec.t0) != hipSuccess || hipEventCreate(&rec.t1) != hipSuccess) return;
         rec.stage = stage;
         on = hipEventRecord(rec.t0, stream) == hipSuccess;
@@ -72,9 +73,10 @@ extern "C" const char* gsr_stage_name(int stage)
     return (stage >= 0 && stage < GSR_NUM_STAGES) ? g_stage_names[stage] : "";
 }
 
-extern "C" int gsr_profile_begin(void)
+extern "C" int gsr_profile_begin(unsigned stage_mask)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = stage_mask ? stage_mask : 0xffffffffu;
     for (auto& r : g_prof) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     g_prof.clear();
     g_prof_on = true;
@@ -145,6 +147,45 @@ static int gsr_check_dims(int P, int W, int H)
     return GSR_OK;
 }
 
+// Validates the stage-1 arguments and enqueues preprocess + counting + the 16-byte D2H copy of {R, max tile count}.
+static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* means3D, const float* scales,
+                              float scale_modifier, const float* rotations, const float* opacities,
+                              const float* features, const float* shs, const float* cov3D_precomp,
+                              const float* colors_precomp, const float* viewmatrix, const float* projmatrix,
+                              const float* campos, float tan_fovx, float tan_fovy, void* geom_ws, void* image_ws,
+                              int32_t* radii, uint32_t* info_host, const gsr_tuning* tuning, int debug, hipStream_t stream)
+{
+    if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    if ((!scales || !rotations) == (cov3D_precomp == nullptr))  // DGR __init__.py:227-228
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations or cov3D_precomp");
+    if ((shs == nullptr) == (colors_precomp == nullptr))  // DGR __init__.py:224-225
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of shs or colors_precomp");
+    if (shs && (!campos || M <= 0)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "SH colours need campos and M > 0");
+    GsrCam cam;
+    int rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, stream);
+    if (rc) return rc;
+    const GsrGeom geom = gsr_carve_geom(geom_ws, P);
+    const GsrImage image = gsr_carve_image(image_ws, P, W, H);
+    const int T = cam.gx * cam.gy;
+    GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(0, P, D, M, cam, means3D, scales, rotations, opacities, features, shs,
+                                    cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr,
+                                    !(tuning && tuning->disable_tile_cull), stream),
+              "preprocess");
+    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, stream), "tile count / scans");
+    GSR_HIP(hipMemcpyAsync(info_host, image.info, 8, hipMemcpyDeviceToHost, stream), "read num_rendered");
+    return GSR_OK;
+}
+
+static int gsr_publish_stage1(const uint32_t* info, gsr_stage1_result* out)
+{
+    if (info[0] > 0x7fffffffu) return gsr_fail(GSR_ERR_UNSUPPORTED, "instance count %u overflows int32", info[0]);
+    out->num_rendered = (int32_t)info[0];
+    out->max_tile_count = (int32_t)info[1];
+    out->num_slots = (int32_t)info[0];  // one gradient slot per binned instance
+    return GSR_OK;
+}
+
 extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float* means3D, const float* scales,
                                   float scale_modifier, const float* rotations, const float* opacities,
                                   const float* features, const float* shs, const float* cov3D_precomp,
@@ -158,46 +199,83 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     int rc = gsr_check_dims(P, W, H);
     if (rc) return rc;
     if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
-    result_host->num_rendered = 0;
-    result_host->max_tile_count = 0;
-    result_host->num_slots = 0;
+    memset(result_host, 0, sizeof(*result_host));
     if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:85
-    if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
-        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
-    if ((!scales || !rotations) == (cov3D_precomp == nullptr))  // DGR __init__.py:227-228
-        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations or cov3D_precomp");
-    if ((shs == nullptr) == (colors_precomp == nullptr))  // DGR __init__.py:224-225
-        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of shs or colors_precomp");
-    if (shs && (!campos || M <= 0)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "SH colours need campos and M > 0");
-
-    GsrCam cam;
-    rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, stream);
+    uint32_t* info = reinterpret_cast<uint32_t*>(result_host);  // {R, max} land in the first two fields
+    rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
+                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
+                            image_ws, radii, info, tuning, debug, stream);
     if (rc) return rc;
+    GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
+    uint32_t got[2] = { info[0], info[1] };
+    return gsr_publish_stage1(got, result_host);
+}
+
+static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, const float* background,
+                              void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
+                              float* out_feature, int debug, hipStream_t stream)
+{
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
-    const int T = cam.gx * cam.gy;
-
-    GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(0, P, D, M, cam, means3D, scales, rotations, opacities, features, shs,
-                                    cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr,
-                                    !(tuning && tuning->disable_tile_cull), stream),
-              "preprocess");
-    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, stream), "tile count / scans");
-    uint32_t info[2] = { 0, 0 }, nslots = 0;
-    GSR_HIP(hipMemcpyAsync(info, image.info, sizeof(info), hipMemcpyDeviceToHost, stream), "read num_rendered");
-    GSR_HIP(hipMemcpyAsync(&nslots, geom.scan_sums + gsr_scan_blocks(P), 4, hipMemcpyDeviceToHost, stream), "read num_slots");
-    GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
-    if (info[0] > 0x7fffffffu || nslots > 0x7fffffffu)
-        return gsr_fail(GSR_ERR_UNSUPPORTED, "instance count %u / %u overflows int32", info[0], nslots);
-    result_host->num_rendered = (int32_t)info[0];
-    result_host->max_tile_count = (int32_t)info[1];
-    result_host->num_slots = (int32_t)nslots;
+    const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
+    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, stream), "scatter");
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, image, bin, stream), "tile sort");
+    GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
+                                                            out_feature, capacity, stream),
+              "forward blend");
     return GSR_OK;
+}
+
+extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means3D, const float* scales,
+                           float scale_modifier, const float* rotations, const float* opacities, const float* features,
+                           const float* shs, const float* cov3D_precomp, const float* colors_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                           float tan_fovy, int prefiltered, const float* background, void* geom_ws, void* image_ws,
+                           void* binning_ws, int binning_capacity, int32_t* radii, float* out_color, float* out_depth,
+                           float* out_feature, gsr_stage1_result* result_host, const gsr_tuning* tuning, int debug,
+                           void* stream_)
+{
+    (void)prefiltered;
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = gsr_check_dims(P, W, H);
+    if (rc) return rc;
+    if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
+    memset(result_host, 0, sizeof(*result_host));
+    if (P == 0) return GSR_OK;
+    if (!background || !binning_ws || !out_color || !out_depth || !out_feature || binning_capacity <= 0)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL or the binning capacity is not positive");
+    // One event per thread marks "R is on the host"; stage 2 is enqueued BEFORE we wait for it, so the GPU never
+    // idles on the host round trip the reference pays at rasterizer_impl.cu:287.
+    static thread_local hipEvent_t ev = nullptr;
+    static thread_local int ev_dev = -1;
+    int dev = 0;
+    GSR_HIP(hipGetDevice(&dev), "hipGetDevice");
+    if (!ev || ev_dev != dev) {
+        GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        ev_dev = dev;
+    }
+    uint32_t* info = reinterpret_cast<uint32_t*>(result_host);
+    rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
+                            cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
+                            image_ws, radii, info, tuning, debug, stream);
+    if (rc) return rc;
+    GSR_HIP(hipEventRecord(ev, stream), "record");
+    rc = gsr_enqueue_stage2(P, W, H, binning_capacity, -1, background, geom_ws, image_ws, binning_ws, out_color,
+                            out_depth, out_feature, debug, stream);
+    if (rc) return rc;
+    GSR_HIP(hipEventSynchronize(ev), "read num_rendered");
+    uint32_t got[2] = { info[0], info[1] };
+    rc = gsr_publish_stage1(got, result_host);
+    if (rc) return rc;
+    return result_host->num_rendered > binning_capacity ? GSR_NEED_CAPACITY : GSR_OK;
 }
 
 extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const float* background,
                                   void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                                   float* out_feature, const gsr_tuning* tuning, int debug, void* stream_)
 {
+    (void)tuning;
     hipStream_t stream = (hipStream_t)stream_;
     int rc = gsr_check_dims(P, W, H);
     if (rc) return rc;
@@ -205,18 +283,12 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     if (!background || !geom_ws || !image_ws || !binning_ws || !out_color || !out_depth || !out_feature)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
-    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
-    const GsrGeom geom = gsr_carve_geom(geom_ws, P);
-    const GsrImage image = gsr_carve_image(image_ws, P, W, H);
-    const GsrBinning bin = gsr_carve_binning(binning_ws, R);
-    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, stream), "scatter");
-    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, R, max_tile_count, image, bin, stream), "tile sort");
-    GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth, out_feature, stream),
-              "forward blend");
-    return GSR_OK;
+    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, background, geom_ws, image_ws, binning_ws, out_color,
+                              out_depth, out_feature, debug, stream);
 }
 
-extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const float* background, const float* means3D,
+extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity, const float* background,
+                            const float* means3D,
                             const int32_t* radii, const float* colors_precomp, const float* shs, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
                             const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
@@ -249,7 +321,8 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, const floa
     const int T = cam.gx * cam.gy;
     const GsrGeom geom = gsr_carve_geom(const_cast<void*>(geom_ws), P);
     const GsrImage image = gsr_carve_image(const_cast<void*>(image_ws), P, W, H);
-    const GsrBinning bin = gsr_carve_binning(const_cast<void*>(binning_ws), R);
+    if (binning_capacity < R) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "binning_capacity < R");
+    const GsrBinning bin = gsr_carve_binning(const_cast<void*>(binning_ws), binning_capacity);
     float* slots = (float*)scratch;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,

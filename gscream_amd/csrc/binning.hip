@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const uint32_t* __restrict__ depthkey,
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ table,
-    const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, u64* __restrict__ seg_keys)
+    const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, u64* __restrict__ seg_keys, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
     const uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
             gsr_for_each_tile(rc, mask, [&](int x, int y) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                seg_keys[slot] = key;
+                if (slot < capacity) seg_keys[slot] = key;  // capacity < R only in a speculative launch that will be redone
             });
         }
     }
@@ -269,12 +269,12 @@ __device__ __forceinline__ void gsr_bitonic(KeyPtr k, const uint32_t n, const in
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
                                                                 const u64* __restrict__ seg_keys,
                                                                 uint32_t* __restrict__ point_list, uint32_t lo,
-                                                                uint32_t hi)
+                                                                uint32_t hi, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) u64 keys[];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n <= lo || n > hi) return;
+    if (n <= lo || n > hi || rg.y > capacity) return;
     for (uint32_t i = threadIdx.x; i < n; i += 256) keys[i] = seg_keys[rg.x + i];
     __syncthreads();
     gsr_bitonic(keys, n, 256);
@@ -285,11 +285,12 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
 // image with a huge cloud).  Same network, in place on seg_keys, one 1024-thread block per tile.
 __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2* __restrict__ ranges,
                                                                     u64* __restrict__ seg_keys,
-                                                                    uint32_t* __restrict__ point_list, uint32_t lo)
+                                                                    uint32_t* __restrict__ point_list, uint32_t lo,
+                                                                    uint32_t capacity)
 {
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n <= lo) return;
+    if (n <= lo || rg.y > capacity) return;
     u64* k = seg_keys + rg.x;
     gsr_bitonic(k, n, 1024);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[rg.x + i] = (uint32_t)k[i];
@@ -298,6 +299,23 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
 // ---------------------------------------------------------------------------------------------
 // Host launchers
 // ---------------------------------------------------------------------------------------------
+// Dynamic LDS beyond 64 KiB needs a one-time opt-in per kernel and device (kept out of the per-call path: a
+// hipFuncSetAttribute between the stage-1 read-back and the stage-2 launches is exposed GPU idle time).
+static hipError_t gsr_allow_big_lds()
+{
+    static thread_local int done_for_device = -1;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (done_for_device == dev) return hipSuccess;
+    const int big = 160 * 1024 - 1024;
+    e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) done_for_device = dev;
+    return e;
+}
+
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
@@ -309,8 +327,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
                        geom.offsets);
     // (2) per-chunk tile histogram -> table
     const size_t lds = (size_t)T * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_tile_hist_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
                        geom.rect, geom.tmask, image.table);
@@ -323,37 +340,37 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
 }
 
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              hipStream_t stream)
+                              int capacity, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
     const size_t lds = (size_t)T * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)gsr_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
                        geom.rect, geom.depthkey, geom.offsets, geom.tiles, geom.tmask, image.table, image.ranges, geom.rec,
-                       bin.seg_keys);
+                       bin.seg_keys, (uint32_t)capacity);
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_tile_sort(int T, int R, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
                                 hipStream_t stream)
 {
-    if (R <= 0) return hipSuccess;
+    // max_tile_count < 0: not known yet (speculative launch) -> run every size class, blocks exit on mismatch
+    if (capacity <= 0) return hipSuccess;
+    if (max_tile_count < 0) max_tile_count = 0x7fffffff;
     hipError_t e;
     // size classes: (0, SMALL] in 32 KiB LDS, (SMALL, LARGE] in 128 KiB LDS, longer in global memory
     hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_SMALL * 8, stream,
-                       image.ranges, bin.seg_keys, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL);
+                       image.ranges, bin.seg_keys, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)capacity);
     if (max_tile_count > GSR_SORT_CAP_SMALL) {
-        e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GSR_SORT_CAP_LARGE * 8);
+        e = gsr_allow_big_lds();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_LARGE * 8, stream,
                            image.ranges, bin.seg_keys, bin.point_list, (uint32_t)GSR_SORT_CAP_SMALL,
-                           (uint32_t)GSR_SORT_CAP_LARGE);
+                           (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     }
     if (max_tile_count > GSR_SORT_CAP_LARGE)
         hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, bin.seg_keys,
-                           bin.point_list, (uint32_t)GSR_SORT_CAP_LARGE);
+                           bin.point_list, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     return hipGetLastError();
 }

@@ -138,7 +138,7 @@ __device__ __forceinline__ int gsr_compact(const uint32_t* sQ, uint16_t* list, i
 __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+    float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t capacity)
 {
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ uint32_t sQ[GSR_BATCH];
@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 rg = ranges[tile];
+    uint2 rg = ranges[tile];
+    rg.x = min(rg.x, capacity); rg.y = min(rg.y, capacity);  // only bites in a speculative launch that is redone
     const int n = (int)(rg.y - rg.x);
     const bool inside = px < W && py < H;
 
@@ -418,11 +419,11 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, hipStream_t stream)
+                                    float* out_feature, int capacity, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
-                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib);
+                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, (uint32_t)capacity);
     return hipGetLastError();
 }
 

@@ -151,12 +151,12 @@ hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* vie
                                    hipStream_t stream);
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream);
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              hipStream_t stream);
-hipError_t gsr_launch_tile_sort(int T, int R, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
+                              int capacity, hipStream_t stream);
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
                                 hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, hipStream_t stream);
+                                    float* out_feature, int capacity, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots,

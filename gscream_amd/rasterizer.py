@@ -22,14 +22,19 @@ import torch.nn as nn
 from . import _native
 
 _tuning = _native.Tuning()
+_capacity_hint = {}  # per-device: binning capacity that let the last forward run without a host round trip
 _pinned = {}  # per-device pinned int32[4] that receives gsr_stage1_result (truly asynchronous D2H copy)
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
-def set_tuning(tile_cull=True):
-    """Performance knob.  Images, radii and gradients do not depend on it; tile_cull=False bins every tile of
-    every rectangle, which makes the internal per-tile lists and num_rendered bit-identical to the reference's."""
+def set_tuning(tile_cull=True, speculative=True):
+    """Performance knobs.  Images, radii and gradients do not depend on them.
+    tile_cull=False bins every tile of every rectangle: the internal per-tile lists and num_rendered become
+    bit-identical to the reference's.  speculative=False always uses the two-stage forward (host reads
+    num_rendered, then sizes the binning workspace exactly), like the reference's blocking read-back."""
     _tuning.disable_tile_cull = 0 if tile_cull else 1
+    _tuning.disable_speculation = 0 if speculative else 1
+    _capacity_hint.clear()
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -109,28 +114,45 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     if pin is None:
         pin = _pinned[dev.index] = torch.zeros(4, dtype=torch.int32).pin_memory()
     res = _native.ctypes.cast(pin.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result))
+    debug = int(bool(rs.debug))
+    common = (P, int(rs.sh_degree), M, W, H, _native.ptr(means3D_c), _native.ptr(scales_c), float(rs.scale_modifier),
+              _native.ptr(rot_c), _native.ptr(opac_c), _native.ptr(unc_c), _native.ptr(sh_c), _native.ptr(cov_c),
+              _native.ptr(colors_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos), float(rs.tanfovx),
+              float(rs.tanfovy), int(bool(rs.prefiltered)))
+    outs = (_native.ptr(color), _native.ptr(depth), _native.ptr(unc))
     with torch.cuda.device(dev):
         stream = _stream()
-        rc = lib.gsr_forward_stage1(
-            P, int(rs.sh_degree), M, W, H, _native.ptr(means3D_c), _native.ptr(scales_c), float(rs.scale_modifier),
-            _native.ptr(rot_c), _native.ptr(opac_c), _native.ptr(unc_c), _native.ptr(sh_c), _native.ptr(cov_c),
-            _native.ptr(colors_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos), float(rs.tanfovx),
-            float(rs.tanfovy), int(bool(rs.prefiltered)), _native.ptr(geom), _native.ptr(img), _native.ptr(radii),
-            res, _native.ctypes.byref(_tuning), int(bool(rs.debug)), stream)
-        _native.check(rc, "gsr_forward_stage1")
+        cap = _capacity_hint.get(dev.index, 0)
+        done = False
+        if cap > 0 and not _tuning.disable_speculation:
+            # Speculative single call: stage 2 is enqueued before the host learns num_rendered, against a workspace
+            # sized from the previous frames.  No GPU-idle window; redone below only if the guess was too small.
+            binning = torch.empty((lib.gsr_binning_bytes(cap),), **u8)
+            rc = lib.gsr_forward(*common, _native.ptr(bg), _native.ptr(geom), _native.ptr(img), _native.ptr(binning), cap,
+                                 _native.ptr(radii), *outs, res, _native.ctypes.byref(_tuning), debug, stream)
+            if rc not in (0, _native.NEED_CAPACITY):
+                _native.check(rc, "gsr_forward")
+            done = rc == 0
+        else:
+            rc = lib.gsr_forward_stage1(*common, _native.ptr(geom), _native.ptr(img), _native.ptr(radii), res,
+                                        _native.ctypes.byref(_tuning), debug, stream)
+            _native.check(rc, "gsr_forward_stage1")
         res = res.contents
         R = int(res.num_rendered)
-        binning = torch.empty((lib.gsr_binning_bytes(R),), **u8)
-        rc = lib.gsr_forward_stage2(
-            P, W, H, R, int(res.max_tile_count), _native.ptr(bg), _native.ptr(geom), _native.ptr(img),
-            _native.ptr(binning), _native.ptr(color), _native.ptr(depth), _native.ptr(unc),
-            _native.ctypes.byref(_tuning), int(bool(rs.debug)), stream)
-        _native.check(rc, "gsr_forward_stage2")
-    _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots))
-    return R, color, depth, unc, radii, geom, binning, img, int(res.num_slots)
+        if not done:
+            cap = R
+            binning = torch.empty((lib.gsr_binning_bytes(cap),), **u8)
+            rc = lib.gsr_forward_stage2(P, W, H, R, int(res.max_tile_count), _native.ptr(bg), _native.ptr(geom),
+                                        _native.ptr(img), _native.ptr(binning), *outs, _native.ctypes.byref(_tuning),
+                                        debug, stream)
+            _native.check(rc, "gsr_forward_stage2")
+        _capacity_hint[dev.index] = int(1.25 * R) + 65536
+    _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots),
+                        binning_capacity=cap, speculative=done)
+    return R, color, depth, unc, radii, geom, binning, img, cap
 
 
-def _backward_native(rs, num_rendered, num_slots, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
+def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
                      geom, binning, img, g_color, g_depth, g_unc):
     """The work of `_C.rasterize_gaussians_backward` (DGR rasterize_points.cu:124-211)."""
     lib = _native.load()
@@ -165,10 +187,10 @@ def _backward_native(rs, num_rendered, num_slots, means3D, radii, colors_precomp
     # could hand its block to the next temporary
     means3D_c, colors_c, sh_c = _f32c(means3D), _f32c(colors_precomp, dev), _f32c(sh, dev)
     scales_c, rot_c, cov_c = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
-    scratch = torch.empty((lib.gsr_backward_scratch_bytes(P, num_slots),), dtype=torch.uint8, device=dev)
+    scratch = torch.empty((lib.gsr_backward_scratch_bytes(P, num_rendered),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gsr_backward(
-            P, int(rs.sh_degree), M, W, H, int(num_rendered), _native.ptr(bg), _native.ptr(means3D_c),
+            P, int(rs.sh_degree), M, W, H, int(num_rendered), int(binning_capacity), _native.ptr(bg), _native.ptr(means3D_c),
             _native.ptr(radii), _native.ptr(colors_c), _native.ptr(sh_c),
             _native.ptr(scales_c), float(rs.scale_modifier), _native.ptr(rot_c),
             _native.ptr(cov_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos),
@@ -200,10 +222,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         else:
             out = _forward_native(*args)
-        num_rendered, color, depth, uncertainty, radii, geom, binning, img, num_slots = out
+        num_rendered, color, depth, uncertainty, radii, geom, binning, img, capacity = out
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
-        ctx.num_slots = num_slots
+        ctx.binning_capacity = capacity
         ctx.opacity_shape, ctx.uncertainty_shape = opacities.shape, uncertainties.shape
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
@@ -216,7 +238,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_out_color is None and grad_out_depth is None and grad_out_uncertainty is None:
             return (None,) * 10
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        args = (rs, ctx.num_rendered, ctx.num_slots, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
+        args = (rs, ctx.num_rendered, ctx.binning_capacity, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
                 geom, binning, img, grad_out_color, grad_out_depth, grad_out_uncertainty)
         if rs.debug:
             saved = _snapshot(args)

@@ -39,7 +39,8 @@ typedef enum gsr_status {
     GSR_ERR_INVALID_ARGUMENT = -1,
     GSR_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed */
     GSR_ERR_UNSUPPORTED = -3,  /* e.g. more tiles than the binning kernels support */
-    GSR_ERR_NO_DEVICE = -4
+    GSR_ERR_NO_DEVICE = -4,
+    GSR_NEED_CAPACITY = 1      /* gsr_forward only: the binning workspace was too small, see there */
 } gsr_status;
 
 /* Result of forward stage 1, written to host memory (pinned memory avoids a staging copy). */
@@ -58,7 +59,9 @@ typedef struct gsr_tuning {
     int32_t disable_tile_cull; /* 1 = bin every tile of the rectangle like the reference (the internal per-tile
                                   lists and num_rendered become bit-identical to the reference's; slower).
                                   Default 0: skip tiles the Gaussian cannot change (gsr_math.h) */
-    int32_t reserved[7];
+    int32_t disable_speculation; /* host-side hint (the library ignores it): 1 = the binding should always use the
+                                  two-stage forward instead of gsr_forward */
+    int32_t reserved[6];
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */
@@ -112,6 +115,24 @@ int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const flo
                        const gsr_tuning* tuning, int debug, void* stream);
 
 /*
+ * Forward in ONE call, without the GPU-idle window of the two-stage form.  The caller passes a binning workspace
+ * sized for `binning_capacity` instances (gsr_binning_bytes(binning_capacity); e.g. 1.25 x the previous frame's
+ * num_rendered).  Stage 2 is enqueued before the host waits for num_rendered, so the device never waits for the
+ * host.  Returns GSR_OK when num_rendered <= binning_capacity (outputs valid; keep `binning_capacity` for
+ * gsr_backward).  Returns GSR_NEED_CAPACITY (> 0) otherwise: nothing was written out of bounds, but the images are
+ * invalid -- allocate gsr_binning_bytes(result_host->num_rendered) and call gsr_forward_stage2 to redo stage 2.
+ */
+int gsr_forward(int P, int D, int M, int W, int H,
+                const float* means3D, const float* scales, float scale_modifier, const float* rotations,
+                const float* opacities, const float* features, const float* shs,
+                const float* cov3D_precomp, const float* colors_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* campos,
+                float tan_fovx, float tan_fovy, int prefiltered, const float* background,
+                void* geom, void* image, void* binning, int binning_capacity, int32_t* radii,
+                float* out_color, float* out_depth, float* out_feature, gsr_stage1_result* result_host,
+                const gsr_tuning* tuning, int debug, void* stream);
+
+/*
  * Backward.  Replaces CudaRasterizer::Rasterizer::backward (DGR rasterizer_impl.cu:536-643):
  * BACKWARD::render + computeCov2DCUDA + preprocessCUDA(bwd).  geom/image/binning are the buffers
  * the forward filled.  Every output row is written (culled Gaussians get exact zeros), so the
@@ -121,7 +142,8 @@ int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const flo
  * dL_dout_depth and dL_dout_feature may both be NULL (= no gradient flows into those maps; a cheaper
  * kernel variant runs).  No floating-point atomics on global memory are used.
  */
-int gsr_backward(int P, int D, int M, int W, int H, int R, const float* background,
+int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity /* what the forward's binning
+                 workspace was sized for; = R after the two-stage forward */, const float* background,
                  const float* means3D, const int32_t* radii, const float* colors_precomp, const float* shs,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* viewmatrix, const float* projmatrix, const float* campos,
@@ -154,7 +176,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * of HIP events recorded on the stream the stage is launched on.  gsr_profile_end() waits for them and
  * returns the per-stage totals.  This is the only process-wide state in the library; off by default.
  */
-int gsr_profile_begin(void);
+int gsr_profile_begin(unsigned stage_mask /* bit i = time stage i; 0 = all */);
 int gsr_profile_end(gsr_profile* out_host);
 const char* gsr_stage_name(int stage);
 

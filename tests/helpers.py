@@ -85,7 +85,7 @@ def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False):
         R, color, depth, unc, radii, geom, binning, img, _ns = RZ._forward_native(
             inp["means3D"].detach(), g("shs"), g("colors_precomp"), inp["opacities"].detach(),
             inp["uncertainties"].detach(), g("scales"), g("rotations"), g("cov3D_precomp"), rs)
-        out.update(num_rendered=R, geom=geom, binning=binning, img=img)
+        out.update(num_rendered=R, geom=geom, binning=binning, img=img, binning_capacity=_ns)
     else:
         color, depth, unc, radii = rast(means3D=inp["means3D"], means2D=means2D, opacities=inp["opacities"],
                                         uncertainties=inp["uncertainties"], **kw)

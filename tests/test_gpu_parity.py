@@ -34,7 +34,7 @@ def _check_binning(s, got, exp_point_list, exp_tile_counts):
     counts = rng[:, 1] - rng[:, 0]
     assert (counts == exp_tile_counts.astype(np.int64)).all(), "per-tile instance counts"
     assert rng[0, 0] == 0 and (rng[1:, 0] == rng[:-1, 1]).all() and rng[-1, 1] == R, "ranges must partition [0,R)"
-    pl = _layout.binning_views(got["binning"], R)["point_list"].cpu().numpy().astype(np.int64)
+    pl = _layout.binning_views(got["binning"], R, got["binning_capacity"])["point_list"].cpu().numpy().astype(np.int64)
     assert (pl == exp_point_list.astype(np.int64)).all(), "sorted per-tile Gaussian id lists"
 
 
@@ -63,7 +63,7 @@ def _check_culled_binning(s, got, st):
     gx = (W + 15) // 16
     img = _layout.image_views(got["img"], P, W, H)
     rng = img["ranges"].cpu().numpy().astype(np.int64)
-    pl = _layout.binning_views(got["binning"], R)["point_list"].cpu().numpy().astype(np.int64)
+    pl = _layout.binning_views(got["binning"], R, got["binning_capacity"])["point_list"].cpu().numpy().astype(np.int64)
     assert rng[0, 0] == 0 and (rng[1:, 0] == rng[:-1, 1]).all() and rng[-1, 1] == R
     ref_rng, ref_pl = st["ranges"].astype(np.int64), st["point_list"].astype(np.int64)
     m2, co = st["means2D"].astype(np.float64), st["conic_opacity"].astype(np.float64)
@@ -322,3 +322,33 @@ def test_non_default_stream_and_strided_inputs():
     img = r(big[:, 2:5], torch.zeros(s["means3D"].shape[0], 3, device="cuda"), t(s["opacities"]), t(s["uncertainties"]),
             colors_precomp=t(s["colors"]), scales=t(s["scales"]), rotations=t(s["rotations"]))[0]
     Hh.assert_images_close(img.cpu().numpy(), exp["out_color"], "strided means3D")
+
+
+def test_speculative_forward_and_capacity_overflow():
+    """gsr_forward enqueues stage 2 before the host knows num_rendered, against a workspace sized from previous
+    frames.  A too-small guess must be detected and redone; a sufficient one must give the same bits as the
+    two-stage path."""
+    from gscream_amd import rasterizer as RZ
+    s, grads, exp = MG.load("cfg1")
+    set_tuning(speculative=False)
+    ref = Hh.hip_run(s, grads)
+    assert RZ._last_stage1["speculative"] is False
+    set_tuning()                                   # clears the capacity history: first call is two-stage
+    a = Hh.hip_run(s, grads)
+    assert RZ._last_stage1["speculative"] is False and RZ._capacity_hint[0] > int(exp["num_rendered"])
+    b = Hh.hip_run(s, grads)                        # now speculative, capacity sufficient
+    assert RZ._last_stage1["speculative"] is True and RZ._last_stage1["binning_capacity"] >= RZ._last_stage1["num_rendered"]
+    RZ._capacity_hint[0] = 64                       # far too small: kernels must not write out of bounds, call is redone
+    c = Hh.hip_run(s, grads)
+    assert RZ._last_stage1["speculative"] is False and RZ._last_stage1["binning_capacity"] == RZ._last_stage1["num_rendered"]
+    for got in (a, b, c):
+        for k in ("out_color", "out_depth", "out_unc", "radii"):
+            assert np.array_equal(got[k], ref[k]), k
+        Hh.assert_grads_nearly_equal(got, ref, context="speculative vs two-stage")
+    st = Hh.hip_run(s, keep_state=True)             # speculative again, oversized workspace: lists still exact
+    assert st["binning_capacity"] > st["num_rendered"]
+    set_tuning(tile_cull=False)
+    Hh.hip_run(s)
+    st = Hh.hip_run(s, keep_state=True)
+    assert RZ._last_stage1["speculative"] is True
+    _check_binning(s, st, exp["point_list"], exp["tile_counts"])
