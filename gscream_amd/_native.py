@@ -67,7 +67,7 @@ def load():
     lib.gsr_forward.restype = _c_int
     lib.gsr_forward.argtypes = (
         [_c_int] * 5 + [_vp, _vp, _c_float, _vp] + [_vp] * 5 + [_vp, _vp, _vp, _c_float, _c_float, _c_int]
-        + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, ctypes.POINTER(Stage1Result), ctypes.POINTER(Tuning), _c_int, _vp])
+        + [_vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, ctypes.POINTER(Stage1Result), ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_backward.restype = _c_int
     lib.gsr_backward.argtypes = (
         [_c_int] * 7 + [_vp] * 6 + [_c_float] + [_vp] * 5 + [_c_float, _c_float] + [_vp] * 3 + [_vp] * 4

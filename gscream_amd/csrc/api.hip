@@ -232,9 +232,9 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                            const float* shs, const float* cov3D_precomp, const float* colors_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                            float tan_fovy, int prefiltered, const float* background, void* geom_ws, void* image_ws,
-                           void* binning_ws, int binning_capacity, int32_t* radii, float* out_color, float* out_depth,
-                           float* out_feature, gsr_stage1_result* result_host, const gsr_tuning* tuning, int debug,
-                           void* stream_)
+                           void* binning_ws, int binning_capacity, int max_tile_count_hint, int32_t* radii,
+                           float* out_color, float* out_depth, float* out_feature, gsr_stage1_result* result_host,
+                           const gsr_tuning* tuning, int debug, void* stream_)
 {
     (void)prefiltered;
     hipStream_t stream = (hipStream_t)stream_;
@@ -261,14 +261,17 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                             image_ws, radii, info, tuning, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipEventRecord(ev, stream), "record");
-    rc = gsr_enqueue_stage2(P, W, H, binning_capacity, -1, background, geom_ws, image_ws, binning_ws, out_color,
-                            out_depth, out_feature, debug, stream);
+    rc = gsr_enqueue_stage2(P, W, H, binning_capacity, max_tile_count_hint > 0 ? max_tile_count_hint : -1, background,
+                            geom_ws, image_ws, binning_ws, out_color, out_depth, out_feature, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipEventSynchronize(ev), "read num_rendered");
     uint32_t got[2] = { info[0], info[1] };
     rc = gsr_publish_stage1(got, result_host);
     if (rc) return rc;
-    return result_host->num_rendered > binning_capacity ? GSR_NEED_CAPACITY : GSR_OK;
+    // the guesses hold iff every list fitted the workspace AND the sort variants that were launched cover the longest list
+    const bool ok = result_host->num_rendered <= binning_capacity &&
+                    (max_tile_count_hint <= 0 || result_host->max_tile_count <= max_tile_count_hint);
+    return ok ? GSR_OK : GSR_NEED_CAPACITY;
 }
 
 extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const float* background,

@@ -150,9 +150,10 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-    uint2 rg = ranges[tile];
-    rg.x = min(rg.x, capacity); rg.y = min(rg.y, capacity);  // only bites in a speculative launch that is redone
-    const int n = (int)(rg.y - rg.x);
+    const uint2 rg = ranges[tile];
+    // a list that does not fit the workspace was neither scattered completely nor sorted (speculative launch that
+    // the host redoes): treat it as empty instead of following unsorted ids
+    const int n = rg.y > capacity ? 0 : (int)(rg.y - rg.x);
     const bool inside = px < W && py < H;
 
     bool done = !inside;

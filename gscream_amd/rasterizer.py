@@ -122,14 +122,14 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     outs = (_native.ptr(color), _native.ptr(depth), _native.ptr(unc))
     with torch.cuda.device(dev):
         stream = _stream()
-        cap = _capacity_hint.get(dev.index, 0)
+        cap, tile_hint = _capacity_hint.get(dev.index, (0, 0))
         done = False
         if cap > 0 and not _tuning.disable_speculation:
             # Speculative single call: stage 2 is enqueued before the host learns num_rendered, against a workspace
             # sized from the previous frames.  No GPU-idle window; redone below only if the guess was too small.
             binning = torch.empty((lib.gsr_binning_bytes(cap),), **u8)
             rc = lib.gsr_forward(*common, _native.ptr(bg), _native.ptr(geom), _native.ptr(img), _native.ptr(binning), cap,
-                                 _native.ptr(radii), *outs, res, _native.ctypes.byref(_tuning), debug, stream)
+                                 tile_hint, _native.ptr(radii), *outs, res, _native.ctypes.byref(_tuning), debug, stream)
             if rc not in (0, _native.NEED_CAPACITY):
                 _native.check(rc, "gsr_forward")
             done = rc == 0
@@ -146,7 +146,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
                                         _native.ptr(img), _native.ptr(binning), *outs, _native.ctypes.byref(_tuning),
                                         debug, stream)
             _native.check(rc, "gsr_forward_stage2")
-        _capacity_hint[dev.index] = int(1.25 * R) + 65536
+        _capacity_hint[dev.index] = (int(1.25 * R) + 65536, max(4096, int(1.5 * res.max_tile_count)))
     _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots),
                         binning_capacity=cap, speculative=done)
     return R, color, depth, unc, radii, geom, binning, img, cap

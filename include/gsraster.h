@@ -118,9 +118,11 @@ int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const flo
  * Forward in ONE call, without the GPU-idle window of the two-stage form.  The caller passes a binning workspace
  * sized for `binning_capacity` instances (gsr_binning_bytes(binning_capacity); e.g. 1.25 x the previous frame's
  * num_rendered).  Stage 2 is enqueued before the host waits for num_rendered, so the device never waits for the
- * host.  Returns GSR_OK when num_rendered <= binning_capacity (outputs valid; keep `binning_capacity` for
- * gsr_backward).  Returns GSR_NEED_CAPACITY (> 0) otherwise: nothing was written out of bounds, but the images are
- * invalid -- allocate gsr_binning_bytes(result_host->num_rendered) and call gsr_forward_stage2 to redo stage 2.
+ * host.  `max_tile_count_hint` (> 0) bounds the longest per-tile list the caller expects: only the sort variants
+ * needed for it are launched; <= 0 launches all of them.  Returns GSR_OK when num_rendered <= binning_capacity and
+ * max_tile_count <= hint (outputs valid; keep `binning_capacity` for gsr_backward).  Returns GSR_NEED_CAPACITY (> 0)
+ * otherwise: nothing was written out of bounds, but the images are invalid -- allocate
+ * gsr_binning_bytes(result_host->num_rendered) and call gsr_forward_stage2 to redo stage 2.
  */
 int gsr_forward(int P, int D, int M, int W, int H,
                 const float* means3D, const float* scales, float scale_modifier, const float* rotations,
@@ -128,7 +130,7 @@ int gsr_forward(int P, int D, int M, int W, int H,
                 const float* cov3D_precomp, const float* colors_precomp,
                 const float* viewmatrix, const float* projmatrix, const float* campos,
                 float tan_fovx, float tan_fovy, int prefiltered, const float* background,
-                void* geom, void* image, void* binning, int binning_capacity, int32_t* radii,
+                void* geom, void* image, void* binning, int binning_capacity, int max_tile_count_hint, int32_t* radii,
                 float* out_color, float* out_depth, float* out_feature, gsr_stage1_result* result_host,
                 const gsr_tuning* tuning, int debug, void* stream);
 

@@ -335,16 +335,21 @@ def test_speculative_forward_and_capacity_overflow():
     assert RZ._last_stage1["speculative"] is False
     set_tuning()                                   # clears the capacity history: first call is two-stage
     a = Hh.hip_run(s, grads)
-    assert RZ._last_stage1["speculative"] is False and RZ._capacity_hint[0] > int(exp["num_rendered"])
+    assert RZ._last_stage1["speculative"] is False and RZ._capacity_hint[0][0] > int(exp["num_rendered"])
     b = Hh.hip_run(s, grads)                        # now speculative, capacity sufficient
     assert RZ._last_stage1["speculative"] is True and RZ._last_stage1["binning_capacity"] >= RZ._last_stage1["num_rendered"]
-    RZ._capacity_hint[0] = 64                       # far too small: kernels must not write out of bounds, call is redone
+    RZ._capacity_hint[0] = (64, 4096)               # far too small: kernels must not write out of bounds, call is redone
     c = Hh.hip_run(s, grads)
     assert RZ._last_stage1["speculative"] is False and RZ._last_stage1["binning_capacity"] == RZ._last_stage1["num_rendered"]
     for got in (a, b, c):
         for k in ("out_color", "out_depth", "out_unc", "radii"):
             assert np.array_equal(got[k], ref[k]), k
         Hh.assert_grads_nearly_equal(got, ref, context="speculative vs two-stage")
+    RZ._capacity_hint[0] = (1 << 20, 8)              # workspace fine, but the longest list exceeds the hinted sort variant
+    d = Hh.hip_run(s, grads)
+    assert RZ._last_stage1["speculative"] is False
+    for k in ("out_color", "out_depth", "out_unc", "radii"):
+        assert np.array_equal(d[k], ref[k]), k
     st = Hh.hip_run(s, keep_state=True)             # speculative again, oversized workspace: lists still exact
     assert st["binning_capacity"] > st["num_rendered"]
     set_tuning(tile_cull=False)
