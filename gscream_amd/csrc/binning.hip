@@ -139,18 +139,28 @@ __global__ void __launch_bounds__(256) gsr_table_colscan_kernel(int T, int nchun
     const int tile = blockIdx.x * 64 + tl;
     const int per = (nchunks + 3) / 4;
     const int c0 = grp * per, c1 = min(nchunks, c0 + per);
+    // each thread owns <= 64 table rows of one tile: keep them in registers between the two passes (the loads of
+    // the first pass are independent, so they are all in flight together; the second pass needs no re-read)
+    constexpr int MAXR = GSR_MAX_CHUNKS / 4;
+    uint32_t v[MAXR];
     uint32_t s = 0;
-    if (tile < T)
-        for (int c = c0; c < c1; c++) s += table[(size_t)c * T + tile];
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) {
+        const int c = c0 + r;
+        v[r] = (tile < T && c < c1) ? table[(size_t)c * T + tile] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) s += v[r];
     part[grp][tl] = s;
     __syncthreads();
     uint32_t run = 0;
     for (int g2 = 0; g2 < grp; g2++) run += part[g2][tl];
     if (tile < T) {
-        for (int c = c0; c < c1; c++) {
-            const uint32_t v = table[(size_t)c * T + tile];
-            table[(size_t)c * T + tile] = run;
-            run += v;
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            const int c = c0 + r;
+            if (c < c1) table[(size_t)c * T + tile] = run;
+            run += v[r];
         }
         if (grp == 3) tile_count[tile] = part[0][tl] + part[1][tl] + part[2][tl] + part[3][tl];
     }
@@ -265,6 +275,82 @@ __device__ __forceinline__ void gsr_bitonic(KeyPtr k, const uint32_t n, const in
     }
 }
 
+// ---- LDS version with fused strides: 8 keys per thread stay in registers for three consecutive compare-exchange
+// distances, so a 2048-key list needs 29 LDS round trips (+ barriers) instead of 66.  Same network, same result.
+#define GSR_KEY_INF 0xffffffffffffffffull
+__device__ __forceinline__ void gsr_cex(u64& a, u64& b)
+{
+    const u64 lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+// half-cleaners at strides q*2^(L-1) ... q on the 2^L keys {base + t*q}; q = 2^lq
+template <int L>
+__device__ __forceinline__ void gsr_fused_round(u64* k, uint32_t n, uint32_t m, int lq, int nthreads)
+{
+    constexpr int E = 1 << L;
+    const uint32_t groups = m >> L, qm = (1u << lq) - 1u;
+    for (uint32_t g = threadIdx.x; g < groups; g += nthreads) {
+        const uint32_t base = ((g >> lq) << (L + lq)) + (g & qm);
+        u64 v[E];
+#pragma unroll
+        for (int t = 0; t < E; t++) {
+            const uint32_t i = base + ((uint32_t)t << lq);
+            v[t] = i < n ? k[i] : GSR_KEY_INF;
+        }
+#pragma unroll
+        for (int h = E >> 1; h >= 1; h >>= 1)
+#pragma unroll
+            for (int t = 0; t < E; t++)
+                if ((t & h) == 0) gsr_cex(v[t], v[t + h]);
+#pragma unroll
+        for (int t = 0; t < E; t++) {
+            const uint32_t i = base + ((uint32_t)t << lq);
+            if (i < n) k[i] = v[t];
+        }
+    }
+}
+
+__device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, const int nthreads)
+{
+    uint32_t lm = 3;
+    while ((1u << lm) < n) lm++;
+    const uint32_t m = 1u << lm;
+    // phase 0: every run of 8 consecutive keys sorted in registers (the merges of size 2, 4, 8)
+    for (uint32_t c = threadIdx.x; c < (m >> 3); c += nthreads) {
+        u64 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = 8 * c + t < n ? k[8 * c + t] : GSR_KEY_INF;
+        gsr_cex(v[0], v[1]); gsr_cex(v[2], v[3]); gsr_cex(v[4], v[5]); gsr_cex(v[6], v[7]);   // size 2
+        gsr_cex(v[0], v[3]); gsr_cex(v[1], v[2]); gsr_cex(v[4], v[7]); gsr_cex(v[5], v[6]);   // size 4: flip
+        gsr_cex(v[0], v[1]); gsr_cex(v[2], v[3]); gsr_cex(v[4], v[5]); gsr_cex(v[6], v[7]);   //         stride 1
+        gsr_cex(v[0], v[7]); gsr_cex(v[1], v[6]); gsr_cex(v[2], v[5]); gsr_cex(v[3], v[4]);   // size 8: flip
+        gsr_cex(v[0], v[2]); gsr_cex(v[1], v[3]); gsr_cex(v[4], v[6]); gsr_cex(v[5], v[7]);   //         stride 2
+        gsr_cex(v[0], v[1]); gsr_cex(v[2], v[3]); gsr_cex(v[4], v[5]); gsr_cex(v[6], v[7]);   //         stride 1
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (8 * c + t < n) k[8 * c + t] = v[t];
+    }
+    __syncthreads();
+    for (uint32_t ls = 4; ls <= lm; ls++) {
+        const uint32_t lh = ls - 1, half = 1u << lh;
+        for (uint32_t t = threadIdx.x; t < (m >> 1); t += nthreads) {  // flip: i <-> mirror inside the 2^ls block
+            const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
+            const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;
+            if (j < n) {
+                const u64 a = k[i], b = k[j];
+                if (a > b) { k[i] = b; k[j] = a; }
+            }
+        }
+        __syncthreads();
+        for (int hs = (int)ls - 2; hs >= 0; hs -= 3) {  // half-cleaner strides 2^hs ... 1, three per round
+            if (hs >= 2) gsr_fused_round<3>(k, n, m, hs - 2, nthreads);
+            else if (hs == 1) gsr_fused_round<2>(k, n, m, 0, nthreads);
+            else gsr_fused_round<1>(k, n, m, 0, nthreads);
+            __syncthreads();
+        }
+    }
+}
+
 // LDS variant for lo < n <= hi (dynamic LDS = 8 * hi bytes).
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
                                                                 const u64* __restrict__ seg_keys,
@@ -277,7 +363,7 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     if (n <= lo || n > hi || rg.y > capacity) return;
     for (uint32_t i = threadIdx.x; i < n; i += 256) keys[i] = seg_keys[rg.x + i];
     __syncthreads();
-    gsr_bitonic(keys, n, 256);
+    gsr_sort_lds_fused(keys, n, 256);
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
 }
 
