@@ -220,7 +220,7 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, stream), "scatter");
-    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, image, bin, stream), "tile sort");
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
                                                             out_feature, capacity, stream),
               "forward blend");

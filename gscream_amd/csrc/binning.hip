@@ -10,8 +10,8 @@
 // = ascending id (SURVEY A-9).  Keys are unique, so the result does not depend on the order in
 // which the scatter claims slots.
 //
-// HBM traffic: hist reads rect (8 B/G); table NB*T*4 B written, scanned, read; scatter reads
-// 16 B/G and writes 8 B/instance + 16 B/G (record tail); sort reads 8 B and writes 4 B per instance.
+// HBM traffic: hist reads rect + mask (16 B/G); table NB*T*4 B written, scanned, read; scatter reads 24 B/G and
+// writes 4 B/instance (the id) + 16 B/G (record tail); sort reads 4 B + a 4-B depth gather and writes 4 B per instance.
 #include "gsr_math.h"
 
 typedef unsigned long long u64;
@@ -197,10 +197,9 @@ __global__ void __launch_bounds__(256) gsr_tile_scan_kernel(int T, const uint32_
 // rectangle (slot claimed with an LDS atomic on the chunk's cursor row), and completes its record.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
-    int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const uint32_t* __restrict__ depthkey,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const u64* __restrict__ tmask,
+    int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ table,
-    const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, u64* __restrict__ seg_keys, uint32_t capacity)
+    const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, uint32_t* __restrict__ point_list, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
     const uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -212,7 +211,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     for (int gb = lo + threadIdx.x; gb < hi; gb += blockDim.x * U) {
         uint2 rcs[U];
         u64 mks[U];
-        uint32_t nts[U], dks[U], ofs[U];
+        uint32_t nts[U], ofs[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
@@ -220,7 +219,6 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             nts[k] = v ? tiles[g] : 0u;
             rcs[k] = v ? rect[g] : make_uint2(0u, 0u);
             mks[k] = v ? tmask[g] : 0ull;
-            dks[k] = v ? depthkey[g] : 0u;
             ofs[k] = v ? offsets[g] : 0u;
         }
 #pragma unroll
@@ -228,12 +226,11 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             if (nts[k] == 0) continue;
             const int g = gb + k * blockDim.x;
             const uint2 rc = rcs[k];
-            const u64 key = ((u64)dks[k] << 32) | (uint32_t)g;
             const u64 mask = mks[k];
             rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
             gsr_for_each_tile(rc, mask, [&](int x, int y) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                if (slot < capacity) seg_keys[slot] = key;  // capacity < R only in a speculative launch that will be redone
+                if (slot < capacity) point_list[slot] = (uint32_t)g;  // capacity < R only in a speculative launch that is redone
             });
         }
     }
@@ -353,7 +350,7 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
 
 // LDS variant for lo < n <= hi (dynamic LDS = 8 * hi bytes).
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
-                                                                const u64* __restrict__ seg_keys,
+                                                                const uint32_t* __restrict__ depthkey,
                                                                 uint32_t* __restrict__ point_list, uint32_t lo,
                                                                 uint32_t hi, uint32_t capacity)
 {
@@ -361,7 +358,12 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || n > hi || rg.y > capacity) return;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) keys[i] = seg_keys[rg.x + i];
+    // the scatter left the tile's Gaussian ids (4 B each) in its segment of point_list; the 64-bit sort key
+    // (depth bits, id) is assembled here with a gather from the 4 MB depth array (L2-resident)
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t id = point_list[rg.x + i];
+        keys[i] = ((u64)depthkey[id] << 32) | id;
+    }
     __syncthreads();
     gsr_sort_lds_fused(keys, n, 256);
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
@@ -370,6 +372,7 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
 // Global-memory variant for lists longer than the LDS capacity (degenerate inputs: e.g. a tiny
 // image with a huge cloud).  Same network, in place on seg_keys, one 1024-thread block per tile.
 __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2* __restrict__ ranges,
+                                                                    const uint32_t* __restrict__ depthkey,
                                                                     u64* __restrict__ seg_keys,
                                                                     uint32_t* __restrict__ point_list, uint32_t lo,
                                                                     uint32_t capacity)
@@ -378,6 +381,11 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || rg.y > capacity) return;
     u64* k = seg_keys + rg.x;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t id = point_list[rg.x + i];
+        k[i] = ((u64)depthkey[id] << 32) | id;
+    }
+    __syncthreads();
     gsr_bitonic(k, n, 1024);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[rg.x + i] = (uint32_t)k[i];
 }
@@ -433,13 +441,13 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.depthkey, geom.offsets, geom.tiles, geom.tmask, image.table, image.ranges, geom.rec,
-                       bin.seg_keys, (uint32_t)capacity);
+                       geom.rect, geom.offsets, geom.tiles, geom.tmask, image.table, image.ranges, geom.rec,
+                       bin.point_list, (uint32_t)capacity);
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
-                                hipStream_t stream)
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrGeom& geom, const GsrImage& image,
+                                const GsrBinning& bin, hipStream_t stream)
 {
     // max_tile_count < 0: not known yet (speculative launch) -> run every size class, blocks exit on mismatch
     if (capacity <= 0) return hipSuccess;
@@ -447,16 +455,16 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const G
     hipError_t e;
     // size classes: (0, SMALL] in 32 KiB LDS, (SMALL, LARGE] in 128 KiB LDS, longer in global memory
     hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_SMALL * 8, stream,
-                       image.ranges, bin.seg_keys, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)capacity);
+                       image.ranges, geom.depthkey, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)capacity);
     if (max_tile_count > GSR_SORT_CAP_SMALL) {
         e = gsr_allow_big_lds();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_LARGE * 8, stream,
-                           image.ranges, bin.seg_keys, bin.point_list, (uint32_t)GSR_SORT_CAP_SMALL,
+                           image.ranges, geom.depthkey, bin.point_list, (uint32_t)GSR_SORT_CAP_SMALL,
                            (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     }
     if (max_tile_count > GSR_SORT_CAP_LARGE)
-        hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, bin.seg_keys,
+        hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, geom.depthkey, bin.seg_keys,
                            bin.point_list, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     return hipGetLastError();
 }

@@ -19,7 +19,8 @@
 //           table[NB*T]   4 B  per-(chunk, tile) instance counts -> scatter offsets
 //           tile_count[T] 4 B
 //           info           16 B {R, max tile count}
-//   binning: point_list[R] 4 B sorted Gaussian ids   seg_keys[R] 8 B (depth bits<<32 | id)
+//   binning: point_list[R] 4 B Gaussian ids per tile segment (unsorted after the scatter, sorted in place by the
+//            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
 //   scratch (backward): slots[R] 48 B  per-instance partial gradients (12 floats)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -152,8 +153,8 @@ hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream);
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
                               int capacity, hipStream_t stream);
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
-                                hipStream_t stream);
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrGeom& geom, const GsrImage& image,
+                                const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
                                     float* out_feature, int capacity, hipStream_t stream);

@@ -100,25 +100,27 @@ __device__ __forceinline__ void gsr_cov2d(const float3 mean, const GsrCam& cam, 
 }
 
 // Minimum over the pixel box [bx0,bx1] x [by0,by1] of q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy with
-// d = mean - pixel, i.e. of -power (DGR forward.cu:523): exact for a convex quadratic -- 0 if the mean is
-// inside the box, otherwise the smallest of the four clamped 1-D edge minima.  rA = 1/A, rC = 1/C are
-// passed in (computed once per Gaussian); an approximate reciprocal only moves the evaluation point off
-// the edge optimum by an ulp, which changes q by O(ulp^2).
+// d = mean - pixel, i.e. of -power (DGR forward.cu:523).  q is convex with its minimum (0) at the mean:
+//   * mean inside the box -> 0;
+//   * otherwise, moving from any box point towards the mean lowers q and leaves the box through an edge that
+//     FACES the mean, so the box minimum is the smaller of the clamped 1-D minima on the (at most two) facing
+//     edges: the vertical edge nearest to the mean if the mean is outside in x, the horizontal one if in y.
+// rA = 1/A, rC = 1/C are passed in (once per Gaussian); an approximate reciprocal only moves the evaluation
+// point off the edge optimum by an ulp, which changes q by O(ulp^2).
 __device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, float B, float C, float rA, float rC,
                                                float bx0, float bx1, float by0, float by1)
 {
-    const float dx0 = mx - bx1, dx1 = mx - bx0, dy0 = my - by1, dy1 = my - by0;
-    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return 0.f;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const float ex = e ? dx1 : dx0;
-        const float dy = fminf(dy1, fmaxf(dy0, -B * ex * rC));
-        best = fminf(best, 0.5f * (A * ex * ex + C * dy * dy) + B * ex * dy);
-        const float ey = e ? dy1 : dy0;
-        const float dx = fminf(dx1, fmaxf(dx0, -B * ey * rA));
-        best = fminf(best, 0.5f * (A * dx * dx + C * ey * ey) + B * dx * ey);
-    }
+    const float dx0 = mx - bx1, dx1 = mx - bx0, dy0 = my - by1, dy1 = my - by0;  // ranges of d = mean - pixel
+    const bool out_x = dx0 > 0.f || dx1 < 0.f, out_y = dy0 > 0.f || dy1 < 0.f;
+    const float ex = dx0 > 0.f ? dx0 : dx1;  // d.x on the vertical edge nearest to the mean
+    const float ey = dy0 > 0.f ? dy0 : dy1;
+    const float dy = fminf(dy1, fmaxf(dy0, -B * ex * rC));
+    const float dx = fminf(dx1, fmaxf(dx0, -B * ey * rA));
+    const float qx = 0.5f * (A * ex * ex + C * dy * dy) + B * ex * dy;
+    const float qy = 0.5f * (A * dx * dx + C * ey * ey) + B * dx * ey;
+    float best = (out_x || out_y) ? 3.0e38f : 0.f;
+    best = out_x ? qx : best;
+    best = out_y ? fminf(best, qy) : best;
     return best;
 }
 

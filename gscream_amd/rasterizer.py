@@ -166,10 +166,12 @@ def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_
     g_means2D, g_colors = mk((P, 3), **f32), mk((P, 3), **f32)
     g_opac, g_feat = mk((P, 1), **f32), mk((P, 1), **f32)
     g_means3D = mk((P, 3), **f32)
-    g_cov = mk((P, 6), **f32) if have_cov else torch.zeros((P, 6), **f32)
-    g_sh = mk((P, M, 3), **f32)
-    g_scales = torch.zeros((P, 3), **f32) if have_cov else mk((P, 3), **f32)
-    g_rot = torch.zeros((P, 4), **f32) if have_cov else mk((P, 4), **f32)
+    # gradients of inputs that were not provided (empty tensors) are None: autograd ignores them, and the
+    # reference's zero tensors for them would cost a fill kernel per iteration
+    g_cov = mk((P, 6), **f32) if have_cov else None
+    g_sh = mk((P, M, 3), **f32) if have_sh else None
+    g_scales = None if have_cov else mk((P, 3), **f32)
+    g_rot = None if have_cov else mk((P, 4), **f32)
     if P == 0:
         return g_means2D, g_colors, g_opac, g_feat, g_means3D, g_cov, g_sh, g_scales, g_rot
     view, proj, campos = _cam(rs, dev)
@@ -197,8 +199,7 @@ def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_
             float(rs.tanfovx), float(rs.tanfovy), _native.ptr(gc), _native.ptr(gd), _native.ptr(gu),
             _native.ptr(geom), _native.ptr(img), _native.ptr(binning), _native.ptr(scratch),
             _native.ptr(g_means2D), _native.ptr(g_colors), _native.ptr(g_opac), _native.ptr(g_feat),
-            _native.ptr(g_means3D), _native.ptr(g_cov) if have_cov else None, _native.ptr(g_sh) if have_sh else None,
-            None if have_cov else _native.ptr(g_scales), None if have_cov else _native.ptr(g_rot),
+            _native.ptr(g_means3D), _native.ptr(g_cov), _native.ptr(g_sh), _native.ptr(g_scales), _native.ptr(g_rot),
             _native.ctypes.byref(_tuning), int(bool(rs.debug)), _stream())
         _native.check(rc, "gsr_backward")
     return g_means2D, g_colors, g_opac, g_feat, g_means3D, g_cov, g_sh, g_scales, g_rot
