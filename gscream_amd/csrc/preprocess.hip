@@ -99,7 +99,9 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
             piy = gsr_ndc2pix(projy, cam.H);
             int x0, y0, x1, y1;
             gsr_get_rect(pix, piy, gsr_f2i(my_radius), cam.gx, cam.gy, x0, y0, x1, y1);
-            if ((x1 - x0) * (y1 - y0) != 0) {
+            // radius <= 0 can only come from a NaN covariance (ceil(3 sqrt(lambda)) >= 1 otherwise): the reference then
+            // has radii = 0 but tiles_touched > 0 and reads uninitialised sort keys; here such a Gaussian is culled
+            if ((x1 - x0) * (y1 - y0) != 0 && gsr_f2i(my_radius) > 0) {
                 radius = gsr_f2i(my_radius);
                 ntiles = (uint32_t)((y1 - y0) * (x1 - x0));
                 rc = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));

@@ -13,7 +13,7 @@
  * task forbids.  The only reference-derived numbers available are the five filter-API
  * known answers recorded in SURVEY.md Appendix B-6; tests/test_oracle.py checks them.
  * Everything else is pinned by (a) closed-form known answers derived from the reference
- * source and (b) an independent float64 autograd restatement (tests/naive_torch.py).
+ * source and (b) an independent float64 autograd restatement (oracle/naive_torch.py).
  *
  * The arithmetic follows the reference source line by line in evaluation order, in
  * IEEE fp32 with NO fused multiply-add (build with -ffp-contract=off), so that the
@@ -224,6 +224,9 @@ void gso_preprocess(int mode, int P, int D, int M, const float *means3D, const f
         int x0, y0, x1, y1;
         get_rect(pix, piy, f2i_sat(my_radius), gx, gy, &x0, &y0, &x1, &y1);
         if ((x1 - x0) * (y1 - y0) == 0) continue;
+        /* NaN covariance -> radius 0: the reference leaves radii = 0 with tiles_touched > 0 and then sorts
+         * uninitialised keys (undefined behaviour); oracle and HIP path both cull such a Gaussian. */
+        if (f2i_sat(my_radius) <= 0) continue;
         radii[idx] = f2i_sat(my_radius);
         if (mode == 1) continue;
         if (mode == 2) { means2D[idx] = pix; means2D[P + idx] = piy; continue; }

@@ -357,3 +357,79 @@ def test_speculative_forward_and_capacity_overflow():
     st = Hh.hip_run(s, keep_state=True)
     assert RZ._last_stage1["speculative"] is True
     _check_binning(s, st, exp["point_list"], exp["tile_counts"])
+
+
+def _vs_oracle(s, grads, name, img_frac=2e-4):
+    st = Hh.oracle_forward(s)
+    ref = Hh.oracle_backward(s, st, grads)
+    got = Hh.hip_run(s, grads)
+    assert (got["radii"] == st["radii"]).all(), f"{name}: radii"
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], f"{name}/{k}", max_outlier_frac=img_frac)
+    Hh.assert_grads_close(got, ref, keys=list(Hh.GRAD_KEYS) + ["dL_dsh", "dL_dcov3D"], context=name)
+    assert all(np.isfinite(v).all() for k, v in got.items() if k.startswith("dL_"))
+    return st, got
+
+
+@pytest.mark.parametrize("variant", ["scale_modifier", "sh_deg0", "sh_deg1", "sh_deg2", "huge_gaussians", "opacity_edges",
+                                     "thin_image", "tall_image", "tiny_gaussians"])
+def test_more_cases_against_live_oracle(variant):
+    rng = np.random.default_rng(hash(variant) % 1000)
+    if variant == "scale_modifier":
+        s = S.scene_config1(seed=80, P=1500, W=120, H=90)
+        s["scale_modifier"] = 0.6
+    elif variant.startswith("sh_deg"):
+        deg = int(variant[-1])
+        s = S.scene_config1(seed=81 + deg, P=1200, W=112, H=80, w2c=S.random_w2c(rng))
+        s["shs"] = rng.normal(0, 0.35, size=(1200, (deg + 1) ** 2, 3)).astype(np.float32)
+        s["sh_degree"] = deg
+        del s["colors"]
+    elif variant == "huge_gaussians":
+        # rectangles far beyond 64 tiles (the tile-cull mask covers the first 64; the rest is always binned)
+        s = S.scene_config1(seed=85, P=300, W=320, H=256)
+        s["scales"][:40] = rng.uniform(0.8, 2.5, size=(40, 3)).astype(np.float32)
+        s["opacities"][:40] = rng.uniform(0.02, 0.6, size=(40, 1)).astype(np.float32)
+    elif variant == "opacity_edges":
+        s = S.scene_config1(seed=86, P=1500, W=120, H=90)
+        s["opacities"][:300:6] = 0.0
+        s["opacities"][1:300:6] = 1.0 / 255.0
+        s["opacities"][2:300:6] = 0.0039
+        s["opacities"][3:300:6] = 1.0
+        s["opacities"][4:300:6] = 3.0     # alpha clamps at 0.99
+        s["opacities"][5:300:6] = -0.5    # never blended
+    elif variant == "thin_image":
+        s = S.scene_config1(seed=87, P=800, W=200, H=3)
+    elif variant == "tall_image":
+        s = S.scene_config1(seed=88, P=800, W=5, H=130)
+    else:
+        s = S.scene_config1(seed=89, P=3000, W=150, H=100)
+        s["scales"] *= 0.01   # sub-pixel: the 0.3 low-pass dominates
+    grads = S.upstream_grads(90, s["W"], s["H"])
+    st, got = _vs_oracle(s, grads, variant)
+    if variant == "huge_gaussians":
+        gx, gy = (s["W"] + 15) // 16, (s["H"] + 15) // 16
+        assert st["tiles_touched"].max() > 64 and st["tiles_touched"].max() <= gx * gy
+        set_tuning(tile_cull=False)
+        full = Hh.hip_run(s, keep_state=True)
+        assert full["num_rendered"] == st["num_rendered"]
+        _check_binning(s, full, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+
+
+def test_non_finite_inputs_do_not_fault():
+    """NaN / inf inputs must never drive a kernel out of bounds: such Gaussians are culled (radius 0) or blended as
+    garbage-in-garbage-out, but the call returns and the finite Gaussians' radii are untouched."""
+    s = S.scene_config1(seed=95, P=2000, W=128, H=96)
+    clean = Hh.oracle_forward(s)["radii"]
+    bad = {k: v.copy() if isinstance(v, np.ndarray) else v for k, v in s.items()}
+    bad["means3D"][0] = np.nan
+    bad["means3D"][1] = [np.inf, 0, 3]
+    bad["means3D"][2] = [0, 0, np.inf]
+    bad["scales"][3] = np.nan
+    bad["scales"][4] = np.inf
+    bad["rotations"][5] = np.nan
+    bad["scales"][6] = 1e30
+    bad["means3D"][7] = [1e30, -1e30, 5]
+    got = Hh.hip_run(bad, S.upstream_grads(3, 128, 96))
+    torch.cuda.synchronize()
+    assert (got["radii"][8:] == clean[8:]).all()
+    assert got["radii"][0] == 0 and got["radii"][3] == 0 and got["radii"][5] == 0
