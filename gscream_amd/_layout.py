@@ -39,6 +39,8 @@ def image_views(buf, P, W, H):
     nb = num_chunks(P)
     out["table"] = _take(buf, off, nb * T * 4, torch.int32, (nb, T)); off += _align(nb * T * 4)
     out["tile_count"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
+    out["tile_work"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
+    out["tile_order"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
     return out
 

@@ -138,7 +138,8 @@ __device__ __forceinline__ int gsr_compact(const uint32_t* sQ, uint16_t* list, i
 __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t capacity)
+    float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    uint32_t* __restrict__ tile_work, uint32_t capacity)
 {
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ uint32_t sQ[GSR_BATCH];
@@ -214,6 +215,17 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
         }
     }
 
+    // deepest contributor of the tile: what the backward has to traverse (drives its launch order)
+    uint32_t wl = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+    __syncthreads();  // every wave has left the batch loop: sQ is free
+    if (t == 0) sQ[0] = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&sQ[0], wl);
+    __syncthreads();
+    if (t == 0) tile_work[tile] = sQ[0];
+
     if (inside) {
         const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
         final_T[pid] = Tr;
@@ -234,7 +246,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dfeature, float4* __restrict__ slots)
+    const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_order, float4* __restrict__ slots)
 {
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ __attribute__((aligned(16))) float acc[GSR_BATCH * GSR_SLOT_FLOATS];
@@ -242,7 +254,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     __shared__ uint16_t sList[4][GSR_BATCH];
     __shared__ int sMax;
 
-    const int tile = gsr_tile_of_block(blockIdx.x, T);
+    const int tile = (int)tile_order[blockIdx.x];  // XCD band kept, deepest tiles of the band first
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
@@ -417,6 +429,44 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     }
 }
 
+// Backward launch order.  Workgroup b runs on XCD b % 8 and, with the forward's map, on the b>>3-th tile of that
+// XCD's band of tile rows.  Here each band is re-ordered by descending work (deepest n_contrib first), so the long
+// tiles start first and the tail of the launch is made of short ones; the band -> XCD assignment (L2 locality)
+// is unchanged.  One workgroup per band; bands hold <= 4608 tiles (T <= 36864), sorted in LDS.
+__global__ void __launch_bounds__(256) gsr_tile_order_kernel(int T, const uint32_t* __restrict__ tile_work,
+                                                              uint32_t* __restrict__ tile_order)
+{
+    __shared__ unsigned long long k[4608 + 1];
+    const int xcd = blockIdx.x, q = T >> 3, r = T & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = q + (xcd < r ? 1 : 0);
+    for (int i = threadIdx.x; i < cnt; i += 256)
+        k[i] = ((unsigned long long)(0xffffffffu - tile_work[first + i]) << 32) | (uint32_t)(first + i);
+    __syncthreads();
+    // plain bitonic network (ascending) with virtual +inf padding, as in binning.hip
+    uint32_t lm = 0;
+    while ((1u << lm) < (uint32_t)cnt) lm++;
+    const uint32_t npairs = (1u << lm) >> 1;
+    for (uint32_t ls = 1; ls <= lm; ls++) {
+        const uint32_t lh = ls - 1, half = 1u << lh;
+        for (uint32_t t = threadIdx.x; t < npairs; t += 256) {
+            const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
+            const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;
+            if (j < (uint32_t)cnt && k[i] > k[j]) { const unsigned long long a = k[i]; k[i] = k[j]; k[j] = a; }
+        }
+        __syncthreads();
+        for (int lst = (int)lh - 1; lst >= 0; lst--) {
+            const uint32_t stride = 1u << lst;
+            for (uint32_t t = threadIdx.x; t < npairs; t += 256) {
+                const uint32_t i = ((t >> lst) << (lst + 1)) + (t & (stride - 1)), j = i + stride;
+                if (j < (uint32_t)cnt && k[i] > k[j]) { const unsigned long long a = k[i]; k[i] = k[j]; k[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < cnt; i += 256) tile_order[xcd + 8 * i] = (uint32_t)k[i];  // block b = 8 i + xcd
+}
+
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
@@ -424,7 +474,8 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
 {
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
-                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, (uint32_t)capacity);
+                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work,
+                       (uint32_t)capacity);
     return hipGetLastError();
 }
 
@@ -434,11 +485,14 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
+    hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(8), dim3(256), 0, stream, T, image.tile_work, image.tile_order);
     if (dL_ddepth && dL_dfeature)
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
-                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature, s4);
+                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature,
+                           image.tile_order, s4);
     else
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
-                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, nullptr, nullptr, s4);
+                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, nullptr, nullptr,
+                           image.tile_order, s4);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@
 //   image : ranges[T]     8 B  [start,end) of each tile in the sorted list
 //           final_T[N], n_contrib[N]
 //           table[NB*T]   4 B  per-(chunk, tile) instance counts -> scatter offsets
-//           tile_count[T] 4 B
+//           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile), tile_order[T] 4 B (backward launch order)
 //           info           16 B {R, max tile count}
 //   binning: point_list[R] 4 B Gaussian ids per tile segment (unsorted after the scatter, sorted in place by the
 //            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
@@ -63,6 +63,8 @@ struct GsrImage {
     uint32_t* n_contrib;
     uint32_t* table;
     uint32_t* tile_count;
+    uint32_t* tile_work;   // per tile: deepest n_contrib of its pixels = instances the backward must traverse
+    uint32_t* tile_order;  // backward launch order: per XCD band, tiles by descending tile_work
     uint32_t* info;  // [0] = R, [1] = max tile count
     size_t bytes;
 };
@@ -115,6 +117,8 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.n_contrib = (uint32_t*)(b + off); off += gsr_align(N * 4);
     im.table = (uint32_t*)(b + off); off += gsr_align((size_t)gsr_num_chunks(P) * T * 4);
     im.tile_count = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.tile_work = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.tile_order = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.bytes = off;
     return im;
