@@ -246,7 +246,8 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_order, float4* __restrict__ slots)
+    const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_order,
+    uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
 {
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ __attribute__((aligned(16))) float acc[GSR_BATCH * GSR_SLOT_FLOATS];
@@ -291,11 +292,19 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     __syncthreads();
     const int nproc = min(n, sMax);
     uint16_t* mylist = sList[wave];
+    // Instances at list positions >= nproc were blended by no pixel of the tile: they are not traversed and their
+    // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots
+    // exist.  On the bench scene lists hold ~1185 instances and pixels saturate after ~276, so three quarters of the
+    // slot traffic and of the batch loads disappear.
 
     // back to front, in batches of 256 instances; local j = 0 is the backmost instance of the batch
+#ifdef GSR_EXP_ALLSLOTS
     for (int hi = n; hi > 0; hi -= GSR_BATCH) {
+#else
+    for (int hi = nproc; hi > 0; hi -= GSR_BATCH) {
+#endif
         const int lo = max(0, hi - GSR_BATCH), cnt = hi - lo;
-        const bool active = lo < nproc;
+        constexpr bool active = true;
         if (t < cnt) {
             const GsrRec* r = rec + point_list[rg.x + (hi - 1 - t)];
             const uint4 d = r->d;
@@ -305,11 +314,9 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             const int pos = (ty - y0) * wd + (tx - x0);
             const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
             sSlot[t] = d.x + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
-            if (active) {
-                const float4 a = r->a, b = r->b;
-                sA[t] = a; sB[t] = b; sC[t] = c;
-                sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
-            }
+            const float4 a = r->a, b = r->b;
+            sA[t] = a; sB[t] = b; sC[t] = c;
+            sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
         }
         __syncthreads();
 
@@ -410,7 +417,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             float4* a4 = reinterpret_cast<float4*>(acc + t * GSR_SLOT_FLOATS);
             float4* dst = slots + (size_t)sSlot[t] * 3;
             float4 o0 = a4[0], o1 = a4[1], o2 = a4[2];
-            if (active) {
+            {
                 // moments -> the reference's per-instance sums (DGR backward.cu:586-601):
                 //   dL/dmean2D = -o (cA Mx + cB My) W/2, -o (cC My + cB Mx) H/2;  dL/dconic = -o/2 (Mxx, Mxy, Myy);
                 //   dL/dopacity = M0            with M* = sum over pixels of G dL/dalpha {dx, dy, dx^2, dx dy, dy^2, 1}
@@ -424,6 +431,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                 a4[0] = a4[1] = a4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             dst[0] = o0; dst[1] = o1; dst[2] = o2;
+            slot_written[sSlot[t]] = 1;
         }
         __syncthreads();
     }
@@ -481,7 +489,8 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
 
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
-                                     const float* dL_ddepth, const float* dL_dfeature, float* slots, hipStream_t stream)
+                                     const float* dL_ddepth, const float* dL_dfeature, float* slots, uint8_t* slot_written,
+                                     hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
@@ -489,10 +498,10 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     if (dL_ddepth && dL_dfeature)
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
                            geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature,
-                           image.tile_order, s4);
+                           image.tile_order, slot_written, s4);
     else
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
                            geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, nullptr, nullptr,
-                           image.tile_order, s4);
+                           image.tile_order, slot_written, s4);
     return hipGetLastError();
 }

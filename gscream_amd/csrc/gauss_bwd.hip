@@ -10,7 +10,7 @@
 // gradient tensors need no memset (the reference zero-fills 116 B/Gaussian, rasterize_points.cu:160-170).
 // Built with -ffp-contract=off: same evaluation order and rounding as oracle/gs_oracle.c.
 //
-// HBM traffic per Gaussian: read 48 B x surviving tiles (contiguous, coalesced through LDS) + 12 + 12 + 16 + 4 + 12;
+// HBM traffic per Gaussian: read 48 B x traversed instances (the slots the backward blend actually wrote) + inputs;
 // write 12 + 12 + 4 + 4 + 12 + 12 + 16 = 72 B.
 #include "gsr_math.h"
 
@@ -93,35 +93,64 @@ __device__ __forceinline__ float3 gsr_sh_backward(int idx, int deg, int M, float
     return r;
 }
 
-__global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
+#ifndef GSR_K7_BS
+#define GSR_K7_BS 64
+#endif
+__global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, int num_slots,
-    const float4* __restrict__ slots, float* __restrict__ dL_dmeans2D,
+    const float4* __restrict__ slots, const uint8_t* __restrict__ slot_written, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeatures,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
 {
-    // The gradient slots of the block's 256 consecutive Gaussians are one contiguous range of `slots`
-    // (offsets[] is the exclusive scan of the per-Gaussian slot counts).  The block streams that range through
-    // LDS with fully coalesced 16-byte loads; each thread then sums its own few slots out of LDS.
-    constexpr int CH = 512;  // slots per chunk: 512 * 48 B = 24 KiB
+    // The gradient slots of the block's consecutive Gaussians are one contiguous range of `slots` (offsets[] is
+    // the exclusive scan of the per-Gaussian slot counts).  The block streams that range through LDS with fully
+    // coalesced 16-byte loads; each thread then sums its own few slots out of LDS.  The backward blend writes a slot
+    // only for instances it traversed (slot_written[s] = 1; the array is zeroed per call): on the bench scene three
+    // quarters of the instances lie behind the depth where their tile saturates and are never touched.
+    constexpr int BS = GSR_K7_BS;  // one wave per block: its barriers are free and waves progress independently
+    constexpr int CH = 2 * BS;     // slots per chunk (48 B each)
     __shared__ float4 stage[CH * 3];
+    __shared__ uint8_t flag[CH];
     const int g0 = blockIdx.x * blockDim.x;
     const int idx = g0 + threadIdx.x;
     const bool live = idx < P;
+    const bool vis = live && radii[idx] > 0;
     const uint32_t off = live ? offsets[idx] : 0u;
     const uint32_t cnt = live ? tiles[idx] : 0u;
     const uint32_t S0 = offsets[g0];
-    const uint32_t S1 = (g0 + 256 < P) ? offsets[g0 + 256] : (uint32_t)num_slots;
+    const uint32_t S1 = (g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots;
     double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
     for (uint32_t c0 = S0; c0 < S1; c0 += CH) {
-        const uint32_t n4 = (min(S1, c0 + CH) - c0) * 3;
-        for (uint32_t i = threadIdx.x; i < n4; i += 256) stage[i] = slots[(size_t)c0 * 3 + i];
+        const uint32_t ns = min(S1, c0 + CH) - c0;
+        // flags first, then only the written slots: unwritten ones are cold HBM lines (the written ones were just
+        // produced by the backward blend and mostly still sit in L2 / Infinity Cache).  Loads go to registers first so
+        // that all of a thread's requests are in flight together.
+        {
+            const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + BS;
+            const uint8_t f0 = i0 < ns ? slot_written[c0 + i0] : (uint8_t)0;
+            const uint8_t f1 = i1 < ns ? slot_written[c0 + i1] : (uint8_t)0;
+            flag[i0] = f0; flag[i1] = f1;
+        }
+        __syncthreads();
+        {
+            float4 v[CH * 3 / BS];
+#pragma unroll
+            for (int k = 0; k < CH * 3 / BS; k++) {
+                const uint32_t i = threadIdx.x + k * BS;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (flag[i / 3]) v[k] = slots[(size_t)c0 * 3 + i];
+            }
+#pragma unroll
+            for (int k = 0; k < CH * 3 / BS; k++) stage[threadIdx.x + k * BS] = v[k];
+        }
         __syncthreads();
         const uint32_t lo = max(off, c0), hi = min(off + cnt, c0 + CH);
         for (uint32_t j = lo; j < hi; j++) {
+            if (!flag[j - c0]) continue;
             const float4 a = stage[(j - c0) * 3], b = stage[(j - c0) * 3 + 1], c = stage[(j - c0) * 3 + 2];
             acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
             acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
@@ -135,7 +164,6 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
     float gm2x = (float)acc[5], gm2y = (float)acc[6], gcx = (float)acc[7], gcy = (float)acc[8], gcw = (float)acc[9];
     float gop = (float)acc[10];
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
-    const bool vis = radii[idx] > 0;
 
     if (vis) {
         const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -258,15 +286,15 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_kernel(
 
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
-                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots, int num_slots,
-                                     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                                     const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
+                                     const uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream)
 {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsr_gauss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, D, M, cam, means3D, radii,
+    hipLaunchKernelGGL(gsr_gauss_bwd_kernel, dim3((P + GSR_K7_BS - 1) / GSR_K7_BS), dim3(GSR_K7_BS), 0, stream, P, D, M, cam, means3D, radii,
                        shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets, geom.tiles, num_slots,
-                       reinterpret_cast<const float4*>(slots), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures,
+                       reinterpret_cast<const float4*>(slots), slot_written, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures,
                        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
     return hipGetLastError();
 }
