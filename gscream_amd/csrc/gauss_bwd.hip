@@ -106,55 +106,90 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
 {
-    // The gradient slots of the block's consecutive Gaussians are one contiguous range of `slots` (offsets[] is
-    // the exclusive scan of the per-Gaussian slot counts).  The block streams that range through LDS with fully
-    // coalesced 16-byte loads; each thread then sums its own few slots out of LDS.  The backward blend writes a slot
-    // only for instances it traversed (slot_written[s] = 1; the array is zeroed per call): on the bench scene three
-    // quarters of the instances lie behind the depth where their tile saturates and are never touched.
-    constexpr int BS = GSR_K7_BS;  // one wave per block: its barriers are free and waves progress independently
-    constexpr int CH = 2 * BS;     // slots per chunk (48 B each)
-    __shared__ float4 stage[CH * 3];
-    __shared__ uint8_t flag[CH];
-    const int g0 = blockIdx.x * blockDim.x;
-    const int idx = g0 + threadIdx.x;
+    // One wave per block owns 64 consecutive Gaussians; their gradient slots are one contiguous range [S0, S1) of
+    // `slots` (offsets[] is the exclusive scan of the per-Gaussian slot counts).  The backward blend writes a slot only
+    // for instances it traversed (slot_written[s] = 1, zeroed per call): on the bench scene three quarters of the
+    // instances lie behind the depth where their tile saturates.  The wave therefore
+    //   1. reads the flag bytes of its range (coalesced), turns them into 64-bit masks + running counts (ballot),
+    //   2. builds the compact list of written slots and fetches only those, 3 lanes per 48-byte slot, into LDS,
+    //   3. lets every lane sum its own written slots out of LDS in ascending slot order (double accumulators).
+    // Three dependent memory round trips per wave instead of two per 128-slot chunk; the per-Gaussian inputs of the
+    // second half are requested before any of it.
+    constexpr int BS = GSR_K7_BS;
+    static_assert(BS == 64, "one wave per block");
+    constexpr int FCH = 512;  // flags per pass (per-wave ranges average ~170 slots)
+    constexpr int WCH = 128;  // written slots staged per sub-pass (48 B each)
+    __shared__ float4 stage[WCH * 3];
+    __shared__ uint16_t wl[FCH];
+    __shared__ unsigned long long gmask[FCH / 64];
+    __shared__ uint32_t gbase[FCH / 64 + 1];
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * BS;
+    const int idx = g0 + lane;
     const bool live = idx < P;
     const bool vis = live && radii[idx] > 0;
     const uint32_t off = live ? offsets[idx] : 0u;
     const uint32_t cnt = live ? tiles[idx] : 0u;
     const uint32_t S0 = offsets[g0];
     const uint32_t S1 = (g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots;
+    // early requests for the per-Gaussian half (independent of the slot phase)
+    float3 m = make_float3(0.f, 0.f, 0.f), sc = make_float3(0.f, 0.f, 0.f);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vis) {
+        m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        if (!cov3D_precomp) {
+            sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            q = reinterpret_cast<const float4*>(rotations)[idx];
+        }
+    }
     double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
-    for (uint32_t c0 = S0; c0 < S1; c0 += CH) {
-        const uint32_t ns = min(S1, c0 + CH) - c0;
-        // flags first, then only the written slots: unwritten ones are cold HBM lines (the written ones were just
-        // produced by the backward blend and mostly still sit in L2 / Infinity Cache).  Loads go to registers first so
-        // that all of a thread's requests are in flight together.
-        {
-            const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + BS;
-            const uint8_t f0 = i0 < ns ? slot_written[c0 + i0] : (uint8_t)0;
-            const uint8_t f1 = i1 < ns ? slot_written[c0 + i1] : (uint8_t)0;
-            flag[i0] = f0; flag[i1] = f1;
+#ifdef GSR_EXP_NOSLOTS
+    for (uint32_t base = S0; base < S0; base += FCH) {
+#else
+    for (uint32_t base = S0; base < S1; base += FCH) {
+#endif
+        const uint32_t nf = min(S1 - base, (uint32_t)FCH);
+        uint8_t f[FCH / 64];
+#pragma unroll
+        for (int k = 0; k < FCH / 64; k++) {
+            const uint32_t i = k * 64 + lane;
+            f[k] = i < nf ? slot_written[base + i] : (uint8_t)0;
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < FCH / 64; k++) {
+            const unsigned long long mk = __ballot(f[k] != 0);
+            if (f[k]) wl[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(k * 64 + lane);
+            if (lane == 0) { gmask[k] = mk; gbase[k] = run; }
+            run += (uint32_t)__popcll(mk);
         }
         __syncthreads();
-        {
-            float4 v[CH * 3 / BS];
+        // A lane's written slots are consecutive entries [ci0, ci1) of the compact list: ci = number of written slots
+        // of the pass below the lane's first / past its last slot.  No flag test is left in the summation loop.
+        const uint32_t lo = min(max(off, base), base + nf) - base, hi = min(max(off + cnt, base), base + nf) - base;
+        uint32_t ci0 = run, ci1 = run;
+        if (lo < nf) ci0 = gbase[lo >> 6] + (uint32_t)__popcll(gmask[lo >> 6] & ((1ull << (lo & 63)) - 1ull));
+        if (hi < nf) ci1 = gbase[hi >> 6] + (uint32_t)__popcll(gmask[hi >> 6] & ((1ull << (hi & 63)) - 1ull));
+        for (uint32_t w0 = 0; w0 < run; w0 += WCH) {
+            const uint32_t nw = min(run - w0, (uint32_t)WCH);
+            float4 v[WCH * 3 / 64];
 #pragma unroll
-            for (int k = 0; k < CH * 3 / BS; k++) {
-                const uint32_t i = threadIdx.x + k * BS;
+            for (int k = 0; k < WCH * 3 / 64; k++) {
+                const uint32_t i = lane + k * 64;
                 v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (flag[i / 3]) v[k] = slots[(size_t)c0 * 3 + i];
+                if (i < nw * 3) v[k] = slots[(size_t)(base + wl[w0 + i / 3]) * 3 + i % 3];
             }
 #pragma unroll
-            for (int k = 0; k < CH * 3 / BS; k++) stage[threadIdx.x + k * BS] = v[k];
-        }
-        __syncthreads();
-        const uint32_t lo = max(off, c0), hi = min(off + cnt, c0 + CH);
-        for (uint32_t j = lo; j < hi; j++) {
-            if (!flag[j - c0]) continue;
-            const float4 a = stage[(j - c0) * 3], b = stage[(j - c0) * 3 + 1], c = stage[(j - c0) * 3 + 2];
-            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-            acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+            for (int k = 0; k < WCH * 3 / 64; k++) stage[lane + k * 64] = v[k];
+            __syncthreads();
+            const uint32_t e0 = max(ci0, w0), e1 = min(ci1, w0 + nw);
+            for (uint32_t e = e0; e < e1; e++) {
+                const float4 a = stage[(e - w0) * 3], b = stage[(e - w0) * 3 + 1], c = stage[(e - w0) * 3 + 2];
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+                acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+            }
+            __syncthreads();
         }
         __syncthreads();
     }
@@ -165,17 +200,16 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     float gop = (float)acc[10];
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
 
+#ifdef GSR_EXP_NOMATH
+    if (vis && gop == 12345.f) {
+#else
     if (vis) {
-        const float3 m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+#endif
         float cov3D[6];
-        float3 sc = make_float3(0.f, 0.f, 0.f);
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * idx + i];
         } else {
-            sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-            q = reinterpret_cast<const float4*>(rotations)[idx];
             gsr_cov3d(sc, cam.scale_modifier, q, cov3D);
         }
         GsrCov2D c2;

@@ -11,3 +11,8 @@ np.save(os.path.join(ROOT, "gpurun_out", "tile_counts_config2.npy"), r[:, 1] - r
 nc = iv["n_contrib"].cpu().numpy()
 np.save(os.path.join(ROOT, "gpurun_out", "n_contrib_config2.npy"), nc.astype(np.int32))
 print("saved", (r[:,1]-r[:,0]).sum())
+gv = _layout.geom_views(got["geom"], 1_000_000)
+t = gv["tiles"].cpu().numpy().astype(np.int64)
+np.save(os.path.join(ROOT, "gpurun_out", "gauss_tiles_config2.npy"), t.astype(np.int32))
+w = t.reshape(-1, 64).sum(1)
+print("per-Gaussian slots: max", t.max(), "p99.9", np.percentile(t, 99.9), "; per-wave range: mean", w.mean(), "p50", np.median(w), "p99", np.percentile(w, 99), "max", w.max())
