@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
     gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
     // four Gaussians per thread per trip, loads issued together (the kernel is latency-bound: 8 waves per CU)
     constexpr int U = 4;
-    for (int gb = lo + threadIdx.x; gb < hi; gb += blockDim.x * U) {
+    for (int gw = lo + (int)(threadIdx.x & ~63u); gw < hi; gw += blockDim.x * U) {  // wave-uniform trip count
+        const int gb = gw + (int)(threadIdx.x & 63);
         uint2 rcs[U];
         u64 mks[U];
 #pragma unroll
@@ -120,9 +121,8 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
             mks[k] = g < hi ? tmask[g] : 0ull;
         }
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            gsr_for_each_tile(rcs[k], mks[k], [&](int x, int y) { atomicAdd(&hist[y * gx + x], 1u); });
-        }
+        for (int k = 0; k < U; k++)
+            gsr_wave_for_each_instance(rcs[k], mks[k], [&](int, int x, int y) { atomicAdd(&hist[y * gx + x], 1u); });
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int lo, hi;
     gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
     constexpr int U = 4;
-    for (int gb = lo + threadIdx.x; gb < hi; gb += blockDim.x * U) {
+    for (int gw = lo + (int)(threadIdx.x & ~63u); gw < hi; gw += blockDim.x * U) {  // wave-uniform trip count
+        const int gb = gw + (int)(threadIdx.x & 63);
         uint2 rcs[U];
         u64 mks[U];
         uint32_t nts[U], ofs[U];
@@ -223,14 +224,16 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            if (nts[k] == 0) continue;
             const int g = gb + k * blockDim.x;
-            const uint2 rc = rcs[k];
-            const u64 mask = mks[k];
-            rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
-            gsr_for_each_tile(rc, mask, [&](int x, int y) {
+            if (nts[k] != 0) {
+                const uint2 rc = rcs[k];
+                const u64 mask = mks[k];
+                rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+            }
+            const int g_lane0 = g - (int)(threadIdx.x & 63);  // lanes of a wave hold consecutive Gaussians
+            gsr_wave_for_each_instance(rcs[k], mks[k], [&](int owner, int x, int y) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                if (slot < capacity) point_list[slot] = (uint32_t)g;  // capacity < R only in a speculative launch that is redone
+                if (slot < capacity) point_list[slot] = (uint32_t)(g_lane0 + owner);  // capacity < R only in a speculative launch that is redone
             });
         }
     }

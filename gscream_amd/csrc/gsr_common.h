@@ -30,7 +30,9 @@
 
 #define GSR_TILE 16
 #define GSR_MAX_CHUNKS 256       // NB: rows of the (chunk, tile) count table
+#ifndef GSR_HIST_THREADS
 #define GSR_HIST_THREADS 512
+#endif
 #define GSR_MAX_TILES_LDS 36864  // tiles whose histogram fits one LDS allocation (144 KiB)
 #define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
 #define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path

@@ -167,6 +167,71 @@ __device__ __forceinline__ void gsr_for_each_tile(const uint2 rc, unsigned long 
     for (int i = 64; i < area; i++) f(x0 + i % w, y0 + i / w);
 }
 
+// Index of the r-th (0-based) set bit of m; r < popcount(m).  Branch-free binary search on popcounts.
+__device__ __forceinline__ uint32_t gsr_select_bit(unsigned long long m, uint32_t r)
+{
+    uint32_t w = (uint32_t)m, pos = 0;
+    uint32_t c = (uint32_t)__popc(w);
+    if (r >= c) { r -= c; w = (uint32_t)(m >> 32); pos = 32; }
+#pragma unroll
+    for (int half = 16; half >= 1; half >>= 1) {
+        const uint32_t lowbits = w & ((1u << half) - 1u);
+        c = (uint32_t)__popc(lowbits);
+        const bool up = r >= c;
+        r -= up ? c : 0u;
+        pos += up ? half : 0;
+        w = up ? (w >> half) : lowbits;
+    }
+    return pos;
+}
+
+// Wave-dense version of gsr_for_each_tile.  Every lane passes the rectangle and survivor mask of ITS Gaussian (a zero
+// rectangle for none); the wave then enumerates all (Gaussian, surviving tile) instances of its 64 Gaussians 64 at a
+// time, one instance per lane, and calls f(owner_lane, x, y) with all lanes (but the last round's tail) active.
+// The per-Gaussian walk has as many rounds as the LARGEST footprint in the wave (~18 for a mean of 2.7), and every
+// round costs one LDS atomic instruction whose latency does not depend on the number of active lanes; the dense form
+// needs total/64 rounds.  Must be called by all 64 lanes (no divergence around the call).
+template <typename F>
+__device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const unsigned long long mask, F f)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int x0 = rc.x & 0xffff, w = (int)(rc.x >> 16) - x0, y0 = rc.y & 0xffff, h = (int)(rc.y >> 16) - y0;
+    const int area = w > 0 ? w * h : 0;
+    const unsigned long long m = area >= 64 ? mask : mask & ((1ull << area) - 1ull);
+    const uint32_t cnt = (uint32_t)__popcll(m) + (uint32_t)max(area - 64, 0);   // == gsr_survivors(mask, area)
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t i = base + lane;
+        int lo = 0;  // number of lanes whose inclusive count is <= i  == the lane that owns instance i
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t v = __shfl(incl, lo + step - 1, 64);
+            lo += v <= i ? step : 0;
+        }
+        const uint32_t oincl = __shfl(incl, lo, 64), ocnt = __shfl(cnt, lo, 64);
+        const uint32_t orx = __shfl(rc.x, lo, 64), ory = __shfl(rc.y, lo, 64);
+        const uint32_t omlo = __shfl((uint32_t)m, lo, 64), omhi = __shfl((uint32_t)(m >> 32), lo, 64);
+        if (i < total) {
+            const uint32_t r = i - (oincl - ocnt);
+            const unsigned long long om = ((unsigned long long)omhi << 32) | omlo;
+            const uint32_t opc = (uint32_t)__popcll(om);
+            const uint32_t pos = r < opc ? gsr_select_bit(om, r) : 64u + (r - opc);
+            const int ox0 = orx & 0xffff, ow = (int)(orx >> 16) - ox0, oy0 = ory & 0xffff;
+            int row = (int)((float)pos * __frcp_rn((float)ow));  // pos < 2^24: off by at most one, fixed below
+            int col = (int)pos - row * ow;
+            if (col < 0) { row--; col += ow; }
+            if (col >= ow) { row++; col -= ow; }
+            f(lo, ox0 + col, oy0 + row);
+        }
+    }
+}
+
 // number of surviving tiles of a rectangle with `area` tiles
 __device__ __forceinline__ int gsr_survivors(unsigned long long mask, int area)
 {
