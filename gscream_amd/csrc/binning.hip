@@ -278,6 +278,10 @@ __device__ __forceinline__ void gsr_bitonic(KeyPtr k, const uint32_t n, const in
 // ---- LDS version with fused strides: 8 keys per thread stay in registers for three consecutive compare-exchange
 // distances, so a 2048-key list needs 29 LDS round trips (+ barriers) instead of 66.  Same network, same result.
 #define GSR_KEY_INF 0xffffffffffffffffull
+// LDS index padding: one spare key after every 16.  The small-stride rounds give each thread 8 keys that are 1, 2 or
+// 4 apart, so the lanes of a wave are 64/128/256 bytes apart -- without padding they all fall on the same few banks
+// (up to 32-way conflicts); with it consecutive groups rotate through the banks.
+#define GSR_PAD(i) ((i) + ((i) >> 4))
 __device__ __forceinline__ void gsr_cex(u64& a, u64& b)
 {
     const u64 lo = a < b ? a : b, hi = a < b ? b : a;
@@ -295,7 +299,7 @@ __device__ __forceinline__ void gsr_fused_round(u64* k, uint32_t n, uint32_t m, 
 #pragma unroll
         for (int t = 0; t < E; t++) {
             const uint32_t i = base + ((uint32_t)t << lq);
-            v[t] = i < n ? k[i] : GSR_KEY_INF;
+            v[t] = i < n ? k[GSR_PAD(i)] : GSR_KEY_INF;
         }
 #pragma unroll
         for (int h = E >> 1; h >= 1; h >>= 1)
@@ -305,7 +309,7 @@ __device__ __forceinline__ void gsr_fused_round(u64* k, uint32_t n, uint32_t m, 
 #pragma unroll
         for (int t = 0; t < E; t++) {
             const uint32_t i = base + ((uint32_t)t << lq);
-            if (i < n) k[i] = v[t];
+            if (i < n) k[GSR_PAD(i)] = v[t];
         }
     }
 }
@@ -319,7 +323,7 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
     for (uint32_t c = threadIdx.x; c < (m >> 3); c += nthreads) {
         u64 v[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) v[t] = 8 * c + t < n ? k[8 * c + t] : GSR_KEY_INF;
+        for (int t = 0; t < 8; t++) v[t] = 8 * c + t < n ? k[GSR_PAD(8 * c + t)] : GSR_KEY_INF;
         gsr_cex(v[0], v[1]); gsr_cex(v[2], v[3]); gsr_cex(v[4], v[5]); gsr_cex(v[6], v[7]);   // size 2
         gsr_cex(v[0], v[3]); gsr_cex(v[1], v[2]); gsr_cex(v[4], v[7]); gsr_cex(v[5], v[6]);   // size 4: flip
         gsr_cex(v[0], v[1]); gsr_cex(v[2], v[3]); gsr_cex(v[4], v[5]); gsr_cex(v[6], v[7]);   //         stride 1
@@ -328,7 +332,7 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
         gsr_cex(v[0], v[1]); gsr_cex(v[2], v[3]); gsr_cex(v[4], v[5]); gsr_cex(v[6], v[7]);   //         stride 1
 #pragma unroll
         for (int t = 0; t < 8; t++)
-            if (8 * c + t < n) k[8 * c + t] = v[t];
+            if (8 * c + t < n) k[GSR_PAD(8 * c + t)] = v[t];
     }
     __syncthreads();
     for (uint32_t ls = 4; ls <= lm; ls++) {
@@ -337,8 +341,8 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
             const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
             const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;
             if (j < n) {
-                const u64 a = k[i], b = k[j];
-                if (a > b) { k[i] = b; k[j] = a; }
+                const u64 a = k[GSR_PAD(i)], b = k[GSR_PAD(j)];
+                if (a > b) { k[GSR_PAD(i)] = b; k[GSR_PAD(j)] = a; }
             }
         }
         __syncthreads();
@@ -351,7 +355,7 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
     }
 }
 
-// LDS variant for lo < n <= hi (dynamic LDS = 8 * hi bytes).
+// LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ depthkey,
                                                                 uint32_t* __restrict__ point_list, uint32_t lo,
@@ -365,11 +369,13 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     // (depth bits, id) is assembled here with a gather from the 4 MB depth array (L2-resident)
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t id = point_list[rg.x + i];
-        keys[i] = ((u64)depthkey[id] << 32) | id;
+        keys[GSR_PAD(i)] = ((u64)depthkey[id] << 32) | id;
     }
     __syncthreads();
+#ifndef GSR_EXP_NOSORT
     gsr_sort_lds_fused(keys, n, 256);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
+#endif
+    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
 }
 
 // Global-memory variant for lists longer than the LDS capacity (degenerate inputs: e.g. a tiny
@@ -457,12 +463,12 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const G
     if (max_tile_count < 0) max_tile_count = 0x7fffffff;
     hipError_t e;
     // size classes: (0, SMALL] in 32 KiB LDS, (SMALL, LARGE] in 128 KiB LDS, longer in global memory
-    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_SMALL * 8, stream,
+    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_PAD(GSR_SORT_CAP_SMALL) * 8, stream,
                        image.ranges, geom.depthkey, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)capacity);
     if (max_tile_count > GSR_SORT_CAP_SMALL) {
         e = gsr_allow_big_lds();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_SORT_CAP_LARGE * 8, stream,
+        hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_PAD(GSR_SORT_CAP_LARGE) * 8, stream,
                            image.ranges, geom.depthkey, bin.point_list, (uint32_t)GSR_SORT_CAP_SMALL,
                            (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     }
