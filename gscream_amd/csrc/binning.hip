@@ -104,6 +104,8 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
                                                                         uint32_t* __restrict__ table)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ uint32_t heads_all[GSR_HIST_THREADS];
+    volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
     for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0;
     __syncthreads();
     int lo, hi;
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
         }
 #pragma unroll
         for (int k = 0; k < U; k++)
-            gsr_wave_for_each_instance(rcs[k], mks[k], [&](int, int x, int y) { atomicAdd(&hist[y * gx + x], 1u); });
+            gsr_wave_for_each_instance(rcs[k], mks[k], heads, [&](int, int x, int y) { atomicAdd(&hist[y * gx + x], 1u); });
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -202,6 +204,8 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, uint32_t* __restrict__ point_list, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
+    __shared__ uint32_t heads_all[GSR_HIST_THREADS];
+    volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
     const uint32_t* row = table + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += blockDim.x) cursor[t] = ranges[t].x + row[t];
     __syncthreads();
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
                 rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
             }
             const int g_lane0 = g - (int)(threadIdx.x & 63);  // lanes of a wave hold consecutive Gaussians
-            gsr_wave_for_each_instance(rcs[k], mks[k], [&](int owner, int x, int y) {
+            gsr_wave_for_each_instance(rcs[k], mks[k], heads, [&](int owner, int x, int y) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
                 if (slot < capacity) point_list[slot] = (uint32_t)(g_lane0 + owner);  // capacity < R only in a speculative launch that is redone
             });
@@ -411,7 +415,7 @@ static hipError_t gsr_allow_big_lds()
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (done_for_device == dev) return hipSuccess;
-    const int big = 160 * 1024 - 1024;
+    const int big = 160 * 1024 - 4096;  // the hist / scatter kernels also hold 2 KiB of static LDS
     e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);

@@ -185,6 +185,34 @@ __device__ __forceinline__ uint32_t gsr_select_bit(unsigned long long m, uint32_
     return pos;
 }
 
+// Wave-wide inclusive scans on DPP (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast15 / row_bcast31 across
+// rows): 6 VALU ops, no LDS traffic.  Lanes outside the source pattern contribute the identity 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t gsr_dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t gsr_wave_scan_add(uint32_t v)
+{
+    v += gsr_dpp_u32<0x111, 0xf>(v);
+    v += gsr_dpp_u32<0x112, 0xf>(v);
+    v += gsr_dpp_u32<0x114, 0xf>(v);
+    v += gsr_dpp_u32<0x118, 0xf>(v);
+    v += gsr_dpp_u32<0x142, 0xa>(v);
+    v += gsr_dpp_u32<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t gsr_wave_scan_max(uint32_t v)
+{
+    v = max(v, gsr_dpp_u32<0x111, 0xf>(v));
+    v = max(v, gsr_dpp_u32<0x112, 0xf>(v));
+    v = max(v, gsr_dpp_u32<0x114, 0xf>(v));
+    v = max(v, gsr_dpp_u32<0x118, 0xf>(v));
+    v = max(v, gsr_dpp_u32<0x142, 0xa>(v));
+    v = max(v, gsr_dpp_u32<0x143, 0xc>(v));
+    return v;
+}
+
 // Wave-dense version of gsr_for_each_tile.  Every lane passes the rectangle and survivor mask of ITS Gaussian (a zero
 // rectangle for none); the wave then enumerates all (Gaussian, surviving tile) instances of its 64 Gaussians 64 at a
 // time, one instance per lane, and calls f(owner_lane, x, y) with all lanes (but the last round's tail) active.
@@ -192,28 +220,25 @@ __device__ __forceinline__ uint32_t gsr_select_bit(unsigned long long m, uint32_
 // round costs one LDS atomic instruction whose latency does not depend on the number of active lanes; the dense form
 // needs total/64 rounds.  Must be called by all 64 lanes (no divergence around the call).
 template <typename F>
-__device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const unsigned long long mask, F f)
+__device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const unsigned long long mask,
+                                                           volatile uint32_t* heads /* LDS, 64 words private to the wave */, F f)
 {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int x0 = rc.x & 0xffff, w = (int)(rc.x >> 16) - x0, y0 = rc.y & 0xffff, h = (int)(rc.y >> 16) - y0;
     const int area = w > 0 ? w * h : 0;
     const unsigned long long m = area >= 64 ? mask : mask & ((1ull << area) - 1ull);
     const uint32_t cnt = (uint32_t)__popcll(m) + (uint32_t)max(area - 64, 0);   // == gsr_survivors(mask, area)
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += y;
-    }
-    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t incl = gsr_wave_scan_add(cnt);
+    const uint32_t excl = incl - cnt;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     for (uint32_t base = 0; base < total; base += 64) {
         const uint32_t i = base + lane;
-        int lo = 0;  // number of lanes whose inclusive count is <= i  == the lane that owns instance i
-#pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const uint32_t v = __shfl(incl, lo + step - 1, 64);
-            lo += v <= i ? step : 0;
-        }
+        // owner of instance i = the last lane whose first instance is <= i.  Every lane whose range meets this round
+        // drops its id at the round-relative position of its first instance (ranges are disjoint, so the positions
+        // are too); an inclusive max-scan over the lanes fills the gaps.  DPP only: no dependent LDS round trips.
+        heads[lane] = 0u;
+        if (cnt != 0u && excl < base + 64u && incl > base) heads[max(excl, base) - base] = (uint32_t)lane;
+        const int lo = (int)gsr_wave_scan_max(heads[lane]);
         const uint32_t oincl = __shfl(incl, lo, 64), ocnt = __shfl(cnt, lo, 64);
         const uint32_t orx = __shfl(rc.x, lo, 64), ory = __shfl(rc.y, lo, 64);
         const uint32_t omlo = __shfl((uint32_t)m, lo, 64), omhi = __shfl((uint32_t)(m >> 32), lo, 64);
