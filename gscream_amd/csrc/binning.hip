@@ -17,7 +17,7 @@
 typedef unsigned long long u64;
 
 // ---------------------------------------------------------------------------------------------
-// Exclusive prefix scan of tiles[P] -> offsets[P]   (three small kernels, 2048 elements / block)
+// Block-wide exclusive scan helper (256 threads)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t gsr_block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds /*[8]*/)
 {
@@ -42,52 +42,6 @@ __device__ __forceinline__ uint32_t gsr_block_exclusive_scan_256(uint32_t v, uin
     return base + x - v;
 }
 
-__global__ void __launch_bounds__(256) gsr_scan_reduce_kernel(int P, const uint32_t* __restrict__ in,
-                                                              uint32_t* __restrict__ sums)
-{
-    __shared__ uint32_t lds[8];
-    const int base = blockIdx.x * GSR_SCAN_ITEMS + threadIdx.x * 8;
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) s += (base + i < P) ? in[base + i] : 0u;
-    uint32_t total;
-    gsr_block_exclusive_scan_256(s, &total, lds);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-// single block: exclusive scan of the block sums in place; sums[nblocks] = grand total
-__global__ void __launch_bounds__(256) gsr_scan_sums_kernel(int nblocks, uint32_t* __restrict__ sums)
-{
-    __shared__ uint32_t lds[8];
-    uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 256) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? sums[i] : 0u;
-        uint32_t total;
-        const uint32_t ex = gsr_block_exclusive_scan_256(v, &total, lds);
-        if (i < nblocks) sums[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) sums[nblocks] = carry;
-}
-
-__global__ void __launch_bounds__(256) gsr_scan_apply_kernel(int P, const uint32_t* __restrict__ in,
-                                                             const uint32_t* __restrict__ sums,
-                                                             uint32_t* __restrict__ out)
-{
-    __shared__ uint32_t lds[8];
-    const int base = blockIdx.x * GSR_SCAN_ITEMS + threadIdx.x * 8;
-    uint32_t v[8], s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { v[i] = (base + i < P) ? in[base + i] : 0u; s += v[i]; }
-    uint32_t run = sums[blockIdx.x] + gsr_block_exclusive_scan_256(s, nullptr, lds);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        if (base + i < P) out[base + i] = run;
-        run += v[i];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Tile histogram per chunk of Gaussians  (one counting-sort pass on the tile id, in LDS)
 // ---------------------------------------------------------------------------------------------
@@ -101,7 +55,8 @@ __device__ __forceinline__ void gsr_chunk_bounds(int P, int nchunks, int chunk, 
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, int T, int gx, int nchunks,
                                                                         const uint2* __restrict__ rect,
                                                                         const u64* __restrict__ tmask,
-                                                                        uint32_t* __restrict__ table)
+                                                                        uint32_t* __restrict__ table,
+                                                                        uint32_t* __restrict__ chunk_sum)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
@@ -128,7 +83,15 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) row[t] = hist[t];
+    uint32_t mine = 0;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) { const uint32_t v = hist[t]; row[t] = v; mine += v; }
+    // instances of the chunk = gradient slots of its Gaussians: the scatter turns these into slot offsets
+    if (threadIdx.x == 0) heads_all[0] = 0u;
+    __syncthreads();
+    mine = gsr_wave_scan_add(mine);
+    if ((threadIdx.x & 63) == 63) atomicAdd(&heads_all[0], mine);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = heads_all[0];
 }
 
 // Column pass over table[nchunks][T]: for every tile, exclusive prefix over chunks (in place) and the
@@ -199,42 +162,61 @@ __global__ void __launch_bounds__(256) gsr_tile_scan_kernel(int T, const uint32_
 // rectangle (slot claimed with an LDS atomic on the chunk's cursor row), and completes its record.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
-    int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, const u64* __restrict__ tmask,
-    const uint32_t* __restrict__ table,
-    const uint2* __restrict__ ranges, GsrRec* __restrict__ rec, uint32_t* __restrict__ point_list, uint32_t capacity)
+    int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum, const uint2* __restrict__ ranges,
+    uint32_t* __restrict__ offsets, uint32_t* __restrict__ point_list, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
+    __shared__ uint32_t wsum[GSR_HIST_THREADS / 64];
+    __shared__ uint32_t chunk_first;
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t* row = table + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += blockDim.x) cursor[t] = ranges[t].x + row[t];
+    if (threadIdx.x == 0) chunk_first = 0u;
     __syncthreads();
+    // first gradient slot of the chunk = instances of all earlier chunks (nchunks <= GSR_MAX_CHUNKS <= blockDim)
+    {
+        uint32_t pv = (int)threadIdx.x < (int)blockIdx.x ? chunk_sum[threadIdx.x] : 0u;
+        pv = gsr_wave_scan_add(pv);
+        if (lane == 63 && pv != 0u) atomicAdd(&chunk_first, pv);
+    }
+    __syncthreads();
+    uint32_t carry = chunk_first;
     int lo, hi;
     gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
     constexpr int U = 4;
-    for (int gw = lo + (int)(threadIdx.x & ~63u); gw < hi; gw += blockDim.x * U) {  // wave-uniform trip count
-        const int gb = gw + (int)(threadIdx.x & 63);
+    for (int tb = lo; tb < hi; tb += blockDim.x * U) {  // block-uniform trip count (barriers inside)
+        const int gb = tb + (int)threadIdx.x;
         uint2 rcs[U];
         u64 mks[U];
-        uint32_t nts[U], ofs[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
             const bool v = g < hi;
-            nts[k] = v ? tiles[g] : 0u;
             rcs[k] = v ? rect[g] : make_uint2(0u, 0u);
             mks[k] = v ? tmask[g] : 0ull;
-            ofs[k] = v ? offsets[g] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
-            if (nts[k] != 0) {
-                const uint2 rc = rcs[k];
-                const u64 mask = mks[k];
-                rec[g].d = make_uint4(ofs[k], (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+            // offsets[] = exclusive scan of the per-Gaussian instance counts in index order: the Gaussian's first
+            // gradient slot (blend backward, gauss_bwd).  Same count as the enumeration below by construction.
+            const uint32_t cnt = gsr_rect_count(rcs[k], mks[k]);
+            const uint32_t incl = gsr_wave_scan_add(cnt);
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+                const uint32_t sw = wsum[w];
+                tot += sw;
+                before += w < wave ? sw : 0u;
             }
-            const int g_lane0 = g - (int)(threadIdx.x & 63);  // lanes of a wave hold consecutive Gaussians
+            if (g < hi) offsets[g] = carry + before + incl - cnt;
+            carry += tot;
+            __syncthreads();
+            const int g_lane0 = g - lane;  // lanes of a wave hold consecutive Gaussians
             gsr_wave_for_each_instance(rcs[k], mks[k], heads, [&](int owner, int x, int y) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
                 if (slot < capacity) point_list[slot] = (uint32_t)(g_lane0 + owner);  // capacity < R only in a speculative launch that is redone
@@ -426,19 +408,13 @@ static hipError_t gsr_allow_big_lds()
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
-    // (1) offsets = exclusive scan of tiles
-    const int nb = gsr_scan_blocks(P);
-    hipLaunchKernelGGL(gsr_scan_reduce_kernel, dim3(nb), dim3(256), 0, stream, P, geom.tiles, geom.scan_sums);
-    hipLaunchKernelGGL(gsr_scan_sums_kernel, dim3(1), dim3(256), 0, stream, nb, geom.scan_sums);
-    hipLaunchKernelGGL(gsr_scan_apply_kernel, dim3(nb), dim3(256), 0, stream, P, geom.tiles, geom.scan_sums,
-                       geom.offsets);
-    // (2) per-chunk tile histogram -> table
+    // (1) per-chunk tile histogram -> table, per-chunk instance totals
     const size_t lds = (size_t)T * 4;
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_tile_hist_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.tmask, image.table);
-    // (3) column scan -> per-(chunk, tile) offsets + tile totals, then tile scan -> ranges, info
+                       geom.rect, geom.tmask, image.table, geom.scan_sums);
+    // (2) column scan -> per-(chunk, tile) offsets + tile totals, then tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
                        image.tile_count);
     hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(256), 0, stream, T, image.tile_count, image.ranges,
@@ -454,8 +430,8 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.offsets, geom.tiles, geom.tmask, image.table, image.ranges, geom.rec,
-                       bin.point_list, (uint32_t)capacity);
+                       geom.rect, geom.tmask, image.table, geom.scan_sums, image.ranges, geom.offsets, bin.point_list,
+                       (uint32_t)capacity);
     return hipGetLastError();
 }
 

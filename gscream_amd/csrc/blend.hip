@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     int H, int gx, int T, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_order,
-    uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
+    const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
 {
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ __attribute__((aligned(16))) float acc[GSR_BATCH * GSR_SLOT_FLOATS];
@@ -306,14 +306,16 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
         const int lo = max(0, hi - GSR_BATCH), cnt = hi - lo;
         constexpr bool active = true;
         if (t < cnt) {
-            const GsrRec* r = rec + point_list[rg.x + (hi - 1 - t)];
+            const uint32_t id = point_list[rg.x + (hi - 1 - t)];
+            const GsrRec* r = rec + id;
+            const uint32_t slot0 = offsets[id];  // first gradient slot of the Gaussian (exclusive scan of tiles[])
             const uint4 d = r->d;
             const float4 c = r->c;
             // gradient slot = Gaussian's scan offset + rank of this tile among the surviving tiles of its rectangle
             const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)__float_as_uint(c.w);
             const int pos = (ty - y0) * wd + (tx - x0);
             const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
-            sSlot[t] = d.x + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
+            sSlot[t] = slot0 + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
             const float4 a = r->a, b = r->b;
             sA[t] = a; sB[t] = b; sC[t] = c;
             sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
@@ -498,10 +500,10 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     if (dL_ddepth && dL_dfeature)
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
                            geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature,
-                           image.tile_order, slot_written, s4);
+                           image.tile_order, geom.offsets, slot_written, s4);
     else
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
                            geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, nullptr, nullptr,
-                           image.tile_order, slot_written, s4);
+                           image.tile_order, geom.offsets, slot_written, s4);
     return hipGetLastError();
 }

@@ -130,8 +130,9 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     const bool vis = live && radii[idx] > 0;
     const uint32_t off = live ? offsets[idx] : 0u;
     const uint32_t cnt = live ? tiles[idx] : 0u;
-    const uint32_t S0 = offsets[g0];
-    const uint32_t S1 = (g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots;
+    // clamped to the slot count: a forward that binned nothing (num_slots = 0) need not have produced offsets
+    const uint32_t S1 = min((g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots, (uint32_t)num_slots);
+    const uint32_t S0 = min(offsets[g0], S1);
     // early requests for the per-Gaussian half (independent of the slot phase)
     float3 m = make_float3(0.f, 0.f, 0.f), sc = make_float3(0.f, 0.f, 0.f);
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -185,6 +185,15 @@ __device__ __forceinline__ uint32_t gsr_select_bit(unsigned long long m, uint32_
     return pos;
 }
 
+// number of (Gaussian, surviving tile) instances of a rectangle + survivor mask (0 for the zero rectangle)
+__device__ __forceinline__ uint32_t gsr_rect_count(const uint2 rc, const unsigned long long mask)
+{
+    const int w = (int)(rc.x >> 16) - (int)(rc.x & 0xffff), h = (int)(rc.y >> 16) - (int)(rc.y & 0xffff);
+    const int area = w > 0 ? w * h : 0;
+    const unsigned long long m = area >= 64 ? mask : mask & ((1ull << area) - 1ull);
+    return (uint32_t)__popcll(m) + (uint32_t)max(area - 64, 0);
+}
+
 // Wave-wide inclusive scans on DPP (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast15 / row_bcast31 across
 // rows): 6 VALU ops, no LDS traffic.  Lanes outside the source pattern contribute the identity 0.
 template <int CTRL, int ROW_MASK>

@@ -235,7 +235,10 @@ def test_preprocess_outputs_are_bit_exact():
     assert (tiles == st["tiles_touched"].astype(np.int64)).all()
     offs = gv["offsets"].cpu().numpy().astype(np.int64)
     assert (offs == np.concatenate([[0], np.cumsum(tiles)[:-1]])).all(), "exclusive scan of tiles_touched"
-    assert (gv["rec_i32"].cpu().numpy()[vis, 12].astype(np.int64) == offs[vis]).all(), "record tail carries the slot offset"
+    # record tail: {0, x0 | y0 << 16, survivor mask lo, hi} (the slot offset lives in offsets[], written by the scatter)
+    tail = gv["rec_i32"].cpu().numpy()[vis, 12:16].astype(np.int64) & 0xffffffff
+    rect = gv["rect"].cpu().numpy().astype(np.int64)[vis] & 0xffffffff
+    assert (tail[:, 0] == 0).all() and (tail[:, 1] == ((rect[:, 0] & 0xffff) | ((rect[:, 1] & 0xffff) << 16))).all()
 
 
 def test_empty_and_degenerate_inputs():
