@@ -52,4 +52,5 @@ def binning_views(buf, R, capacity=None):
     out = {}
     out["seg_keys"] = _take(buf, off, r * 8, torch.int64, (r,))[:R]; off += _align(r * 8)
     out["point_list"] = _take(buf, off, r * 4, torch.int32, (r,))[:R]; off += _align(r * 4)
+    out["slot_written"] = _take(buf, off, r, torch.uint8, (r,))[:R]; off += _align(r)
     return out

@@ -116,11 +116,10 @@ extern "C" int gsr_device_count(void)
 extern "C" size_t gsr_geom_bytes(int P) { return gsr_carve_geom(nullptr, P).bytes; }
 extern "C" size_t gsr_image_bytes(int P, int W, int H) { return gsr_carve_image(nullptr, P, W, H).bytes; }
 extern "C" size_t gsr_binning_bytes(int R) { return gsr_carve_binning(nullptr, R).bytes; }
-static size_t gsr_slot_bytes(int num_slots) { return gsr_align((size_t)(num_slots > 0 ? num_slots : 1) * GSR_SLOT_FLOATS * sizeof(float)); }
 extern "C" size_t gsr_backward_scratch_bytes(int P, int num_slots)
 {
-    (void)P;  // slots[num_slots] (48 B each) followed by one "written" byte per slot
-    return gsr_slot_bytes(num_slots) + gsr_align((size_t)(num_slots > 0 ? num_slots : 1));
+    (void)P;  // slots[num_slots], 48 B each
+    return gsr_align((size_t)(num_slots > 0 ? num_slots : 1) * GSR_SLOT_FLOATS * sizeof(float));
 }
 
 static int gsr_make_cam(GsrCam& cam, int W, int H, const float* view_d, const float* proj_d, const float* campos_d,
@@ -328,8 +327,9 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binnin
     if (binning_capacity < R) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "binning_capacity < R");
     const GsrBinning bin = gsr_carve_binning(const_cast<void*>(binning_ws), binning_capacity);
     float* slots = (float*)scratch;
-    uint8_t* slot_written = (uint8_t*)scratch + gsr_slot_bytes(R);
-    if (R > 0) GSR_HIP(hipMemsetAsync(slot_written, 0, (size_t)R, stream), "clear slot flags");
+    // written-slot flags: cleared by the forward's tile sort, set by the backward blend, cleared again by the
+    // per-Gaussian backward as it consumes them -- so a second backward over the same forward state works
+    uint8_t* slot_written = bin.slot_written;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
                                             dL_dout_feature, slots, slot_written, stream),

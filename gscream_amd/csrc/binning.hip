@@ -344,13 +344,16 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
 // LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ depthkey,
-                                                                uint32_t* __restrict__ point_list, uint32_t lo,
+                                                                uint32_t* __restrict__ point_list,
+                                                                uint8_t* __restrict__ slot_written, uint32_t lo,
                                                                 uint32_t hi, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) u64 keys[];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || n > hi || rg.y > capacity) return;
+    // the tile ranges partition [0, R): each block clears its share of the written-slot flags for the backward
+    for (uint32_t i = threadIdx.x; i < n; i += 256) slot_written[rg.x + i] = 0;
     // the scatter left the tile's Gaussian ids (4 B each) in its segment of point_list; the 64-bit sort key
     // (depth bits, id) is assembled here with a gather from the 4 MB depth array (L2-resident)
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -369,12 +372,14 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
 __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2* __restrict__ ranges,
                                                                     const uint32_t* __restrict__ depthkey,
                                                                     u64* __restrict__ seg_keys,
-                                                                    uint32_t* __restrict__ point_list, uint32_t lo,
+                                                                    uint32_t* __restrict__ point_list,
+                                                                    uint8_t* __restrict__ slot_written, uint32_t lo,
                                                                     uint32_t capacity)
 {
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || rg.y > capacity) return;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) slot_written[rg.x + i] = 0;
     u64* k = seg_keys + rg.x;
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t id = point_list[rg.x + i];
@@ -444,16 +449,17 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const G
     hipError_t e;
     // size classes: (0, SMALL] in 32 KiB LDS, (SMALL, LARGE] in 128 KiB LDS, longer in global memory
     hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_PAD(GSR_SORT_CAP_SMALL) * 8, stream,
-                       image.ranges, geom.depthkey, bin.point_list, 0u, (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)capacity);
+                       image.ranges, geom.depthkey, bin.point_list, bin.slot_written, 0u, (uint32_t)GSR_SORT_CAP_SMALL,
+                       (uint32_t)capacity);
     if (max_tile_count > GSR_SORT_CAP_SMALL) {
         e = gsr_allow_big_lds();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_PAD(GSR_SORT_CAP_LARGE) * 8, stream,
-                           image.ranges, geom.depthkey, bin.point_list, (uint32_t)GSR_SORT_CAP_SMALL,
+                           image.ranges, geom.depthkey, bin.point_list, bin.slot_written, (uint32_t)GSR_SORT_CAP_SMALL,
                            (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     }
     if (max_tile_count > GSR_SORT_CAP_LARGE)
         hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, geom.depthkey, bin.seg_keys,
-                           bin.point_list, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
+                           bin.point_list, bin.slot_written, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     return hipGetLastError();
 }

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, int num_slots,
-    const float4* __restrict__ slots, const uint8_t* __restrict__ slot_written, float* __restrict__ dL_dmeans2D,
+    const float4* __restrict__ slots, uint8_t* __restrict__ slot_written, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeatures,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
         for (int k = 0; k < FCH / 64; k++) {
             const unsigned long long mk = __ballot(f[k] != 0);
             if (f[k]) wl[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(k * 64 + lane);
+            if (f[k]) slot_written[base + k * 64 + lane] = 0;  // consumed: the flags stay clear for the next backward
             if (lane == 0) { gmask[k] = mk; gbase[k] = run; }
             run += (uint32_t)__popcll(mk);
         }
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
                                      const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
-                                     const uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                                     uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream)
 {

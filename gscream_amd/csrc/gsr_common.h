@@ -74,6 +74,7 @@ struct GsrImage {
 struct GsrBinning {
     uint32_t* point_list;
     unsigned long long* seg_keys;
+    uint8_t* slot_written;  // [R] 1 = the backward blend wrote this gradient slot; all zero between calls
     size_t bytes;
 };
 
@@ -134,6 +135,7 @@ static inline GsrBinning gsr_carve_binning(void* base, int R)
     size_t r = (size_t)(R > 0 ? R : 1);
     bn.seg_keys = (unsigned long long*)(b + off); off += gsr_align(r * 8);
     bn.point_list = (uint32_t*)(b + off); off += gsr_align(r * 4);
+    bn.slot_written = (uint8_t*)(b + off); off += gsr_align(r);
     bn.bytes = off;
     return bn;
 }
@@ -171,6 +173,6 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
                                      const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
-                                     const uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                                     uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream);

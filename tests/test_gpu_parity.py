@@ -290,6 +290,12 @@ def test_render_call_pattern_of_gaussian_renderer():
     assert screenspace_points.grad.shape == (3000, 3) and screenspace_points.grad[visibility_filter, :2].abs().sum() > 0
     assert xyz.grad.shape == (3000, 3) and opacity.grad.shape == (3000, 1) and unc.grad.shape == (3000, 1)
     assert not unc.grad.any(), "no loss on the feature map -> zero feature gradient"
+    # a second backward over the same saved forward state (the written-slot flags must have been left clear)
+    g1 = xyz.grad.clone()
+    xyz.grad = None
+    loss.backward(retain_graph=True)
+    d = (xyz.grad - g1).abs().max().item()
+    assert d <= 1e-5 * max(g1.abs().max().item(), 1e-30) + 1e-12, f"second backward differs by {d}"
     with torch.no_grad():  # eval path, train.py:756-763
         img2 = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color, opacities=opacity,
                           uncertainties=unc, scales=scaling, rotations=rot, cov3D_precomp=None)[0]
