@@ -443,23 +443,42 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
 // XCD's band of tile rows.  Here each band is re-ordered by descending work (deepest n_contrib first), so the long
 // tiles start first and the tail of the launch is made of short ones; the band -> XCD assignment (L2 locality)
 // is unchanged.  One workgroup per band; bands hold <= 4608 tiles (T <= 36864), sorted in LDS.
-__global__ void __launch_bounds__(256) gsr_tile_order_kernel(int T, const uint32_t* __restrict__ tile_work,
-                                                              uint32_t* __restrict__ tile_order)
+__global__ void __launch_bounds__(1024) gsr_tile_order_kernel(int T, const uint32_t* __restrict__ tile_work,
+                                                               uint32_t* __restrict__ tile_order)
 {
     __shared__ unsigned long long k[4608 + 1];
+    __shared__ uint32_t rank[1024];
     const int xcd = blockIdx.x, q = T >> 3, r = T & 7;
     const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int cnt = q + (xcd < r ? 1 : 0);
-    for (int i = threadIdx.x; i < cnt; i += 256)
+    const int nt = blockDim.x;
+    for (int i = threadIdx.x; i < cnt; i += nt)
         k[i] = ((unsigned long long)(0xffffffffu - tile_work[first + i]) << 32) | (uint32_t)(first + i);
+    if (threadIdx.x < 1024) rank[threadIdx.x] = 0u;
     __syncthreads();
+    if (cnt <= 1024) {
+        // rank sort: the keys are unique, so the number of smaller keys IS the output position.  Thread (e, part)
+        // compares element e with one quarter of the keys (LDS broadcast reads); the four partial ranks meet in LDS.
+        const int part = threadIdx.x >> 8, e0 = threadIdx.x & 255;
+        const int j0 = (cnt * part) >> 2, j1 = (cnt * (part + 1)) >> 2;
+        for (int e = e0; e < cnt; e += 256) {
+            const unsigned long long mine = k[e];
+            uint32_t c = 0;
+#pragma unroll 8
+            for (int j = j0; j < j1; j++) c += k[j] < mine ? 1u : 0u;
+            atomicAdd(&rank[e], c);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += nt) tile_order[xcd + 8 * rank[e]] = (uint32_t)k[e];  // block b = 8 i + xcd
+        return;
+    }
     // plain bitonic network (ascending) with virtual +inf padding, as in binning.hip
     uint32_t lm = 0;
     while ((1u << lm) < (uint32_t)cnt) lm++;
     const uint32_t npairs = (1u << lm) >> 1;
     for (uint32_t ls = 1; ls <= lm; ls++) {
         const uint32_t lh = ls - 1, half = 1u << lh;
-        for (uint32_t t = threadIdx.x; t < npairs; t += 256) {
+        for (uint32_t t = threadIdx.x; t < npairs; t += nt) {
             const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
             const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;
             if (j < (uint32_t)cnt && k[i] > k[j]) { const unsigned long long a = k[i]; k[i] = k[j]; k[j] = a; }
@@ -467,14 +486,14 @@ __global__ void __launch_bounds__(256) gsr_tile_order_kernel(int T, const uint32
         __syncthreads();
         for (int lst = (int)lh - 1; lst >= 0; lst--) {
             const uint32_t stride = 1u << lst;
-            for (uint32_t t = threadIdx.x; t < npairs; t += 256) {
+            for (uint32_t t = threadIdx.x; t < npairs; t += nt) {
                 const uint32_t i = ((t >> lst) << (lst + 1)) + (t & (stride - 1)), j = i + stride;
                 if (j < (uint32_t)cnt && k[i] > k[j]) { const unsigned long long a = k[i]; k[i] = k[j]; k[j] = a; }
             }
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < cnt; i += 256) tile_order[xcd + 8 * i] = (uint32_t)k[i];  // block b = 8 i + xcd
+    for (int i = threadIdx.x; i < cnt; i += nt) tile_order[xcd + 8 * i] = (uint32_t)k[i];  // block b = 8 i + xcd
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -496,7 +515,7 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
-    hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(8), dim3(256), 0, stream, T, image.tile_work, image.tile_order);
+    hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(8), dim3(1024), 0, stream, T, image.tile_work, image.tile_order);
     if (dL_ddepth && dL_dfeature)
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
                            geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature,
