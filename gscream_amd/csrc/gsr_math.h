@@ -222,6 +222,25 @@ __device__ __forceinline__ uint32_t gsr_wave_scan_max(uint32_t v)
     return v;
 }
 
+// Generic wave-dense enumeration: lane L contributes cnt_L items; the wave walks all sum(cnt) items 64 at a time and
+// calls f(owner_lane, r, active) in EVERY lane each round (active = this lane holds an item: the r-th of `owner`), so
+// that f may itself use cross-lane reads of the owner's registers.  `heads`: 64 words of LDS private to the wave.
+template <typename F>
+__device__ __forceinline__ void gsr_wave_dense(const uint32_t cnt, volatile uint32_t* heads, F f)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t incl = gsr_wave_scan_add(cnt);
+    const uint32_t excl = incl - cnt;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t base = 0; base < total; base += 64) {
+        heads[lane] = 0u;
+        if (cnt != 0u && excl < base + 64u && incl > base) heads[max(excl, base) - base] = (uint32_t)lane;
+        const int owner = (int)gsr_wave_scan_max(heads[lane]);
+        const uint32_t oexcl = __shfl(excl, owner, 64);
+        f(owner, base + lane - oexcl, base + lane < total);
+    }
+}
+
 // Wave-dense version of gsr_for_each_tile.  Every lane passes the rectangle and survivor mask of ITS Gaussian (a zero
 // rectangle for none); the wave then enumerates all (Gaussian, surviving tile) instances of its 64 Gaussians 64 at a
 // time, one instance per lane, and calls f(owner_lane, x, y) with all lanes (but the last round's tail) active.

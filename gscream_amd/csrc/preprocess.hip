@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
     GsrRec* __restrict__ rec, uint2* __restrict__ rect, uint32_t* __restrict__ depthkey, uint32_t* __restrict__ tiles,
     unsigned long long* __restrict__ tmask, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, float* __restrict__ out_px, float* __restrict__ out_py)
 {
+    __shared__ uint32_t s_heads[MODE == 0 ? 256 : 1];
+    __shared__ unsigned long long s_mask[MODE == 0 ? 256 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
 
@@ -120,11 +122,11 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
     depthkey[idx] = __float_as_uint(viewz);
     unsigned long long mask = ~0ull;
     float tau = 0.f;
+    int4 cull_box = make_int4(0, 0, 0, 0);  // tiles (x, y, w, h) of the alpha >= 1/255 ellipse box inside the rectangle
     if (radius > 0) {
         tau = gsr_cull_tau(opacities[idx]);
         if (tile_cull) {
             const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-            const float rA = 1.0f / conx, rC = 1.0f / conz;
             // Tiles outside the axis-aligned bounding box of the alpha >= 1/255 ellipse {q <= tau} cannot
             // survive: |dx| <= sqrt(2 tau cov_xx), |dy| <= sqrt(2 tau cov_yy) (cov = inverse conic).  Only the
             // tiles inside box & rectangle run the exact test; for a typical splat that is 1-4 of the 4-16
@@ -133,15 +135,50 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
             const float ex = sqrtf(t2 * cova) + 1.0f, ey = sqrtf(t2 * covc) + 1.0f;  // +1 px slack
             const int bx0 = max(x0, gsr_f2i((pix - ex) * 0.0625f)), bx1 = min(x1, gsr_f2i((pix + ex) * 0.0625f) + 1);
             const int by0 = max(y0, gsr_f2i((piy - ey) * 0.0625f)), by1 = min(y1, gsr_f2i((piy + ey) * 0.0625f) + 1);
-            const int wd = x1 - x0;
+            cull_box = make_int4(bx0, by0, max(bx1 - bx0, 0), max(by1 - by0, 0));
             mask = 0ull;
-            if (!(tau == tau)) mask = ~0ull;  // NaN tau (non-positive opacity): keep everything, like the box test would
-            else
-                for (int y = by0; y < by1; y++)
-                    for (int x = bx0; x < bx1; x++) {
-                        const int i = (y - y0) * wd + (x - x0);
-                        if (i < 64 && gsr_tile_survives(pix, piy, conx, cony, conz, rA, rC, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
-                    }
+            if (!(tau == tau)) {  // NaN tau (non-positive opacity): keep everything, like the box test would
+                mask = ~0ull;
+                cull_box.z = cull_box.w = 0;
+            }
+        }
+    }
+    if (tile_cull) {
+        // The exact test runs once per (Gaussian, tile of its ellipse box).  A per-lane loop has as many trips as the
+        // LARGEST box in the wave; full waves instead enumerate all their boxes' tiles densely, one per lane per
+        // round (the owner's operands come over ds_bpermute, the survivor bits meet in an LDS word per Gaussian).
+        const bool full_wave = blockIdx.x * blockDim.x + (threadIdx.x | 63u) < (unsigned)P;  // wave-uniform
+        const int x0 = rc.x & 0xffff, y0 = rc.y & 0xffff, wd = (int)(rc.x >> 16) - x0;
+        const float rA = 1.0f / conx, rC = 1.0f / conz;
+        if (full_wave) {
+            const int lane = threadIdx.x & 63;
+            volatile uint32_t* heads = s_heads + (threadIdx.x & ~63u);
+            unsigned long long* wmask = s_mask + (threadIdx.x & ~63u);
+            wmask[lane] = 0ull;
+            gsr_wave_dense((uint32_t)(cull_box.z * cull_box.w), heads, [&](int owner, uint32_t r, bool act) {
+                const float o_pix = __shfl(pix, owner, 64), o_piy = __shfl(piy, owner, 64);
+                const float o_cx = __shfl(conx, owner, 64), o_cy = __shfl(cony, owner, 64), o_cz = __shfl(conz, owner, 64);
+                const float o_rA = __shfl(rA, owner, 64), o_rC = __shfl(rC, owner, 64), o_tau = __shfl(tau, owner, 64);
+                const int o_bx0 = __shfl(cull_box.x, owner, 64), o_by0 = __shfl(cull_box.y, owner, 64), o_bw = __shfl(cull_box.z, owner, 64);
+                const int o_x0 = __shfl(x0, owner, 64), o_y0 = __shfl(y0, owner, 64), o_wd = __shfl(wd, owner, 64);
+                if (act) {
+                    int row = (int)((float)r * __frcp_rn((float)o_bw));  // off by at most one, fixed below
+                    int col = (int)r - row * o_bw;
+                    if (col < 0) { row--; col += o_bw; }
+                    if (col >= o_bw) { row++; col -= o_bw; }
+                    const int x = o_bx0 + col, y = o_by0 + row;
+                    const int i = (y - o_y0) * o_wd + (x - o_x0);
+                    if (i < 64 && gsr_tile_survives(o_pix, o_piy, o_cx, o_cy, o_cz, o_rA, o_rC, o_tau, x, y, cam.W, cam.H))
+                        atomicOr(&wmask[owner], 1ull << i);
+                }
+            });
+            if (cull_box.z * cull_box.w > 0) mask = wmask[lane];
+        } else if (cull_box.z * cull_box.w > 0) {
+            for (int y = cull_box.y; y < cull_box.y + cull_box.w; y++)
+                for (int x = cull_box.x; x < cull_box.x + cull_box.z; x++) {
+                    const int i = (y - y0) * wd + (x - x0);
+                    if (i < 64 && gsr_tile_survives(pix, piy, conx, cony, conz, rA, rC, tau, x, y, cam.W, cam.H)) mask |= 1ull << i;
+                }
         }
     }
     tmask[idx] = mask;
