@@ -143,6 +143,10 @@ int gsr_forward(int P, int D, int M, int W, int H,
  *   dL_dmeans3D[P,3]  dL_dscales[P,3]  dL_drotations[P,4]
  * dL_dout_depth and dL_dout_feature may both be NULL (= no gradient flows into those maps; a cheaper
  * kernel variant runs).  No floating-point atomics on global memory are used.
+ * The image workspace (tile launch order) and the binning workspace (one "slot written" byte per instance: set by
+ * the blend, cleared again by the per-Gaussian pass) are used as scratch during the call and left as the forward
+ * produced them, so the backward may run again on the same forward state; two backward calls on ONE forward state
+ * must not overlap on different streams.
  */
 int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity /* what the forward's binning
                  workspace was sized for; = R after the two-stage forward */, const float* background,
