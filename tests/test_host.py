@@ -28,7 +28,7 @@ def test_workspace_sizes(native_lib):
     g, i, b = native_lib.gsr_geom_bytes(P), native_lib.gsr_image_bytes(P, W, H), native_lib.gsr_binning_bytes(R)
     assert g % 256 == 0 and i % 256 == 0 and b % 256 == 0
     assert 84 * P <= g <= 100 * P          # 64-B record + rect 8 + depthkey 4 + tiles 4 + offsets 4 (+ SH flags)
-    assert 12 * R <= b <= 12 * R + 4096    # 8-B sort key + 4-B sorted id per instance
+    assert 13 * R <= b <= 13 * R + 4096    # 8-B sort key + 4-B sorted id + 1 "slot written" byte per instance
     assert native_lib.gsr_backward_scratch_bytes(P, R) >= 48 * R
     assert native_lib.gsr_geom_bytes(0) > 0 and native_lib.gsr_binning_bytes(0) > 0
     # layout mirror used by the tests agrees with the C carve
