@@ -275,11 +275,13 @@ __device__ __forceinline__ void gsr_cex(u64& a, u64& b)
 }
 // half-cleaners at strides q*2^(L-1) ... q on the 2^L keys {base + t*q}; q = 2^lq
 template <int L>
-__device__ __forceinline__ void gsr_fused_round(u64* k, uint32_t n, uint32_t m, int lq, int nthreads)
+__device__ __forceinline__ void gsr_fused_round(u64* k, uint32_t n, uint32_t m, int lq, int nthreads, uint32_t vt)
 {
     constexpr int E = 1 << L;
-    const uint32_t groups = m >> L, qm = (1u << lq) - 1u;
-    for (uint32_t g = threadIdx.x; g < groups; g += nthreads) {
+    // groups whose keys all lie in the virtual +inf padding (index >= n) have nothing to do: whole waves drop out
+    const uint32_t span = (uint32_t)E << lq, qm = (1u << lq) - 1u;
+    const uint32_t groups = min(m >> L, ((n + span - 1u) / span) << lq);
+    for (uint32_t g = vt; g < groups; g += nthreads) {
         const uint32_t base = ((g >> lq) << (L + lq)) + (g & qm);
         u64 v[E];
 #pragma unroll
@@ -302,11 +304,16 @@ __device__ __forceinline__ void gsr_fused_round(u64* k, uint32_t n, uint32_t m, 
 
 __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, const int nthreads)
 {
+    // Work is dealt to wavefronts in 64-thread quanta from the low indices up, so with virtual padding the high
+    // wavefronts idle.  Wave w of every workgroup tends to sit on SIMD w: rotate the wave <-> quantum map per
+    // workgroup so that the idle slots of the CU's resident workgroups fall on different SIMDs.
+    const uint32_t vt = (threadIdx.x + 64u * ((blockIdx.x >> 3) & 3u)) & (uint32_t)(nthreads - 1);
+
     uint32_t lm = 3;
     while ((1u << lm) < n) lm++;
     const uint32_t m = 1u << lm;
     // phase 0: every run of 8 consecutive keys sorted in registers (the merges of size 2, 4, 8)
-    for (uint32_t c = threadIdx.x; c < (m >> 3); c += nthreads) {
+    for (uint32_t c = vt; c < ((n + 7u) >> 3); c += nthreads) {
         u64 v[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) v[t] = 8 * c + t < n ? k[GSR_PAD(8 * c + t)] : GSR_KEY_INF;
@@ -323,7 +330,8 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
     __syncthreads();
     for (uint32_t ls = 4; ls <= lm; ls++) {
         const uint32_t lh = ls - 1, half = 1u << lh;
-        for (uint32_t t = threadIdx.x; t < (m >> 1); t += nthreads) {  // flip: i <-> mirror inside the 2^ls block
+        const uint32_t npairs = min(m >> 1, ((n + (1u << ls) - 1u) >> ls) << lh);  // blocks that start below n
+        for (uint32_t t = vt; t < npairs; t += nthreads) {  // flip: i <-> mirror inside the 2^ls block
             const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
             const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;
             if (j < n) {
@@ -333,9 +341,9 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
         }
         __syncthreads();
         for (int hs = (int)ls - 2; hs >= 0; hs -= 3) {  // half-cleaner strides 2^hs ... 1, three per round
-            if (hs >= 2) gsr_fused_round<3>(k, n, m, hs - 2, nthreads);
-            else if (hs == 1) gsr_fused_round<2>(k, n, m, 0, nthreads);
-            else gsr_fused_round<1>(k, n, m, 0, nthreads);
+            if (hs >= 2) gsr_fused_round<3>(k, n, m, hs - 2, nthreads, vt);
+            else if (hs == 1) gsr_fused_round<2>(k, n, m, 0, nthreads, vt);
+            else gsr_fused_round<1>(k, n, m, 0, nthreads, vt);
             __syncthreads();
         }
     }
@@ -346,12 +354,14 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
                                                                 const uint32_t* __restrict__ depthkey,
                                                                 uint32_t* __restrict__ point_list,
                                                                 uint8_t* __restrict__ slot_written, uint32_t lo,
-                                                                uint32_t hi, uint32_t capacity)
+                                                                uint32_t hi, uint32_t fits, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) u64 keys[];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n <= lo || n > hi || rg.y > capacity) return;
+    // n > fits: the LDS was provisioned from a stale hint of the longest list (speculative launch); the host sees the
+    // true maximum after the fact and redoes stage 2
+    if (n <= lo || n > hi || n > fits || rg.y > capacity) return;
     // the tile ranges partition [0, R): each block clears its share of the written-slot flags for the backward
     for (uint32_t i = threadIdx.x; i < n; i += 256) slot_written[rg.x + i] = 0;
     // the scatter left the tile's Gaussian ids (4 B each) in its segment of point_list; the 64-bit sort key
@@ -447,16 +457,24 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const G
     if (capacity <= 0) return hipSuccess;
     if (max_tile_count < 0) max_tile_count = 0x7fffffff;
     hipError_t e;
-    // size classes: (0, SMALL] in 32 KiB LDS, (SMALL, LARGE] in 128 KiB LDS, longer in global memory
-    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_PAD(GSR_SORT_CAP_SMALL) * 8, stream,
-                       image.ranges, geom.depthkey, bin.point_list, bin.slot_written, 0u, (uint32_t)GSR_SORT_CAP_SMALL,
-                       (uint32_t)capacity);
-    if (max_tile_count > GSR_SORT_CAP_SMALL) {
-        e = gsr_allow_big_lds();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), (size_t)GSR_PAD(GSR_SORT_CAP_LARGE) * 8, stream,
-                           image.ranges, geom.depthkey, bin.point_list, bin.slot_written, (uint32_t)GSR_SORT_CAP_SMALL,
-                           (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
+    // size classes by list length: (0, SMALL] and (SMALL, LARGE] in LDS, longer in global memory.  The network is a
+    // chain of ~30 LDS round trips + barriers per workgroup and runs at the speed occupancy allows, and virtual
+    // padding is never stored: the dynamic LDS is sized for the longest list that exists (8.5 B per key), not for
+    // the class limit -- 11 KiB instead of 34 KiB on the bench scene, twice the resident workgroups.
+    const uint32_t caps[] = { (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)GSR_SORT_CAP_LARGE };
+    uint32_t lo = 0;
+    for (uint32_t cap : caps) {
+        if ((uint32_t)max_tile_count > lo) {
+            if (cap > GSR_SORT_CAP_SMALL) {
+                e = gsr_allow_big_lds();
+                if (e != hipSuccess) return e;
+            }
+            const uint32_t longest = min(cap, (uint32_t)max_tile_count);
+            const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
+            hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, geom.depthkey,
+                               bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity);
+        }
+        lo = cap;
     }
     if (max_tile_count > GSR_SORT_CAP_LARGE)
         hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, geom.depthkey, bin.seg_keys,

@@ -146,7 +146,9 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
                                         _native.ptr(img), _native.ptr(binning), *outs, _native.ctypes.byref(_tuning),
                                         debug, stream)
             _native.check(rc, "gsr_forward_stage2")
-        _capacity_hint[dev.index] = (int(1.25 * R) + 65536, max(4096, int(1.5 * res.max_tile_count)))
+        # second field: provision for the longest tile list (sizes the LDS of the per-tile sort; a tight value lets
+        # more sort workgroups be resident); exceeded -> GSR_NEED_CAPACITY -> stage 2 is redone above
+        _capacity_hint[dev.index] = (int(1.25 * R) + 65536, max(1024, int(1.25 * res.max_tile_count) + 64))
     _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots),
                         binning_capacity=cap, speculative=done)
     return R, color, depth, unc, radii, geom, binning, img, cap
