@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
         }
 #pragma unroll
         for (int k = 0; k < U; k++)
-            gsr_wave_for_each_instance(rcs[k], mks[k], heads, [&](int, int x, int y) { atomicAdd(&hist[y * gx + x], 1u); });
+            gsr_wave_for_each_instance(rcs[k], mks[k], 0u, heads, [&](int, int x, int y, uint32_t) { atomicAdd(&hist[y * gx + x], 1u); });
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * T;
@@ -163,8 +163,8 @@ __global__ void __launch_bounds__(256) gsr_tile_scan_kernel(int T, const uint32_
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum, const uint2* __restrict__ ranges,
-    uint32_t* __restrict__ offsets, uint32_t* __restrict__ point_list, uint32_t capacity)
+    const uint32_t* __restrict__ depthkey, const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum,
+    const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
@@ -191,12 +191,14 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         const int gb = tb + (int)threadIdx.x;
         uint2 rcs[U];
         u64 mks[U];
+        uint32_t dks[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
             const bool v = g < hi;
             rcs[k] = v ? rect[g] : make_uint2(0u, 0u);
             mks[k] = v ? tmask[g] : 0ull;
+            dks[k] = v ? depthkey[g] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
@@ -217,9 +219,12 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             carry += tot;
             __syncthreads();
             const int g_lane0 = g - lane;  // lanes of a wave hold consecutive Gaussians
-            gsr_wave_for_each_instance(rcs[k], mks[k], heads, [&](int owner, int x, int y) {
+            // the instance's 64-bit sort key (depth bits, id) goes straight into its tile's segment: a scattered store
+            // costs one 32-byte sector whether it carries 4 or 8 bytes, and the sort then reads its keys coalesced
+            // instead of gathering 4-byte depths
+            gsr_wave_for_each_instance(rcs[k], mks[k], dks[k], heads, [&](int owner, int x, int y, uint32_t odk) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                if (slot < capacity) point_list[slot] = (uint32_t)(g_lane0 + owner);  // capacity < R only in a speculative launch that is redone
+                if (slot < capacity) seg_keys[slot] = ((u64)odk << 32) | (uint32_t)(g_lane0 + owner);  // capacity < R only in a speculative launch that is redone
             });
         }
     }
@@ -351,7 +356,7 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
 
 // LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
-                                                                const uint32_t* __restrict__ depthkey,
+                                                                const u64* __restrict__ seg_keys,
                                                                 uint32_t* __restrict__ point_list,
                                                                 uint8_t* __restrict__ slot_written, uint32_t lo,
                                                                 uint32_t hi, uint32_t fits, uint32_t capacity)
@@ -364,12 +369,8 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     if (n <= lo || n > hi || n > fits || rg.y > capacity) return;
     // the tile ranges partition [0, R): each block clears its share of the written-slot flags for the backward
     for (uint32_t i = threadIdx.x; i < n; i += 256) slot_written[rg.x + i] = 0;
-    // the scatter left the tile's Gaussian ids (4 B each) in its segment of point_list; the 64-bit sort key
-    // (depth bits, id) is assembled here with a gather from the 4 MB depth array (L2-resident)
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t id = point_list[rg.x + i];
-        keys[GSR_PAD(i)] = ((u64)depthkey[id] << 32) | id;
-    }
+    // the scatter left the tile's 64-bit keys (depth bits, Gaussian id) in its segment of seg_keys
+    for (uint32_t i = threadIdx.x; i < n; i += 256) keys[GSR_PAD(i)] = seg_keys[rg.x + i];
     __syncthreads();
 #ifndef GSR_EXP_NOSORT
     gsr_sort_lds_fused(keys, n, 256);
@@ -380,7 +381,6 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
 // Global-memory variant for lists longer than the LDS capacity (degenerate inputs: e.g. a tiny
 // image with a huge cloud).  Same network, in place on seg_keys, one 1024-thread block per tile.
 __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2* __restrict__ ranges,
-                                                                    const uint32_t* __restrict__ depthkey,
                                                                     u64* __restrict__ seg_keys,
                                                                     uint32_t* __restrict__ point_list,
                                                                     uint8_t* __restrict__ slot_written, uint32_t lo,
@@ -390,11 +390,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || rg.y > capacity) return;
     for (uint32_t i = threadIdx.x; i < n; i += 1024) slot_written[rg.x + i] = 0;
-    u64* k = seg_keys + rg.x;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t id = point_list[rg.x + i];
-        k[i] = ((u64)depthkey[id] << 32) | id;
-    }
+    u64* k = seg_keys + rg.x;  // the scatter's keys, sorted in place
     __syncthreads();
     gsr_bitonic(k, n, 1024);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[rg.x + i] = (uint32_t)k[i];
@@ -445,8 +441,8 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.tmask, image.table, geom.scan_sums, image.ranges, geom.offsets, bin.point_list,
-                       (uint32_t)capacity);
+                       geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
+                       bin.seg_keys, (uint32_t)capacity);
     return hipGetLastError();
 }
 
@@ -471,13 +467,13 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const G
             }
             const uint32_t longest = min(cap, (uint32_t)max_tile_count);
             const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
-            hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, geom.depthkey,
+            hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys,
                                bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity);
         }
         lo = cap;
     }
     if (max_tile_count > GSR_SORT_CAP_LARGE)
-        hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, geom.depthkey, bin.seg_keys,
+        hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, bin.seg_keys,
                            bin.point_list, bin.slot_written, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
     return hipGetLastError();
 }

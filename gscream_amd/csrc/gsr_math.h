@@ -243,12 +243,13 @@ __device__ __forceinline__ void gsr_wave_dense(const uint32_t cnt, volatile uint
 
 // Wave-dense version of gsr_for_each_tile.  Every lane passes the rectangle and survivor mask of ITS Gaussian (a zero
 // rectangle for none); the wave then enumerates all (Gaussian, surviving tile) instances of its 64 Gaussians 64 at a
-// time, one instance per lane, and calls f(owner_lane, x, y) with all lanes (but the last round's tail) active.
+// time, one instance per lane, and calls f(owner_lane, x, y, owner's payload) with all lanes (but the last round's tail) active.
 // The per-Gaussian walk has as many rounds as the LARGEST footprint in the wave (~18 for a mean of 2.7), and every
 // round costs one LDS atomic instruction whose latency does not depend on the number of active lanes; the dense form
 // needs total/64 rounds.  Must be called by all 64 lanes (no divergence around the call).
 template <typename F>
 __device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const unsigned long long mask,
+                                                           const uint32_t payload /* handed to f as the owner's value */,
                                                            volatile uint32_t* heads /* LDS, 64 words private to the wave */, F f)
 {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -270,6 +271,7 @@ __device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const
         const uint32_t oincl = __shfl(incl, lo, 64), ocnt = __shfl(cnt, lo, 64);
         const uint32_t orx = __shfl(rc.x, lo, 64), ory = __shfl(rc.y, lo, 64);
         const uint32_t omlo = __shfl((uint32_t)m, lo, 64), omhi = __shfl((uint32_t)(m >> 32), lo, 64);
+        const uint32_t opay = __shfl(payload, lo, 64);  // cross-lane reads stay outside the divergent part below
         if (i < total) {
             const uint32_t r = i - (oincl - ocnt);
             const unsigned long long om = ((unsigned long long)omhi << 32) | omlo;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const
             int col = (int)pos - row * ow;
             if (col < 0) { row--; col += ow; }
             if (col >= ow) { row++; col -= ow; }
-            f(lo, ox0 + col, oy0 + row);
+            f(lo, ox0 + col, oy0 + row, opay);
         }
     }
 }
