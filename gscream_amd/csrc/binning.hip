@@ -131,30 +131,39 @@ __global__ void __launch_bounds__(256) gsr_table_colscan_kernel(int T, int nchun
     }
 }
 
-// Single block: exclusive scan of the tile totals -> ranges[t] = [start, end); info = {R, max count}.
-__global__ void __launch_bounds__(256) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
-                                                            uint2* __restrict__ ranges, uint32_t* __restrict__ info)
+// Single block of 1024: exclusive scan of the tile totals -> ranges[t] = [start, end); info = {R, max count}.
+// Thread i owns ceil(T/1024) consecutive tiles; one DPP wave scan + 16 wave totals in LDS.
+__global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
+                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ info)
 {
-    __shared__ uint32_t lds[8];
-    __shared__ uint32_t smax[4];
-    uint32_t carry = 0, mx = 0;
-    for (int base = 0; base < T; base += 256) {
-        const int t = base + threadIdx.x;
-        const uint32_t v = t < T ? tile_count[t] : 0u;
+    __shared__ uint32_t wsum[16], wmax[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (T + 1023) / 1024, t0 = threadIdx.x * per;
+    uint32_t sum = 0, mx = 0;
+    for (int i = 0; i < per; i++) {
+        const uint32_t v = t0 + i < T ? tile_count[t0 + i] : 0u;
+        sum += v;
         mx = max(mx, v);
-        uint32_t total;
-        const uint32_t ex = gsr_block_exclusive_scan_256(v, &total, lds);
-        if (t < T) ranges[t] = make_uint2(carry + ex, carry + ex + v);
-        carry += total;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+    const uint32_t incl = gsr_wave_scan_add(sum);
+    mx = gsr_wave_scan_max(mx);
+    if (lane == 63) { wsum[wave] = incl; wmax[wave] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        info[0] = carry;
-        info[1] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    uint32_t run = incl - sum, total = 0, gmax = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t sw = wsum[w];
+        run += w < wave ? sw : 0u;
+        total += sw;
+        gmax = max(gmax, wmax[w]);
     }
+    for (int i = 0; i < per; i++) {
+        if (t0 + i >= T) break;
+        const uint32_t v = tile_count[t0 + i];
+        ranges[t0 + i] = make_uint2(run, run + v);
+        run += v;
+    }
+    if (threadIdx.x == 0) { info[0] = total; info[1] = gmax; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,7 +437,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
     // (2) column scan -> per-(chunk, tile) offsets + tile totals, then tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
                        image.tile_count);
-    hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(256), 0, stream, T, image.tile_count, image.ranges,
+    hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
                        image.info);
     return hipGetLastError();
 }
