@@ -157,13 +157,18 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const int n = rg.y > capacity ? 0 : (int)(rg.y - rg.x);
     const bool inside = px < W && py < H;
 
-    bool done = !inside;
+    // Pixel state that is only ever tested wave-wide lives in wave-uniform 64-bit lane masks (SGPR pairs): `donem` =
+    // pixels that are finished.  Compares feed the masks directly (v_cmp writes an SGPR pair), the logic between them is
+    // scalar, and __builtin_amdgcn_inverse_ballot_w64 turns a mask back into a lane predicate for v_cndmask -- the
+    // compiler's own lowering of a loop-carried `bool done` + ballot re-materialises it in a VGPR every iteration.
+    const unsigned long long full = __builtin_amdgcn_ballot_w64(true);
+    unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Uf = 0.f;
     uint32_t last = 0;
     uint16_t* mylist = sList[wave];
 
     for (int base = 0; base < n; base += GSR_BATCH) {
-        if (__syncthreads_and(done)) break;  // also fences the previous batch's LDS reads
+        if (__syncthreads_and(donem == full)) break;  // also fences the previous batch's LDS reads
         const int cnt = min(GSR_BATCH, n - base);
         if (t < cnt) {
             const float4* r = reinterpret_cast<const float4*>(rec + point_list[rg.x + base + t]);
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
         __builtin_amdgcn_wave_barrier();
 
         for (int c0 = 0; c0 < nw; c0 += 64) {
-            if (GSR_ALL(done)) break;  // wave-uniform
+            if (donem == full) break;  // wave-uniform
             const int m = min(64, nw - c0);
 #if GSR_PREFETCH
             const int jj = mylist[min(c0 + lane, nw - 1)];
@@ -184,7 +189,7 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
             float4 A = sA[j], B = sB[j];
 #endif
             for (int k = 0; k < m; k++) {
-                if (GSR_ALL(done)) break;  // wave-uniform
+                if (donem == full) break;  // wave-uniform
 #if GSR_PREFETCH
                 const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
                 const float4 An = sA[jn], Bn = sB[jn];
@@ -195,12 +200,13 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the Gaussian falloff
                 const float alpha = fminf(0.99f, B.y * GSR_EXP2(power));
-                bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                if (GSR_ANY(ok)) {  // wave-uniform
+                const unsigned long long okm = __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                               __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f)) & ~donem;
+                if (okm != 0ull) {  // wave-uniform
                     const float test_T = Tr * (1.0f - alpha);
-                    const bool stop = ok && test_T < 0.0001f;
-                    done = done || stop;
-                    ok = ok && !stop;
+                    const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
+                    donem |= stopm;
+                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm & ~stopm);
                     const float w = ok ? alpha * Tr : 0.0f;
                     const float4 C = sC[j];
                     C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
