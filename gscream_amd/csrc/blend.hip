@@ -352,8 +352,11 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                     const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the falloff
                     const float G = GSR_EXP2(power);
                     const float alpha = fminf(0.99f, B.y * G);
-                    const bool ok = p < lastc && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                    if (GSR_ANY(ok)) {  // wave-uniform: some pixel of this quadrant blends the instance
+                    // lane masks straight from the compares, combined on the scalar unit (see the forward)
+                    const unsigned long long okm = __builtin_amdgcn_ballot_w64(p < lastc) & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                                   __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f));
+                    if (okm != 0ull) {  // wave-uniform: some pixel of this quadrant blends the instance
+                        const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
                         // per-lane partials: s0-2 colour, s3 depth, s4 feature, s5.. moments of g = G * dL/dalpha:
                         // sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The per-Gaussian factors
                         // (conic, opacity, -1/2, viewport scale) are applied once per instance at flush time.
