@@ -360,32 +360,34 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                         // per-lane partials: s0-2 colour, s3 depth, s4 feature, s5.. moments of g = G * dL/dalpha:
                         // sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The per-Gaussian factors
                         // (conic, opacity, -1/2, viewport scale) are applied once per instance at flush time.
-                        float s[11];
-#pragma unroll
-                        for (int v = 0; v < 11; v++) s[v] = 0.f;
+                        // Only the two per-lane weights are zero-initialised for the lanes that do not blend; the
+                        // 9 (11) products below then run unpredicated (a VALU instruction costs the same whatever its
+                        // EXEC mask, and nine v_mov 0 per instance are saved).
+                        float w = 0.f, g = 0.f;
                         const float4 C = sC[j];
                         if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
                             const float rinv = GSR_RCP(1.0f - alpha);
                             const float Tn = Tr * rinv;  // T / (1 - alpha)
-                            const float w = alpha * Tn;
+                            w = alpha * Tn;
                             const float oml = 1.0f - la;
                             ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
                             float dL_dalpha = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
                             if (AUX) {
                                 ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
                                 dL_dalpha += (B.z - ard) * gd + (B.w - aru) * gu;
-                                s[3] = w * gd; s[4] = w * gu;
                                 lcd = B.z; lcu = B.w;
                             }
                             dL_dalpha *= Tn;
                             dL_dalpha += (-Tf * rinv) * bgdot;
-                            const float g = G * dL_dalpha;
-                            const float gdx = g * dx, gdy = g * dy;
-                            s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
-                            s[5] = gdx; s[6] = gdy; s[7] = gdx * dx; s[8] = gdx * dy; s[9] = gdy * dy; s[10] = g;
+                            g = G * dL_dalpha;
                             Tr = Tn; la = alpha;
                             lc0 = C.x; lc1 = C.y; lc2 = C.z;
                         }
+                        float s[11];
+                        const float gdx = g * dx, gdy = g * dy;
+                        s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
+                        s[3] = AUX ? w * gd : 0.f; s[4] = AUX ? w * gu : 0.f;
+                        s[5] = gdx; s[6] = gdy; s[7] = gdx * dx; s[8] = gdx * dy; s[9] = gdy * dy; s[10] = g;
                         // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly: the xor-1 and xor-2 steps
                         // merge registers pairwise (lane l of a quad ends up owning value l & 3 of each group of
                         // four), two row_ror steps sum the four quads of a DPP row, two lane-aligned cross-row adds
@@ -409,11 +411,23 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                             q2 = r4 + gsr_dpp<0x4E>(r4);
                         }
                         q0 += gsr_dpp<0x124>(q0); q1 += gsr_dpp<0x124>(q1); q2 += gsr_dpp<0x124>(q2);  // row_ror:4
-                        q0 += gsr_dpp<0x128>(q0); q1 += gsr_dpp<0x128>(q1); q2 += gsr_dpp<0x128>(q2);  // row_ror:8
-                        const int li = lane & 15;
-                        float x = li < 4 ? q0 : (li < 8 ? q1 : q2);
-                        x += __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-                        x += __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+                        // row_ror:8 finishes the row sums.  Lanes l and l+8 are partners in it, so the register a lane
+                        // will report is chosen BEFORE the step wherever both partners choose alike (bit 2: q0 / q1):
+                        // select + add + add + select instead of three adds and a three-way select.
+                        const float y0 = (lane & 4) ? q1 : q0;
+                        const float y = y0 + gsr_dpp<0x128>(y0);
+                        const float z = q2 + gsr_dpp<0x128>(q2);
+                        float x = (lane & 8) ? z : y;  // row lanes 0-3: q0's values, 4-7: q1's, 8-11: q2's
+                        // swap(x, x) leaves {lower half twice, upper half twice}: the sum of BOTH results is the
+                        // cross-half sum in every lane, and x itself is dead afterwards (one register copy, not two)
+                        {
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                            x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                        }
+                        {
+                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                            x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                        }
                         // lane -> accumulator field: AUX: identity (0..10); else {0,1,2,5,6,7,8,9,10}
                         if (lane < (AUX ? 11 : 9)) atomicAdd(acc + j * GSR_SLOT_FLOATS + (AUX || lane < 3 ? lane : lane + 2), x);
                     }
