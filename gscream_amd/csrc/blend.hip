@@ -183,20 +183,14 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
         for (int c0 = 0; c0 < nw; c0 += 64) {
             if (donem == full) break;  // wave-uniform
             const int m = min(64, nw - c0);
-#if GSR_PREFETCH
+            // software pipeline, unrolled by two so that the operand registers of instance k+1 become "current" by
+            // renaming instead of by copies: body(cur, next) / body(next, cur)
             const int jj = mylist[min(c0 + lane, nw - 1)];
-            int j = __builtin_amdgcn_readlane(jj, 0);
-            float4 A = sA[j], B = sB[j];
-#endif
-            for (int k = 0; k < m; k++) {
-                if (donem == full) break;  // wave-uniform
-#if GSR_PREFETCH
-                const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
-                const float4 An = sA[jn], Bn = sB[jn];
-#else
-                const int j = mylist[c0 + k];
-                const float4 A = sA[j], B = sB[j];
-#endif
+            int j0 = __builtin_amdgcn_readlane(jj, 0), j1;
+            float4 A0 = sA[j0], B0 = sB[j0], A1, B1;
+            auto body = [&](const int k, const int j, const float4& A, const float4& B, int& jn, float4& An, float4& Bn) {
+                jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
+                An = sA[jn]; Bn = sB[jn];
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the Gaussian falloff
                 const float alpha = fminf(0.99f, B.y * GSR_EXP2(power));
@@ -214,9 +208,12 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
                     Tr = ok ? test_T : Tr;
                     last = ok ? (uint32_t)(base + j + 1) : last;
                 }
-#if GSR_PREFETCH
-                j = jn; A = An; B = Bn;
-#endif
+            };
+            for (int k = 0; k < m; k += 2) {
+                if (donem == full) break;  // wave-uniform
+                body(k, j0, A0, B0, j1, A1, B1);
+                if (k + 1 >= m || donem == full) break;
+                body(k + 1, j1, A1, B1, j0, A0, B0);
             }
         }
     }
