@@ -15,6 +15,7 @@ EXPORTED_SYMBOLS = (
     "gsr_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
     "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
+    "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
 )
 NUM_STAGES = 7
 
@@ -82,6 +83,12 @@ def load():
     lib.gsr_profile_end.argtypes = [ctypes.POINTER(Profile)]
     lib.gsr_stage_name.restype = ctypes.c_char_p
     lib.gsr_stage_name.argtypes = [_c_int]
+    lib.gsr_loss_workspace_bytes.restype = ctypes.c_size_t
+    lib.gsr_loss_workspace_bytes.argtypes = [_c_int] * 3
+    lib.gsr_rgb_loss_forward.restype = _c_int
+    lib.gsr_rgb_loss_forward.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _vp, _vp, _c_int, _vp]
+    lib.gsr_rgb_loss_backward.restype = _c_int
+    lib.gsr_rgb_loss_backward.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
 

@@ -374,3 +374,37 @@ extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewma
     GSR_HIP(gsr_launch_mark_visible(P, means3D, viewmatrix, present, stream), "mark_visible");
     return GSR_OK;
 }
+
+// ---- image-space RGB loss (loss.hip) ----
+extern "C" size_t gsr_loss_workspace_bytes(int C, int H, int W) { return gsl_workspace_bytes(C, H, W); }
+
+static int gsr_check_loss_args(int C, int H, int W, const float* img, const float* gt, const void* workspace)
+{
+    if (C < 1 || H < 1 || W < 1) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: C, H, W must be >= 1 (got %d, %d, %d)", C, H, W);
+    if ((long long)C * H * W > 0x7fffffffLL) return gsr_fail(GSR_ERR_UNSUPPORTED, "loss: image too large");
+    if (!img || !gt || !workspace) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: a required pointer is NULL");
+    return GSR_OK;
+}
+
+extern "C" int gsr_rgb_loss_forward(int C, int H, int W, const float* img, const float* gt, const float* weight,
+                                    float a_l1, float a_ssim, void* workspace, float* out3, int keep_state, void* stream)
+{
+    int rc = gsr_check_loss_args(C, H, W, img, gt, workspace);
+    if (rc) return rc;
+    if (!out3) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: out3 is NULL");
+    GSR_HIP(gsl_launch_forward(C, H, W, img, gt, weight, a_l1, a_ssim, workspace, out3, keep_state, (hipStream_t)stream),
+            "rgb loss forward");
+    return GSR_OK;
+}
+
+extern "C" int gsr_rgb_loss_backward(int C, int H, int W, const float* img, const float* gt, const float* weight,
+                                     float a_l1, float a_ssim, const void* workspace, const float* upstream,
+                                     float* dL_dimg, void* stream)
+{
+    int rc = gsr_check_loss_args(C, H, W, img, gt, workspace);
+    if (rc) return rc;
+    if (!dL_dimg) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: dL_dimg is NULL");
+    GSR_HIP(gsl_launch_backward(C, H, W, img, gt, weight, a_l1, a_ssim, workspace, upstream, dL_dimg, (hipStream_t)stream),
+            "rgb loss backward");
+    return GSR_OK;
+}

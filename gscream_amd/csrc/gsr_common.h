@@ -176,3 +176,11 @@ hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, con
                                      uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream);
+
+// ---- loss.hip ----
+size_t gsl_workspace_bytes(int C, int H, int W);
+hipError_t gsl_launch_forward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                              float a_ssim, void* workspace, float* out, int keep_state, hipStream_t stream);
+hipError_t gsl_launch_backward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                               float a_ssim, const void* workspace, const float* upstream, float* dL_dimg,
+                               hipStream_t stream);

@@ -1,0 +1,117 @@
+"""Image-space RGB losses on the HIP path -- SURVEY 8(f) rank 2, the step right after the rasterizer.
+
+Mirrors the names and call signatures GScream's trainer imports from ``utils/loss_utils.py``:
+
+    l1_loss(network_output, gt)                    loss_utils.py:26-27
+    l1_loss_masked(network_output, gt, mask)       loss_utils.py:29-30
+    ssim(img1, img2, window_size=11, size_average=True)                 loss_utils.py:131-160
+    ssim_masked(img1, img2, mask, window_size=11, size_average=True)    loss_utils.py:165-190
+
+and adds ``rgb_loss`` = the composition train.py:538-545 builds from them, in ONE forward and ONE backward kernel:
+
+    rgb_loss(image, gt, weight=None, lambda_dssim=0.2, scale=1.0)
+        = scale * ((1 - lambda) * mean(|image - gt| * weight) + lambda * (1 - mean(ssim_map * weight)))
+
+All of them run `gsr_rgb_loss_forward/backward` (include/gsraster.h) through ctypes; gradients flow to the first
+image argument only (the ground truth is a constant in the trainer).  There is no CPU fallback: tensors must live on
+a HIP device.  Differences from the reference: the 11x11 window is applied separably (two 11-tap passes) instead of
+as one 121-tap depthwise conv2d, so values agree to fp32 rounding (~1e-6), not bit for bit.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+
+__all__ = ["l1_loss", "l1_loss_masked", "ssim", "ssim_masked", "rgb_loss"]
+
+
+def _prep(img, gt, weight):
+    if not img.is_cuda:
+        raise RuntimeError("gscream_amd.loss_utils: tensors must be on a HIP device (there is no CPU fallback)")
+    if img.shape != gt.shape:
+        raise ValueError(f"image {tuple(img.shape)} and ground truth {tuple(gt.shape)} differ in shape")
+    if img.dim() == 4 and img.shape[0] == 1:
+        img, gt = img[0], gt[0]
+    if img.dim() != 3:
+        raise ValueError("expected a [C,H,W] (or [1,C,H,W]) image")
+    C, H, W = img.shape
+    x = img.contiguous().float()
+    y = gt.detach().contiguous().float()
+    w = None
+    if weight is not None:
+        w = weight.detach().float()
+        if w.numel() != H * W:
+            raise ValueError(f"weight must broadcast as [1,H,W]; got {tuple(weight.shape)} for a {H}x{W} image")
+        w = w.reshape(H, W).contiguous()
+    return x, y, w, C, H, W
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _FusedLoss(torch.autograd.Function):
+    """L = a_l1 * mean(|img - gt| * m) + a_ssim * mean(ssim_map(img, gt) * m)."""
+
+    @staticmethod
+    def forward(ctx, img, gt, weight, a_l1, a_ssim):
+        lib = _native.load()
+        x, y, w, C, H, W = _prep(img, gt, weight)
+        need_grad = img.requires_grad
+        with torch.cuda.device(x.device):
+            ws = torch.empty((lib.gsr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=x.device)
+            out = torch.empty((3,), dtype=torch.float32, device=x.device)
+            _native.check(lib.gsr_rgb_loss_forward(C, H, W, _native.ptr(x), _native.ptr(y), _native.ptr(w), float(a_l1),
+                                                   float(a_ssim), _native.ptr(ws), _native.ptr(out), int(need_grad),
+                                                   _stream()), "gsr_rgb_loss_forward")
+        ctx.save_for_backward(x, y, w if w is not None else torch.empty(0, device=x.device), ws)
+        ctx.coef = (float(a_l1), float(a_ssim))
+        ctx.in_shape = tuple(img.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        lib = _native.load()
+        x, y, w, ws = ctx.saved_tensors
+        C, H, W = x.shape
+        up = g_loss.detach().reshape(1).float().contiguous()
+        with torch.cuda.device(x.device):
+            grad = torch.empty_like(x)
+            _native.check(lib.gsr_rgb_loss_backward(C, H, W, _native.ptr(x), _native.ptr(y), _native.ptr(w), ctx.coef[0],
+                                                    ctx.coef[1], _native.ptr(ws), _native.ptr(up), _native.ptr(grad),
+                                                    _stream()), "gsr_rgb_loss_backward")
+        return grad.reshape(ctx.in_shape), None, None, None, None
+
+
+def _check_window(window_size, size_average):
+    if window_size != 11:
+        raise NotImplementedError("only window_size=11 (what GScream uses everywhere) is implemented")
+    if not size_average:
+        raise NotImplementedError("size_average=False is never used by GScream's trainer and is not implemented")
+
+
+def l1_loss(network_output, gt):
+    return _FusedLoss.apply(network_output, gt, None, 1.0, 0.0)[0]
+
+
+def l1_loss_masked(network_output, gt, mask):
+    return _FusedLoss.apply(network_output, gt, mask, 1.0, 0.0)[0]
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    _check_window(window_size, size_average)
+    return _FusedLoss.apply(img1, img2, None, 0.0, 1.0)[0]
+
+
+def ssim_masked(img1, img2, mask, window_size=11, size_average=True):
+    _check_window(window_size, size_average)
+    return _FusedLoss.apply(img1, img2, mask, 0.0, 1.0)[0]
+
+
+def rgb_loss(image, gt, weight=None, lambda_dssim=0.2, scale=1.0, return_parts=False):
+    """train.py:538-545 in one pass.  return_parts -> (loss, L1 term, SSIM term) (the last two detached)."""
+    loss, parts = _FusedLoss.apply(image, gt, weight, scale * (1.0 - lambda_dssim), -scale * lambda_dssim)
+    loss = loss + scale * lambda_dssim
+    return (loss, parts[1], parts[2]) if return_parts else loss

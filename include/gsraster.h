@@ -176,6 +176,22 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
                      uint8_t* present, void* stream);
 
 /*
+ * ---- the image-space RGB loss that follows the rasterizer ----------------------------------
+ * Fused weighted L1 + weighted SSIM (11x11 Gaussian window, sigma 1.5, zero padding), value and gradient:
+ *     L = a_l1 * mean(|img - gt| * m) + a_ssim * mean(ssim_map(img, gt) * m),   m = weight[H,W] (1 when NULL),
+ * means over C*H*W.  Replaces GScream's utils/loss_utils.py:26-30 (l1_loss, l1_loss_masked) and :131-190 (ssim,
+ * ssim_masked: five depthwise conv2d + ~10 elementwise passes each) as composed in train.py:538-545
+ * (a_l1 = w (1 - lambda), a_ssim = -w lambda, the constant w lambda is added by the caller).
+ * img, gt: [C,H,W] fp32 contiguous.  out3 (device): {L, mean(|d| m), mean(ssim m)}.  keep_state = 1 also stores what
+ * the backward needs in the workspace (gsr_loss_workspace_bytes).  upstream: device pointer to dL/dL (NULL = 1).
+ */
+size_t gsr_loss_workspace_bytes(int C, int H, int W);
+int gsr_rgb_loss_forward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                         float a_ssim, void* workspace, float* out3, int keep_state, void* stream);
+int gsr_rgb_loss_backward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                          float a_ssim, const void* workspace, const float* upstream, float* dL_dimg, void* stream);
+
+/*
  * Optional per-stage timing (bench.py's roofline numbers; the reference has no counterpart -- its only
  * timing is two CUDA events around a whole training iteration, train.py:343-344,406,578).
  * Between gsr_profile_begin() and gsr_profile_end() every stage of every call is bracketed by a pair

@@ -1,0 +1,47 @@
+"""Generates tests/golden/loss_*.npz from the CPU oracle (oracle/loss_oracle.py, float64).
+
+    python tests/golden/make_loss_golden.py
+
+The reference module (utils/loss_utils.py) cannot be imported in this image (it imports kornia), so these vectors
+come from the restatement -- "parity unpinned", see the oracle's header."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import loss_oracle as LO  # noqa: E402
+
+
+def cases():
+    return {
+        "loss_plain": dict(seed=1, C=3, H=40, W=56, weight=False, lam=0.2, scale=1.0),
+        "loss_masked": dict(seed=2, C=3, H=37, W=61, weight=True, lam=0.2, scale=1.0),       # odd sizes, weight map
+        "loss_mono": dict(seed=3, C=1, H=16, W=33, weight=True, lam=0.5, scale=0.7),          # one channel, tile edge
+        "loss_tiny": dict(seed=4, C=3, H=5, W=7, weight=False, lam=0.2, scale=1.0),           # smaller than the window
+    }
+
+
+def make_inputs(c):
+    rng = np.random.default_rng(c["seed"])
+    gt = rng.random((c["C"], c["H"], c["W"])).astype(np.float32)
+    # a rendering close to the ground truth, as in training (SSIM well away from 0)
+    img = np.clip(gt + 0.15 * rng.standard_normal(gt.shape), 0.0, 1.0).astype(np.float32)
+    w = None
+    if c["weight"]:
+        w = (rng.random((1, c["H"], c["W"])) > 0.4).astype(np.float32) * np.float32(0.75) + np.float32(0.25)
+    return img, gt, w
+
+
+def main():
+    for name, c in cases().items():
+        img, gt, w = make_inputs(c)
+        loss, l1, ss, grad = LO.value_and_grad(img, gt, w, c["lam"], c["scale"])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), loss=np.float64(loss), l1=np.float64(l1), ssim=np.float64(ss),
+                            grad=grad.astype(np.float64))
+        print(name, loss, l1, ss, grad.shape)
+
+
+if __name__ == "__main__":
+    main()

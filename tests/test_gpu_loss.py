@@ -1,0 +1,99 @@
+"""GPU parity tests of the fused RGB loss (gscream_amd.loss_utils -> ctypes -> gsr_rgb_loss_*) against the CPU
+oracle (float64 restatement of GScream's utils/loss_utils.py) and the committed fixtures.
+
+Tolerances (floating point; fp32 kernel vs fp64 oracle): loss / terms 2e-6 abs; gradient 1e-4 of its largest entry
+(the separable window reorders the 121-term sums; measured differences are ~1e-6)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from golden import make_loss_golden as MLG  # noqa: E402
+from oracle import loss_oracle as LO  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(img, gt, w, lam, scale):
+    from gscream_amd import loss_utils as L
+    x = torch.from_numpy(img).cuda().requires_grad_(True)
+    y = torch.from_numpy(gt).cuda()
+    m = None if w is None else torch.from_numpy(w).cuda()
+    loss, l1, ss = L.rgb_loss(x, y, m, lam, scale, return_parts=True)
+    loss.backward()
+    return float(loss.detach()), float(l1), float(ss), x.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", sorted(MLG.cases().keys()))
+def test_golden(name):
+    c = MLG.cases()[name]
+    img, gt, w = MLG.make_inputs(c)
+    exp = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    loss, l1, ss, grad = _run(img, gt, w, c["lam"], c["scale"])
+    assert abs(loss - float(exp["loss"])) < 2e-6 and abs(l1 - float(exp["l1"])) < 2e-6 and abs(ss - float(exp["ssim"])) < 2e-6
+    assert np.abs(grad - exp["grad"]).max() <= 1e-4 * np.abs(exp["grad"]).max()
+
+
+@pytest.mark.parametrize("C,H,W,weighted", [(3, 71, 112, False), (3, 142, 252, True), (1, 33, 65, True), (3, 16, 32, False)])
+def test_against_live_oracle(C, H, W, weighted):
+    rng = np.random.default_rng(C * 1000 + H)
+    gt = rng.random((C, H, W)).astype(np.float32)
+    img = np.clip(gt + 0.2 * rng.standard_normal(gt.shape), 0, 1).astype(np.float32)
+    w = rng.random((1, H, W)).astype(np.float32) if weighted else None
+    ref = LO.value_and_grad(img, gt, w, 0.2, 1.0)
+    got = _run(img, gt, w, 0.2, 1.0)
+    for a, b in zip(got[:3], ref[:3]):
+        assert abs(a - b) < 2e-6
+    assert np.abs(got[3] - ref[3]).max() <= 1e-4 * np.abs(ref[3]).max()
+
+
+def test_mirrored_functions_and_upstream_gradient():
+    """The four names the trainer imports, with a non-unit upstream gradient (train.py:538-545 mixes them)."""
+    from gscream_amd import loss_utils as L
+    rng = np.random.default_rng(5)
+    gt = rng.random((3, 48, 80)).astype(np.float32)
+    img = np.clip(gt + 0.1 * rng.standard_normal(gt.shape), 0, 1).astype(np.float32)
+    mask = (rng.random((1, 48, 80)) > 0.5).astype(np.float32)
+    x = torch.from_numpy(img).cuda().requires_grad_(True)
+    y, m = torch.from_numpy(gt).cuda(), torch.from_numpy(mask).cuda()
+    total = 0.8 * L.l1_loss(x, y) + 0.2 * (1.0 - L.ssim(x, y)) + 0.5 * (0.8 * L.l1_loss_masked(x, y, m) + 0.2 * (1.0 - L.ssim_masked(x, y, m)))
+    total.backward()
+    xr = torch.from_numpy(img).double().requires_grad_(True)
+    yr, mr = torch.from_numpy(gt).double(), torch.from_numpy(mask).double()
+    ref = 0.8 * LO.l1_loss(xr, yr) + 0.2 * (1.0 - LO.ssim(xr, yr)) + 0.5 * (0.8 * LO.l1_loss_masked(xr, yr, mr) + 0.2 * (1.0 - LO.ssim_masked(xr, yr, mr)))
+    ref.backward()
+    assert abs(float(total) - float(ref)) < 3e-6
+    assert (x.grad.cpu().double() - xr.grad).abs().max() <= 1e-4 * xr.grad.abs().max()
+    with pytest.raises(NotImplementedError):
+        L.ssim(x, y, window_size=7)
+    with pytest.raises(RuntimeError):
+        L.ssim(x.detach().cpu(), y.cpu())
+
+
+def test_full_size_properties_and_reproducibility():
+    """BASELINE's image size (3 x 567 x 1008): identities that need no oracle, and bit-reproducibility."""
+    from gscream_amd import loss_utils as L
+    g = torch.Generator(device="cuda").manual_seed(0)
+    y = torch.rand((3, 567, 1008), device="cuda", generator=g)
+    assert abs(float(L.ssim(y, y)) - 1.0) < 1e-5 and float(L.l1_loss(y, y)) == 0.0
+    x = (y + 0.1 * torch.randn(y.shape, device="cuda", generator=g)).clamp(0, 1).requires_grad_(True)
+    a = L.rgb_loss(x, y)
+    a.backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    b = L.rgb_loss(x, y)
+    b.backward()
+    assert float(a) == float(b) and torch.equal(g1, x.grad), "fixed-order reductions: bit-reproducible"
+    assert abs(float(L.ssim(x, y)) - float(L.ssim(y, x.detach()))) < 1e-6  # symmetric
+    # directional derivative check at full size: L(x + eps d) - L(x - eps d) ~= 2 eps <grad, d>
+    d = torch.sign(g1)  # steepest-ascent direction: the derivative along it is sum |grad|, far above fp32 noise
+    eps = 1e-3
+    with torch.no_grad():
+        fd = (float(L.rgb_loss(x + eps * d, y)) - float(L.rgb_loss(x - eps * d, y))) / (2 * eps)
+    an = float((g1 * d).sum())
+    assert an > 0 and abs(fd - an) < 5e-2 * an, (fd, an)

@@ -1,0 +1,58 @@
+"""CPU tests of the loss oracle (oracle/loss_oracle.py) and of the committed loss fixtures."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from golden import make_loss_golden as MLG  # noqa: E402
+from oracle import loss_oracle as LO  # noqa: E402
+
+
+def test_window_matches_the_published_constants():
+    g = LO.gaussian(11, 1.5)
+    assert abs(float(g.sum()) - 1.0) < 1e-6 and g.argmax() == 5 and torch.allclose(g, g.flip(0))
+    assert abs(float(g[5]) - 0.26601171) < 1e-7 and abs(float(g[0]) - 0.00102838) < 1e-8
+    # the 2-D window is the outer product, so it is separable -- the property the HIP kernel relies on
+    w = LO.create_window(11, 3, torch.float64)[0, 0]
+    assert torch.allclose(w, torch.outer(g.double(), g.double()), atol=1e-9)
+
+
+def test_identities():
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.random((3, 24, 31)))
+    assert abs(float(LO.ssim(x, x)) - 1.0) < 1e-9 and float(LO.l1_loss(x, x)) == 0.0
+    m = torch.from_numpy((rng.random((1, 24, 31)) > 0.5).astype(np.float64))
+    assert abs(float(LO.ssim_masked(x, x, m)) - float(m.mean())) < 1e-9
+    assert abs(float(LO.rgb_loss(x, x)) - 0.0) < 1e-9
+    y = torch.from_numpy(rng.random((3, 24, 31)))
+    assert abs(float(LO.ssim(x, y)) - float(LO.ssim(y, x))) < 1e-12  # symmetric in its arguments
+
+
+def test_gradient_against_finite_differences():
+    rng = np.random.default_rng(1)
+    x, y = rng.random((2, 9, 12)), rng.random((2, 9, 12))
+    w = rng.random((1, 9, 12))
+    _, _, _, g = LO.value_and_grad(x, y, w, 0.3, 1.7)
+    eps = 1e-6
+    for idx in [(0, 0, 0), (1, 4, 7), (0, 8, 11), (1, 3, 0)]:
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps
+        xm[idx] -= eps
+        fd = (LO.value_and_grad(xp, y, w, 0.3, 1.7)[0] - LO.value_and_grad(xm, y, w, 0.3, 1.7)[0]) / (2 * eps)
+        assert abs(fd - g[idx]) < 1e-6 * max(1.0, abs(fd)), (idx, fd, g[idx])
+
+
+def test_fixtures_reproduce():
+    for name, c in MLG.cases().items():
+        img, gt, w = MLG.make_inputs(c)
+        exp = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        loss, l1, ss, grad = LO.value_and_grad(img, gt, w, c["lam"], c["scale"])
+        assert abs(loss - float(exp["loss"])) < 1e-12 and abs(ss - float(exp["ssim"])) < 1e-12
+        assert np.allclose(grad, exp["grad"], rtol=0, atol=1e-14)
+        # fp32 evaluation of the same restatement stays within the GPU test's tolerance of the fp64 fixture
+        l32 = LO.value_and_grad(img, gt, w, c["lam"], c["scale"], dtype=torch.float32)[0]
+        assert abs(l32 - loss) < 2e-6
