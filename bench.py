@@ -101,6 +101,74 @@ def cpu_torch_naive():
             "sample": "config1: 2k Gaussians @128x128, forward only, oracle/naive_torch.py float32"}
 
 
+def loss_row(dev, H, W, steps, with_cpu):
+    """SURVEY 8(f) rank 2 (the step after the rasterizer): fused weighted L1 + SSIM loss, forward + backward at the
+    bench resolution.  Timed with HIP events on torch's current stream (the stream the kernels are launched on).
+    Algorithmic bytes per pixel-channel: forward 8 in + 12 out, backward 20 in + 4 out (+ the weight map)."""
+    from gscream_amd import loss_utils as L
+    g = torch.Generator(device=dev).manual_seed(7)
+    gt = torch.rand((3, H, W), device=dev, generator=g)
+    img = (gt + 0.1 * torch.randn(gt.shape, device=dev, generator=g)).clamp(0, 1).requires_grad_(True)
+    wmap = torch.rand((1, H, W), device=dev, generator=g)
+
+    def fused():
+        loss = L.rgb_loss(img, gt, wmap, 0.2, 1.0)
+        return torch.autograd.grad(loss, img)[0]
+
+    def eager():  # the reference's formulation (loss_utils.py:174-190 + :29-30) in eager torch on the same GPU
+        from oracle import loss_oracle as LO
+        loss = LO.rgb_loss(img, gt, wmap, 0.2, 1.0)
+        return torch.autograd.grad(loss, img)[0]
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def native():  # the C ABI alone (pre-allocated buffers, no autograd): what the GPU needs for forward + backward
+        _native.check(lib.gsr_rgb_loss_forward(3, H, W, _native.ptr(xd), _native.ptr(gt), _native.ptr(wd), 0.8, -0.2,
+                                               _native.ptr(ws), _native.ptr(out3), 1, stream), "loss forward")
+        _native.check(lib.gsr_rgb_loss_backward(3, H, W, _native.ptr(xd), _native.ptr(gt), _native.ptr(wd), 0.8, -0.2,
+                                                _native.ptr(ws), None, _native.ptr(gbuf), stream), "loss backward")
+
+    import ctypes
+    from gscream_amd import _native
+    lib = _native.load()
+    xd, wd = img.detach().contiguous(), wmap.reshape(H, W).contiguous()
+    ws = torch.empty((lib.gsr_loss_workspace_bytes(3, H, W),), dtype=torch.uint8, device=dev)
+    out3, gbuf = torch.empty(3, device=dev), torch.empty_like(xd)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = timed(fused, steps)
+    ms_native = timed(native, steps)
+    ms_eager = timed(eager, max(5, steps // 5))
+    nbytes = 3 * H * W * 44 + 2 * H * W * 4
+    row = {"what": f"fused weighted L1 + SSIM(11x11) loss, forward + backward, 3x{H}x{W} fp32 (gsr_rgb_loss_*)",
+           "ms_through_autograd_api": round(ms, 4), "ms": round(ms_native, 4), "iters_per_s": round(1e3 / ms_native, 1),
+           "algorithmic_bytes": nbytes,
+           "roofline": {"bound": "hbm", "achieved": round(nbytes / 1e9 / (ms_native / 1e3), 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(nbytes / 1e9 / (ms_native / 1e3) / HBM_PEAK_GBS, 4)},
+           "torch_eager_same_gpu_ms": round(ms_eager, 4), "speedup_vs_torch_eager": round(ms_eager / ms, 1)}
+    if with_cpu:
+        from oracle import loss_oracle as LO
+        x, y, w = img.detach().cpu().numpy(), gt.cpu().numpy(), wmap.cpu().numpy()
+        LO.value_and_grad(x, y, w, 0.2, 1.0, dtype=torch.float32)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 4.0:
+            LO.value_and_grad(x, y, w, 0.2, 1.0, dtype=torch.float32)
+            n += 1
+        dt = time.perf_counter() - t0
+        row["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/loss_oracle.py fp32 value+grad, same 3x{H}x{W} images, {n} iterations in {dt:.1f}s"}
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +294,11 @@ def main():
                                 "kernel_ms_sum": round(sum(v["avg_ms"] for v in stages.values()), 4)},
             "stages": stages,
         }
+        if world == 1:
+            try:  # the next 8(f) row, reported beside the north-star line; never allowed to break it
+                out["next_rows"] = {"rgb_loss": loss_row(dev, H, W, args.steps, not args.no_cpu_baseline)}
+            except Exception as e:  # noqa: BLE001
+                out["next_rows"] = {"rgb_loss": {"error": repr(e)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_torch_naive"] = cpu_torch_naive()

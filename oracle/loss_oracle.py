@@ -31,7 +31,7 @@ def create_window(window_size, channel, dtype):  # loss_utils.py:117-121
 
 def ssim_map(img1, img2, window_size=11):  # loss_utils.py:140-157
     C = img1.size(-3)
-    win = create_window(window_size, C, img1.dtype)
+    win = create_window(window_size, C, img1.dtype).to(img1.device)  # loss_utils.py:135-137
     pad = window_size // 2
     x, y = img1.reshape(1, C, *img1.shape[-2:]), img2.reshape(1, C, *img2.shape[-2:])
     mu1, mu2 = F.conv2d(x, win, padding=pad, groups=C), F.conv2d(y, win, padding=pad, groups=C)
