@@ -55,35 +55,67 @@ __global__ void __launch_bounds__(256) gsl_forward_kernel(int H, int W, const fl
     const size_t plane = (size_t)H * W;
     const float* ip = img + ch * plane;
     const float* gp = gt + ch * plane;
-    for (int i = t; i < GSL_HH * GSL_HW; i += 256) {
-        const int r = i / GSL_HW, c = i - r * GSL_HW;
-        sx[r][c] = gsl_load(ip, x0 - GSL_R + c, y0 - GSL_R + r, W, H);
-        sy[r][c] = gsl_load(gp, x0 - GSL_R + c, y0 - GSL_R + r, W, H);
+    {   // halo tile: all of a thread's loads are issued before the first LDS store (one memory round trip, not five)
+        constexpr int NL = (GSL_HH * GSL_HW + 255) / 256;
+        float vx[NL], vy[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = t + k * 256, r = i / GSL_HW, c = i - r * GSL_HW;
+            const bool in = i < GSL_HH * GSL_HW;
+            vx[k] = in ? gsl_load(ip, x0 - GSL_R + c, y0 - GSL_R + r, W, H) : 0.f;
+            vy[k] = in ? gsl_load(gp, x0 - GSL_R + c, y0 - GSL_R + r, W, H) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = t + k * 256, r = i / GSL_HW, c = i - r * GSL_HW;
+            if (i < GSL_HH * GSL_HW) { sx[r][c] = vx[k]; sy[r][c] = vy[k]; }
+        }
     }
     __syncthreads();
-    for (int i = t; i < GSL_HH * GSL_TW; i += 256) {  // horizontal pass
-        const int r = i / GSL_TW, c = i % GSL_TW;
-        float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    // horizontal pass: a thread produces four adjacent outputs of one row from a 14-value register window (28 LDS
+    // reads instead of 88)
+    if (t < GSL_HH * (GSL_TW / 4)) {
+        const int r = t / (GSL_TW / 4), c = (t % (GSL_TW / 4)) * 4;
+        float xs[14], ys[14];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float g = GSL_G[k], x = sx[r][c + k], y = sy[r][c + k];
-            const float gx = g * x, gy = g * y;
-            s1 += gx; s2 += gy; s11 += gx * x; s22 += gy * y; s12 += gx * y;
+        for (int k = 0; k < 14; k++) { xs[k] = sx[r][c + k]; ys[k] = sy[r][c + k]; }
+        float s1[4] = { 0, 0, 0, 0 }, s2[4] = { 0, 0, 0, 0 }, s11[4] = { 0, 0, 0, 0 }, s22[4] = { 0, 0, 0, 0 }, s12[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            const float x = xs[k], y = ys[k], xx = x * x, yy = y * y, xy = x * y;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int tap = k - o;
+                if (tap >= 0 && tap < 11) {
+                    const float g = GSL_G[tap];
+                    s1[o] += g * x; s2[o] += g * y; s11[o] += g * xx; s22[o] += g * yy; s12[o] += g * xy;
+                }
+            }
         }
-        hx[0][r][c] = s1; hx[1][r][c] = s2; hx[2][r][c] = s11; hx[3][r][c] = s22; hx[4][r][c] = s12;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            hx[0][r][c + o] = s1[o]; hx[1][r][c + o] = s2[o]; hx[2][r][c + o] = s11[o]; hx[3][r][c + o] = s22[o]; hx[4][r][c + o] = s12[o];
+        }
     }
     __syncthreads();
     double l1sum = 0.0, ssum = 0.0;
+    // vertical pass: a thread finishes two vertically adjacent pixels from a 12-row register window
+    const int vc = t % GSL_TW, vr = (t / GSL_TW) * 2;
+    float col[5][12];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {  // vertical pass, two pixels per thread
-        const int i = t + half * 256, r = i / GSL_TW, c = i % GSL_TW;
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) col[q][k] = hx[q][vr + k][vc];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int r = vr + half, c = vc;
         const int px = x0 + c, py = y0 + r;
         float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
             const float g = GSL_G[k];
-            mu1 += g * hx[0][r + k][c]; mu2 += g * hx[1][r + k][c];
-            e11 += g * hx[2][r + k][c]; e22 += g * hx[3][r + k][c]; e12 += g * hx[4][r + k][c];
+            mu1 += g * col[0][half + k]; mu2 += g * col[1][half + k];
+            e11 += g * col[2][half + k]; e22 += g * col[3][half + k]; e12 += g * col[4][half + k];
         }
         if (px < W && py < H) {
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // loss_utils.py:153-154
@@ -155,35 +187,60 @@ __global__ void __launch_bounds__(256) gsl_backward_kernel(int H, int W, const f
     const float* p0 = d_mu1 + ch * plane;
     const float* p1 = d_e11 + ch * plane;
     const float* p2 = d_e12 + ch * plane;
-    for (int i = t; i < GSL_HH * GSL_HW; i += 256) {
-        const int r = i / GSL_HW, c = i - r * GSL_HW;
-        const int x = x0 - GSL_R + c, y = y0 - GSL_R + r;
-        sm[0][r][c] = gsl_load(p0, x, y, W, H);
-        sm[1][r][c] = gsl_load(p1, x, y, W, H);
-        sm[2][r][c] = gsl_load(p2, x, y, W, H);
+    {   // halo tiles of the three derivative planes; loads first, LDS stores after (see the forward)
+        constexpr int NL = (GSL_HH * GSL_HW + 255) / 256;
+        float v0[NL], v1[NL], v2[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = t + k * 256, r = i / GSL_HW, c = i - r * GSL_HW;
+            const int x = x0 - GSL_R + c, y = y0 - GSL_R + r;
+            const bool in = i < GSL_HH * GSL_HW;
+            v0[k] = in ? gsl_load(p0, x, y, W, H) : 0.f;
+            v1[k] = in ? gsl_load(p1, x, y, W, H) : 0.f;
+            v2[k] = in ? gsl_load(p2, x, y, W, H) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = t + k * 256, r = i / GSL_HW, c = i - r * GSL_HW;
+            if (i < GSL_HH * GSL_HW) { sm[0][r][c] = v0[k]; sm[1][r][c] = v1[k]; sm[2][r][c] = v2[k]; }
+        }
     }
     __syncthreads();
-    for (int i = t; i < GSL_HH * GSL_TW; i += 256) {
-        const int r = i / GSL_TW, c = i % GSL_TW;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (t < GSL_HH * (GSL_TW / 4)) {  // horizontal pass, four adjacent outputs per thread (see the forward)
+        const int r = t / (GSL_TW / 4), c = (t % (GSL_TW / 4)) * 4;
+        float a[3][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float g = GSL_G[k];
-            s0 += g * sm[0][r][c + k]; s1 += g * sm[1][r][c + k]; s2 += g * sm[2][r][c + k];
+        for (int k = 0; k < 14; k++) {
+            const float v0 = sm[0][r][c + k], v1 = sm[1][r][c + k], v2 = sm[2][r][c + k];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int tap = k - o;
+                if (tap >= 0 && tap < 11) {
+                    const float g = GSL_G[tap];
+                    a[0][o] += g * v0; a[1][o] += g * v1; a[2][o] += g * v2;
+                }
+            }
         }
-        hx[0][r][c] = s0; hx[1][r][c] = s1; hx[2][r][c] = s2;
+#pragma unroll
+        for (int o = 0; o < 4; o++) { hx[0][r][c + o] = a[0][o]; hx[1][r][c + o] = a[1][o]; hx[2][r][c + o] = a[2][o]; }
     }
     __syncthreads();
     const float up = upstream ? upstream[0] : 1.0f;
+    const int vc = t % GSL_TW, vr = (t / GSL_TW) * 2;
+    float col[3][12];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) col[q][k] = hx[q][vr + k][vc];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        const int i = t + half * 256, r = i / GSL_TW, c = i % GSL_TW;
+        const int r = vr + half, c = vc;
         const int px = x0 + c, py = y0 + r;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
             const float g = GSL_G[k];
-            f0 += g * hx[0][r + k][c]; f1 += g * hx[1][r + k][c]; f2 += g * hx[2][r + k][c];
+            f0 += g * col[0][half + k]; f1 += g * col[1][half + k]; f2 += g * col[2][half + k];
         }
         if (px < W && py < H) {
             const size_t o = ch * plane + (size_t)py * W + px;
