@@ -36,7 +36,7 @@ def image_views(buf, P, W, H):
     out["ranges"] = _take(buf, off, T * 8, torch.int32, (T, 2)); off += _align(T * 8)
     out["final_T"] = _take(buf, off, N * 4, torch.float32, (H, W)); off += _align(N * 4)
     out["n_contrib"] = _take(buf, off, N * 4, torch.int32, (H, W)); off += _align(N * 4)
-    nb = num_chunks(P)
+    nb = num_chunks(P) if T <= 36864 else 1  # beyond the LDS tile limit only T cursor words (gsr_common.h)
     out["table"] = _take(buf, off, nb * T * 4, torch.int32, (nb, T)); off += _align(nb * T * 4)
     out["tile_count"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["tile_work"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)

@@ -142,8 +142,8 @@ static int gsr_check_dims(int P, int W, int H)
     if (W <= 0 || H <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "image size must be positive (got %dx%d)", W, H);
     const long gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
     if (gx > 65535 || gy > 65535) return gsr_fail(GSR_ERR_UNSUPPORTED, "image too large: %ldx%ld tiles", gx, gy);
-    if (gx * gy > GSR_MAX_TILES_LDS)
-        return gsr_fail(GSR_ERR_UNSUPPORTED, "%ld tiles exceed the LDS histogram capacity of %d", gx * gy, GSR_MAX_TILES_LDS);
+    // more than GSR_MAX_TILES_LDS tiles: supported through the global-counter binning fallback (binning.hip)
+    if (gx * gy > (1L << 24)) return gsr_fail(GSR_ERR_UNSUPPORTED, "image too large: %ld tiles", gx * gy);
     return GSR_OK;
 }
 
@@ -222,7 +222,7 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, stream),
+                                                            out_feature, capacity, max_tile_count, stream),
               "forward blend");
     return GSR_OK;
 }

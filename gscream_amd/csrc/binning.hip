@@ -52,17 +52,25 @@ __device__ __forceinline__ void gsr_chunk_bounds(int P, int nchunks, int chunk, 
     hi = min(P, lo + per);
 }
 
+// GLOBAL = true: image with more tiles than one LDS allocation holds (> GSR_MAX_TILES_LDS, ~3000x3000 px): the
+// counters are the global tile_count[] (zeroed by the launcher), one agent-scope atomic per instance -- slow but
+// unbounded; no table is produced and the column scan is skipped.
+template <bool GLOBAL>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, int T, int gx, int nchunks,
                                                                         const uint2* __restrict__ rect,
                                                                         const u64* __restrict__ tmask,
                                                                         uint32_t* __restrict__ table,
                                                                         uint32_t* __restrict__ chunk_sum)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist_lds[];
+    uint32_t* hist = GLOBAL ? table /* = tile_count[T] */ : hist_lds;
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
-    for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0;
-    __syncthreads();
+    if (!GLOBAL) {
+        for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0;
+        __syncthreads();
+    }
+    uint32_t mine = 0;
     int lo, hi;
     gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
     // four Gaussians per thread per trip, loads issued together (the kernel is latency-bound: 8 waves per CU)
@@ -79,12 +87,13 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
         }
 #pragma unroll
         for (int k = 0; k < U; k++)
-            gsr_wave_for_each_instance(rcs[k], mks[k], 0u, heads, [&](int, int x, int y, uint32_t) { atomicAdd(&hist[y * gx + x], 1u); });
+            gsr_wave_for_each_instance(rcs[k], mks[k], 0u, heads, [&](int, int x, int y, uint32_t) { atomicAdd(&hist[y * gx + x], 1u); if (GLOBAL) mine++; });
     }
     __syncthreads();
-    uint32_t* row = table + (size_t)blockIdx.x * T;
-    uint32_t mine = 0;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) { const uint32_t v = hist[t]; row[t] = v; mine += v; }
+    if (!GLOBAL) {
+        uint32_t* row = table + (size_t)blockIdx.x * T;
+        for (int t = threadIdx.x; t < T; t += blockDim.x) { const uint32_t v = hist[t]; row[t] = v; mine += v; }
+    }
     // instances of the chunk = gradient slots of its Gaussians: the scatter turns these into slot offsets
     if (threadIdx.x == 0) heads_all[0] = 0u;
     __syncthreads();
@@ -170,19 +179,25 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
 // Scatter: every Gaussian writes (depth bits << 32 | id) into the segment of each tile of its
 // rectangle (slot claimed with an LDS atomic on the chunk's cursor row), and completes its record.
 // ---------------------------------------------------------------------------------------------
+// GLOBAL = true (more tiles than LDS holds): the per-tile cursors are a global array initialised to the segment
+// starts (`table` then points at it), claimed with agent-scope atomics.
+template <bool GLOBAL>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ depthkey, const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum,
     const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cursor[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t cursor_lds[];
+    uint32_t* cursor = GLOBAL ? const_cast<uint32_t*>(table) : cursor_lds;
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
     __shared__ uint32_t wsum[GSR_HIST_THREADS / 64];
     __shared__ uint32_t chunk_first;
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t* row = table + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) cursor[t] = ranges[t].x + row[t];
+    if (!GLOBAL) {
+        const uint32_t* row = table + (size_t)blockIdx.x * T;
+        for (int t = threadIdx.x; t < T; t += blockDim.x) cursor[t] = ranges[t].x + row[t];
+    }
     if (threadIdx.x == 0) chunk_first = 0u;
     __syncthreads();
     // first gradient slot of the chunk = instances of all earlier chunks (nchunks <= GSR_MAX_CHUNKS <= blockDim)
@@ -237,6 +252,12 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             });
         }
     }
+}
+
+__global__ void __launch_bounds__(256) gsr_cursor_init_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ cursor)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < T) cursor[t] = ranges[t].x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,8 +439,8 @@ static hipError_t gsr_allow_big_lds()
     if (e != hipSuccess) return e;
     if (done_for_device == dev) return hipSuccess;
     const int big = 160 * 1024 - 4096;  // the hist / scatter kernels also hold 2 KiB of static LDS
-    e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) done_for_device = dev;
     return e;
@@ -428,15 +449,24 @@ static hipError_t gsr_allow_big_lds()
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
-    // (1) per-chunk tile histogram -> table, per-chunk instance totals
-    const size_t lds = (size_t)T * 4;
-    hipError_t e = gsr_allow_big_lds();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gsr_tile_hist_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.tmask, image.table, geom.scan_sums);
-    // (2) column scan -> per-(chunk, tile) offsets + tile totals, then tile scan -> ranges, info
-    hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
-                       image.tile_count);
+    hipError_t e;
+    if (T > GSR_MAX_TILES_LDS) {
+        // fallback for very large images: global counters (see gsr_tile_hist_kernel<true>)
+        e = hipMemsetAsync(image.tile_count, 0, (size_t)T * 4, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gsr_tile_hist_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
+                           geom.rect, geom.tmask, image.tile_count, geom.scan_sums);
+    } else {
+        // (1) per-chunk tile histogram -> table, per-chunk instance totals
+        e = gsr_allow_big_lds();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gsr_tile_hist_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx,
+                           nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums);
+        // (2) column scan -> per-(chunk, tile) offsets + tile totals
+        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
+                           image.tile_count);
+    }
+    // (3) tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
                        image.info);
     return hipGetLastError();
@@ -446,10 +476,16 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
                               int capacity, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
-    const size_t lds = (size_t)T * 4;
+    if (T > GSR_MAX_TILES_LDS) {
+        hipLaunchKernelGGL(gsr_cursor_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, image.ranges, image.table);
+        hipLaunchKernelGGL(gsr_scatter_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
+                           geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
+                           bin.seg_keys, (uint32_t)capacity);
+        return hipGetLastError();
+    }
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gsr_scatter_kernel, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
+    hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx, nchunks,
                        geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
                        bin.seg_keys, (uint32_t)capacity);
     return hipGetLastError();

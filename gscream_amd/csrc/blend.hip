@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    uint32_t* __restrict__ tile_work, uint32_t capacity)
+    uint32_t* __restrict__ tile_work, uint32_t capacity, uint32_t longest_sorted)
 {
     __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
     __shared__ uint32_t sQ[GSR_BATCH];
@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
     const uint2 rg = ranges[tile];
     // a list that does not fit the workspace was neither scattered completely nor sorted (speculative launch that
     // the host redoes): treat it as empty instead of following unsorted ids
-    const int n = rg.y > capacity ? 0 : (int)(rg.y - rg.x);
+    // (likewise a list longer than what the sort was provisioned for from a stale hint: point_list holds no ids for it)
+    const int n = (rg.y > capacity || rg.y - rg.x > longest_sorted) ? 0 : (int)(rg.y - rg.x);
     const bool inside = px < W && py < H;
 
     // Pixel state that is only ever tested wave-wide lives in wave-uniform 64-bit lane masks (SGPR pairs): `donem` =
@@ -472,6 +473,10 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(int T, const uint3
     const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int cnt = q + (xcd < r ? 1 : 0);
     const int nt = blockDim.x;
+    if (cnt > 4608) {  // beyond the LDS provision (> 36 864 tiles): keep the band in natural order
+        for (int i = threadIdx.x; i < cnt; i += nt) tile_order[xcd + 8 * i] = (uint32_t)(first + i);
+        return;
+    }
     for (int i = threadIdx.x; i < cnt; i += nt)
         k[i] = ((unsigned long long)(0xffffffffu - tile_work[first + i]) << 32) | (uint32_t)(first + i);
     if (threadIdx.x < 1024) rank[threadIdx.x] = 0u;
@@ -519,12 +524,12 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(int T, const uint3
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, hipStream_t stream)
+                                    float* out_feature, int capacity, int max_tile_count, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work,
-                       (uint32_t)capacity);
+                       (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count);
     return hipGetLastError();
 }
 

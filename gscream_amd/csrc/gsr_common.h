@@ -118,7 +118,8 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.ranges = (uint2*)(b + off); off += gsr_align(T * sizeof(uint2));
     im.final_T = (float*)(b + off); off += gsr_align(N * 4);
     im.n_contrib = (uint32_t*)(b + off); off += gsr_align(N * 4);
-    im.table = (uint32_t*)(b + off); off += gsr_align((size_t)gsr_num_chunks(P) * T * 4);
+    // [chunks][T] count table; beyond the LDS tile limit (global-counter fallback) only T cursor words are needed
+    im.table = (uint32_t*)(b + off); off += gsr_align((T > GSR_MAX_TILES_LDS ? (size_t)1 : (size_t)gsr_num_chunks(P)) * T * 4);
     im.tile_count = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.tile_work = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.tile_order = (uint32_t*)(b + off); off += gsr_align(T * 4);
@@ -165,7 +166,7 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const G
                                 const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, hipStream_t stream);
+                                    float* out_feature, int capacity, int max_tile_count, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots,

@@ -443,3 +443,26 @@ def test_non_finite_inputs_do_not_fault():
     torch.cuda.synchronize()
     assert (got["radii"][8:] == clean[8:]).all()
     assert got["radii"][0] == 0 and got["radii"][3] == 0 and got["radii"][5] == 0
+
+
+def test_image_beyond_the_lds_tile_limit():
+    """More than 36 864 tiles (3200x3200 px = 40 000 tiles): the binning falls back to global counters; results must
+    match the oracle exactly as for ordinary sizes."""
+    W = H = 3200
+    s = S.scene_config1(seed=77, P=1500, W=W, H=H)
+    # spread the cloud over the big frame and make the splats large enough to span several tiles
+    s["scales"] = (s["scales"] * np.float32(0.5)).astype(np.float32)
+    grads = S.upstream_grads(5, W, H)
+    st = Hh.oracle_forward(s, nthreads=max(1, min(16, os.cpu_count() or 1)))
+    ref = Hh.oracle_backward(s, st, grads, nthreads=max(1, min(16, os.cpu_count() or 1)))
+    got = Hh.hip_run(s, grads)
+    assert (got["radii"] == st["radii"]).all()
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k)
+    # splats of up to 400 px radius sum ~1e5 pixel contributions each: fp32 partials (ours per tile, the reference's
+    # atomics) against the oracle's double accumulators -> a looser bar for this stress case only
+    Hh.assert_grads_close(got, ref, tol=5e-3, max_bad_frac=5e-3, context="huge image")
+    set_tuning(tile_cull=False)
+    g2 = Hh.hip_run(s, keep_state=True)
+    assert g2["num_rendered"] == st["num_rendered"]
+    _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
