@@ -54,9 +54,9 @@ def test_argument_validation_without_gpu(native_lib):
     rc = native_lib.gsr_forward_stage1(10, 0, 0, 0, 64, None, None, 1.0, None, None, None, None, None, None, None, None,
                                        None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
     assert rc == -1
-    rc = native_lib.gsr_forward_stage1(10, 0, 0, 16 * 4000, 16 * 4000, None, None, 1.0, None, None, None, None, None, None,
+    rc = native_lib.gsr_forward_stage1(10, 0, 0, 16 * 5000, 16 * 5000, None, None, 1.0, None, None, None, None, None, None,
                                        None, None, None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
-    assert rc == -3  # unsupported: more tiles than the LDS histogram holds
+    assert rc == -3  # unsupported: 25M tiles (beyond 2^24; up to there the global-counter binning fallback applies)
     rc = native_lib.gsr_forward_stage1(0, 0, 0, 64, 64, None, None, 1.0, None, None, None, None, None, None, None, None,
                                        None, 0.5, 0.5, 0, None, None, None, _native.ctypes.byref(res), None, 0, None)
     assert rc == 0 and res.num_rendered == 0  # P == 0 short-circuits (DGR rasterize_points.cu:85)
