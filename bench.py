@@ -169,6 +169,33 @@ def loss_row(dev, H, W, steps, with_cpu):
     return row
 
 
+def knn_row(dev, with_cpu, P=1_000_000):
+    """SURVEY 8(f) rank 4 (init-only): simple_knn.distCUDA2 on 1M uniform points."""
+    from gscream_amd.simple_knn import distCUDA2
+    g = torch.Generator(device=dev).manual_seed(11)
+    pts = torch.rand((P, 3), device=dev, generator=g) * 10
+    distCUDA2(pts)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        distCUDA2(pts)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    row = {"what": f"simple_knn.distCUDA2 (mean squared distance to the 3 nearest neighbours), {P} uniform points (gsr_knn_mean_dist2)",
+           "ms": round(ms, 3), "Mpoints_per_s": round(P / ms / 1e3, 1)}
+    if with_cpu:
+        from oracle import knn_oracle as KO
+        sample = pts[:200_000].cpu().numpy()
+        t0 = time.perf_counter()
+        KO.mean_dist2(sample)
+        dt = time.perf_counter() - t0
+        row["cpu_baseline"] = {"value": round(sample.shape[0] / dt / 1e6, 3), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/knn_oracle.py (scipy cKDTree, exact 3-NN) on the first {sample.shape[0]} points, {dt:.1f}s"}
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,6 +326,10 @@ def main():
                 out["next_rows"] = {"rgb_loss": loss_row(dev, H, W, args.steps, not args.no_cpu_baseline)}
             except Exception as e:  # noqa: BLE001
                 out["next_rows"] = {"rgb_loss": {"error": repr(e)}}
+            try:
+                out["next_rows"]["simple_knn"] = knn_row(dev, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                out["next_rows"]["simple_knn"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_torch_naive"] = cpu_torch_naive()

@@ -16,6 +16,7 @@ EXPORTED_SYMBOLS = (
     "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
+    "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2",
 )
 NUM_STAGES = 7
 
@@ -89,6 +90,10 @@ def load():
     lib.gsr_rgb_loss_forward.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _vp, _vp, _c_int, _vp]
     lib.gsr_rgb_loss_backward.restype = _c_int
     lib.gsr_rgb_loss_backward.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _vp, _vp, _vp, _vp]
+    lib.gsr_knn_workspace_bytes.restype = ctypes.c_size_t
+    lib.gsr_knn_workspace_bytes.argtypes = [_c_int]
+    lib.gsr_knn_mean_dist2.restype = _c_int
+    lib.gsr_knn_mean_dist2.argtypes = [_c_int, _vp, _vp, _vp, _vp]
     _lib = lib
     return lib
 

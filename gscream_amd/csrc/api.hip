@@ -408,3 +408,18 @@ extern "C" int gsr_rgb_loss_backward(int C, int H, int W, const float* img, cons
             "rgb loss backward");
     return GSR_OK;
 }
+
+// ---- simple_knn (knn.hip) ----
+extern "C" size_t gsr_knn_workspace_bytes(int P) { return gsk_workspace_bytes(P); }
+
+extern "C" int gsr_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream)
+{
+    if (P < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "knn: P must be >= 0 (got %d)", P);
+    if (P == 0) return GSR_OK;
+    if (!points || !mean_dist2 || !workspace) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "knn: a required pointer is NULL");
+    const char* why = "";
+    hipError_t e = gsk_launch(P, points, mean_dist2, workspace, (hipStream_t)stream, &why);
+    if (e != hipSuccess) return gsr_fail(GSR_ERR_HIP, "knn: %s %s", hipGetErrorString(e), why);
+    return GSR_OK;
+}
+

@@ -185,3 +185,7 @@ hipError_t gsl_launch_forward(int C, int H, int W, const float* img, const float
 hipError_t gsl_launch_backward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
                                float a_ssim, const void* workspace, const float* upstream, float* dL_dimg,
                                hipStream_t stream);
+
+// ---- knn.hip ----
+size_t gsk_workspace_bytes(int P);
+hipError_t gsk_launch(int P, const float* points, float* mean_dist2, void* workspace, hipStream_t stream, const char** why);

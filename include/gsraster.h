@@ -192,6 +192,15 @@ int gsr_rgb_loss_backward(int C, int H, int W, const float* img, const float* gt
                           float a_ssim, const void* workspace, const float* upstream, float* dL_dimg, void* stream);
 
 /*
+ * ---- SURVEY 8(f) rank 4 (init-only): simple_knn ------------------------------------------------------------------
+ * mean_dist2[i] = mean of the three smallest squared fp32 distances from point i to the OTHER points.  Replaces
+ * simple_knn._C.distCUDA2 (submodules/simple-knn/simple_knn.cu:185-220, spatial.cu), called once by
+ * scene/gaussian_model.py at initialisation.  points: [P,3] fp32 contiguous; workspace: gsr_knn_workspace_bytes(P).
+ */
+size_t gsr_knn_workspace_bytes(int P);
+int gsr_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream);
+
+/*
  * Optional per-stage timing (bench.py's roofline numbers; the reference has no counterpart -- its only
  * timing is two CUDA events around a whole training iteration, train.py:343-344,406,578).
  * Between gsr_profile_begin() and gsr_profile_end() every stage of every call is bracketed by a pair

@@ -56,3 +56,16 @@ def test_fixtures_reproduce():
         # fp32 evaluation of the same restatement stays within the GPU test's tolerance of the fp64 fixture
         l32 = LO.value_and_grad(img, gt, w, c["lam"], c["scale"], dtype=torch.float32)[0]
         assert abs(l32 - loss) < 2e-6
+
+
+def test_knn_oracle_against_brute_force():
+    """oracle/knn_oracle.py (exact 3-NN through a k-d tree) against the O(P^2) definition."""
+    from oracle import knn_oracle as KO
+    rng = np.random.default_rng(3)
+    pts = rng.random((400, 3))
+    pts[10:20] = pts[0:10]  # coincident points are neighbours at distance 0
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    ref = np.sort(d2, axis=1)[:, :3].mean(1)
+    assert np.allclose(KO.mean_dist2(pts), ref, rtol=1e-12, atol=1e-15)
+    assert KO.mean_dist2(pts[:0]).shape == (0,) and np.all(KO.mean_dist2(pts[:3]) > 1e37)
