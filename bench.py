@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows (loss, knn) reported beside the north-star line")
     ap.add_argument("--no-tile-cull", action="store_true", help="bin every rectangle tile like the reference")
     args = ap.parse_args()
 
@@ -321,7 +322,7 @@ def main():
                                 "kernel_ms_sum": round(sum(v["avg_ms"] for v in stages.values()), 4)},
             "stages": stages,
         }
-        if world == 1:
+        if world == 1 and not args.no_next_rows:
             try:  # the next 8(f) row, reported beside the north-star line; never allowed to break it
                 out["next_rows"] = {"rgb_loss": loss_row(dev, H, W, args.steps, not args.no_cpu_baseline)}
             except Exception as e:  # noqa: BLE001
