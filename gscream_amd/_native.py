@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = (
     "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
-    "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2",
+    "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
 )
 NUM_STAGES = 7
 
@@ -94,6 +94,12 @@ def load():
     lib.gsr_knn_workspace_bytes.argtypes = [_c_int]
     lib.gsr_knn_mean_dist2.restype = _c_int
     lib.gsr_knn_mean_dist2.argtypes = [_c_int, _vp, _vp, _vp, _vp]
+    lib.gsr_decode_count.restype = _c_int
+    lib.gsr_decode_count.argtypes = [_c_int, _c_int] + [_vp] * 10
+    lib.gsr_decode_emit.restype = _c_int
+    lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 16
+    lib.gsr_decode_backward.restype = _c_int
+    lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 23
     _lib = lib
     return lib
 

@@ -423,3 +423,63 @@ extern "C" int gsr_knn_mean_dist2(int P, const float* points, float* mean_dist2,
     return GSR_OK;
 }
 
+// ---- neural-Gaussian decode (decode.hip) ----
+static int gsr_check_decode(int N, int K, const float* const* weights)
+{
+    if (N < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: N must be >= 0 (got %d)", N);
+    if (K < 1 || K > 10) return gsr_fail(GSR_ERR_UNSUPPORTED, "decode: n_offsets must be in 1..10 (got %d)", K);
+    if (!weights) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: weights is NULL");
+    for (int i = 0; i < 16; i++)
+        if (!weights[i]) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: weights[%d] is NULL", i);
+    return GSR_OK;
+}
+
+extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                                const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
+                                uint32_t* total, void* stream)
+{
+    int rc = gsr_check_decode(N, K, weights);
+    if (rc) return rc;
+    if (!total) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: total is NULL");
+    if (N == 0) { GSR_HIP(hipMemsetAsync(total, 0, 4, (hipStream_t)stream), "decode total"); return GSR_OK; }
+    if (!feat || !anchor || !campos || !neural_opacity || !mask || !count || !first)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    GSR_HIP(gsd_launch_count(N, K, weights, feat, anchor, campos, neural_opacity, mask, count, first, total, (hipStream_t)stream),
+            "decode count");
+    return GSR_OK;
+}
+
+extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                               const float* offsets, const float* grid_scaling, const float* campos,
+                               const float* neural_opacity, const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity, float* uncertainty,
+                               float* scaling, float* rot, void* stream)
+{
+    int rc = gsr_check_decode(N, K, weights);
+    if (rc) return rc;
+    if (N == 0) return GSR_OK;
+    if (!feat || !anchor || !offsets || !grid_scaling || !campos || !neural_opacity || !mask || !first)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    GSR_HIP(gsd_launch_emit(N, K, weights, feat, anchor, offsets, grid_scaling, campos, neural_opacity, mask, first, xyz, color, opacity,
+                            uncertainty, scaling, rot, (hipStream_t)stream), "decode emit");
+    return GSR_OK;
+}
+
+extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                                   const float* offsets, const float* grid_scaling, const float* campos,
+                                   const uint8_t* mask, const uint32_t* first, const float* g_xyz, const float* g_color,
+                                   const float* g_opacity, const float* g_uncertainty, const float* g_scaling,
+                                   const float* g_rot, float* d_feat, float* d_anchor, float* d_offsets,
+                                   float* d_grid_scaling, float* D2, float* D1, float* H, float* X, void* stream)
+{
+    int rc = gsr_check_decode(N, K, weights);
+    if (rc) return rc;
+    if (N == 0) return GSR_OK;
+    if (!feat || !anchor || !offsets || !grid_scaling || !campos || !mask || !first || !d_feat || !d_anchor || !d_offsets ||
+        !d_grid_scaling || !D2 || !D1 || !H || !X)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    GSR_HIP(gsd_launch_backward(N, K, weights, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
+                                g_opacity, g_uncertainty, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_grid_scaling, D2,
+                                D1, H, X, (hipStream_t)stream), "decode backward");
+    return GSR_OK;
+}
+

@@ -1,0 +1,369 @@
+// decode.hip -- fused neural-Gaussian decode + compaction (the step right BEFORE the rasterizer).
+//
+// Replaces the body of GScream's gaussian_renderer/__init__.py:18-102 generate_neural_gaussians after the
+// visible-anchor gather (:25-28): view vector / distance (:30-35), the four per-anchor MLPs 36 -> 32 -> {10, 10, 30, 70}
+// (scene/gaussian_model.py:118-144: opacity+Tanh, uncertainty+Sigmoid, color+Sigmoid, cov linear), the opacity mask
+// (:57-60), the [N*K, 23] concat + boolean-mask compaction (:78-87) and the post-processing (:90-96:
+// scaling = grid_scaling[:,3:] * sigmoid(.), rot = normalize(.), xyz = anchor + offset * grid_scaling[:,:3]).
+// The torch path materialises ~20 intermediates of up to [N*K, 23] floats; here one thread owns one anchor, nothing
+// but the compacted per-Gaussian outputs reaches HBM in the forward.
+//
+// Mapping.  Thread = anchor.  The MLP weights are wave-uniform operands: rows are fetched with scalar loads and
+// feed v_fma with an SGPR source, so a multiply-accumulate is one VALU op per 64 anchors.  Layer 1 walks its 32 rows
+// in a real loop (36 unrolled FMAs per row against the register-resident input) and parks each hidden unit in LDS
+// ([32][256], conflict-free); layer 2 pulls the 32 hidden units back into registers once and walks its output rows in
+// a real loop -- no dynamically indexed register arrays, ~70 FMA bodies of code instead of 8 400.
+//   pass A  gsd_count_kernel : opacity MLP only -> neural_opacity[N*K], mask[N*K], per-anchor survivor count
+//   scan    gsd_scan_kernel  : exclusive scan of the counts (one block; N ~ 2e5) -> first output row per anchor, total
+//   pass B  gsd_emit_kernel  : all four MLPs, writes the surviving offsets' rows in the reference's order
+//                              (anchor-major, offset-minor = boolean-mask order)
+//   bwd     gsd_backward_kernel : recomputes the activations, turns the per-Gaussian upstream gradients into
+//                              gradients of feat / anchor / offsets / grid scaling, and writes the per-anchor layer
+//                              deltas + activations; the WEIGHT gradients are then four pairs of plain GEMMs
+//                              (delta^T @ activations) done by the caller with the library GEMM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr_common.h"
+#include "gsr_math.h"
+
+#define GSD_F 32        // feat_dim (arguments/__init__.py:50)
+#define GSD_IN 36       // feat + view(3) + dist(1)
+#define GSD_HID 32
+#define GSD_MAXK 10     // n_offsets (arguments/__init__.py:51); the kernels handle K <= 10
+#define GSD_THREADS 256
+
+struct GsdMlps {  // device pointers; m = 0 opacity (K, tanh), 1 uncertainty (K, sigmoid), 2 color (3K, sigmoid), 3 cov (7K)
+    const float* w1[4];  // [32][36] row-major (torch Linear.weight)
+    const float* b1[4];  // [32]
+    const float* w2[4];  // [out][32]
+    const float* b2[4];  // [out]
+};
+
+__device__ __forceinline__ float gsd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// input vector of one anchor (gaussian_renderer/__init__.py:30-47): [feat(32), ob_view(3), ob_dist]
+__device__ __forceinline__ void gsd_input(const float* __restrict__ feat, const float* __restrict__ anchor,
+                                          const float* __restrict__ campos, int n, float x[GSD_IN], float& dist)
+{
+    const float4* f4 = reinterpret_cast<const float4*>(feat + (size_t)n * GSD_F);
+#pragma unroll
+    for (int i = 0; i < GSD_F / 4; i++) {
+        const float4 v = f4[i];
+        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    const float vx = anchor[3 * (size_t)n] - campos[0], vy = anchor[3 * (size_t)n + 1] - campos[1], vz = anchor[3 * (size_t)n + 2] - campos[2];
+    dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    x[32] = vx / dist; x[33] = vy / dist; x[34] = vz / dist; x[35] = dist;
+}
+
+// layer 1 of MLP m: hidden units -> LDS column of this thread (post-ReLU); hs is [GSD_HID][GSD_THREADS]
+__device__ __forceinline__ void gsd_layer1(const GsdMlps& P, int m, const float x[GSD_IN], float* hs)
+{
+    const float* __restrict__ w = P.w1[m];
+    const float* __restrict__ b = P.b1[m];
+#pragma unroll 1
+    for (int j = 0; j < GSD_HID; j++) {
+        float s = b[j];
+#pragma unroll
+        for (int i = 0; i < GSD_IN; i++) s += w[j * GSD_IN + i] * x[i];
+        hs[j * GSD_THREADS + threadIdx.x] = fmaxf(s, 0.0f);
+    }
+}
+__device__ __forceinline__ void gsd_load_hidden(const float* hs, float h[GSD_HID])
+{
+#pragma unroll
+    for (int j = 0; j < GSD_HID; j++) h[j] = hs[j * GSD_THREADS + threadIdx.x];
+}
+__device__ __forceinline__ float gsd_out(const GsdMlps& P, int m, int o, const float h[GSD_HID])
+{
+    const float* __restrict__ w = P.w2[m] + o * GSD_HID;
+    float s = P.b2[m][o];
+#pragma unroll
+    for (int j = 0; j < GSD_HID; j++) s += w[j] * h[j];
+    return s;
+}
+
+// ---- pass A: opacity MLP, mask, count ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, GsdMlps P, const float* __restrict__ feat,
+                                                                const float* __restrict__ anchor,
+                                                                const float* __restrict__ campos,
+                                                                float* __restrict__ neural_opacity,
+                                                                uint8_t* __restrict__ mask, uint8_t* __restrict__ count)
+{
+    __shared__ float hs[GSD_HID * GSD_THREADS];
+    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
+    if (n >= N) return;
+    float x[GSD_IN], dist, h[GSD_HID];
+    gsd_input(feat, anchor, campos, n, x, dist);
+    gsd_layer1(P, 0, x, hs);
+    gsd_load_hidden(hs, h);
+    int c = 0;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        const float op = tanhf(gsd_out(P, 0, k, h));
+        const bool keep = op > 0.0f;  // gaussian_renderer/__init__.py:59
+        neural_opacity[(size_t)n * K + k] = op;
+        mask[(size_t)n * K + k] = keep ? 1 : 0;
+        c += keep ? 1 : 0;
+    }
+    count[n] = (uint8_t)c;
+}
+
+// ---- exclusive scan of the per-anchor counts (single block of 1024; each thread owns a contiguous chunk) ---------
+__global__ void __launch_bounds__(1024) gsd_scan_kernel(int N, const uint8_t* __restrict__ count, uint32_t* __restrict__ first,
+                                                        uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (N + 1023) / 1024, i0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (int i = 0; i < per; i++) s += i0 + i < N ? count[i0 + i] : 0u;
+    const uint32_t incl = gsr_wave_scan_add(s);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - s, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const uint32_t sw = wsum[w]; run += w < wave ? sw : 0u; tot += sw; }
+    for (int i = 0; i < per && i0 + i < N; i++) { first[i0 + i] = run; run += count[i0 + i]; }
+    if (threadIdx.x == 0) total[0] = tot;
+}
+
+// ---- pass B: full decode, compacted output ------------------------------------------------------------------------
+__global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
+    int N, int K, GsdMlps P, const float* __restrict__ feat, const float* __restrict__ anchor,
+    const float* __restrict__ offsets /*[N,K,3]*/, const float* __restrict__ gscale /*[N,6]*/,
+    const float* __restrict__ campos, const float* __restrict__ neural_opacity, const uint8_t* __restrict__ mask,
+    const uint32_t* __restrict__ first, float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity, float* __restrict__ uncertainty,
+    float* __restrict__ scaling, float* __restrict__ rot)
+{
+    __shared__ float hs[GSD_HID * GSD_THREADS];
+    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
+    if (n >= N) return;
+    float x[GSD_IN], dist, h[GSD_HID];
+    gsd_input(feat, anchor, campos, n, x, dist);
+    uint32_t keep = 0;
+    for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
+    if (keep == 0u) return;
+    const uint32_t row0 = first[n];
+    const float ax = anchor[3 * (size_t)n], ay = anchor[3 * (size_t)n + 1], az = anchor[3 * (size_t)n + 2];
+    float gs[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)n + i];
+
+    // opacity = neural_opacity[mask] (:63): copied from pass A, bit for bit; geometry of the offsets
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        if (!((keep >> k) & 1u)) continue;
+        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        opacity[r] = neural_opacity[(size_t)n * K + k];
+        const float* of = offsets + ((size_t)n * K + k) * 3;
+        xyz[3 * (size_t)r] = ax + of[0] * gs[0];       // :94-95
+        xyz[3 * (size_t)r + 1] = ay + of[1] * gs[1];
+        xyz[3 * (size_t)r + 2] = az + of[2] * gs[2];
+    }
+    gsd_layer1(P, 1, x, hs);
+    gsd_load_hidden(hs, h);
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        if (!((keep >> k) & 1u)) continue;
+        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        uncertainty[r] = gsd_sigmoid(gsd_out(P, 1, k, h));
+    }
+    gsd_layer1(P, 2, x, hs);
+    gsd_load_hidden(hs, h);
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        if (!((keep >> k) & 1u)) continue;
+        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+#pragma unroll
+        for (int c = 0; c < 3; c++) color[3 * (size_t)r + c] = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
+    }
+    gsd_layer1(P, 3, x, hs);
+    gsd_load_hidden(hs, h);
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        if (!((keep >> k) & 1u)) continue;
+        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        float sr[7];
+#pragma unroll
+        for (int c = 0; c < 7; c++) sr[c] = gsd_out(P, 3, 7 * k + c, h);
+#pragma unroll
+        for (int c = 0; c < 3; c++) scaling[3 * (size_t)r + c] = gs[3 + c] * gsd_sigmoid(sr[c]);  // :90
+        const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);  // F.normalize
+#pragma unroll
+        for (int c = 0; c < 4; c++) rot[4 * (size_t)r + c] = sr[3 + c] / nrm;  // :91
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------------
+// Per anchor: upstream gradients of its surviving rows -> d(out) of the four second layers -> d(hidden) -> d(input).
+// Writes d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3], d_gscale[N,6] and, for the weight-gradient GEMMs of the caller,
+//   D2[N, 12K] (opacity K | uncertainty K | color 3K | cov 7K)   = dL/d(second-layer pre-activations)
+//   D1[N, 128], H[N, 128]  (four blocks of 32)                    = dL/d(first-layer pre-activations), hidden activations
+//   X [N, 36]                                                     = the MLP input
+__global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
+    int N, int K, GsdMlps P, const float* __restrict__ feat, const float* __restrict__ anchor,
+    const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
+    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ first, const float* __restrict__ g_xyz,
+    const float* __restrict__ g_color, const float* __restrict__ g_opacity, const float* __restrict__ g_unc,
+    const float* __restrict__ g_scaling, const float* __restrict__ g_rot, float* __restrict__ d_feat,
+    float* __restrict__ d_anchor, float* __restrict__ d_offsets, float* __restrict__ d_gscale, float* __restrict__ D2,
+    float* __restrict__ D1, float* __restrict__ Hout, float* __restrict__ Xout)
+{
+    __shared__ float hs[GSD_HID * GSD_THREADS];   // hidden activations of the current MLP
+    __shared__ float ds[GSD_HID * GSD_THREADS];   // dL/d(hidden) accumulators of the current MLP
+    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const int OUT2 = 12 * K;
+    float x[GSD_IN], dist, h[GSD_HID], dx[GSD_IN];
+    gsd_input(feat, anchor, campos, n, x, dist);
+#pragma unroll
+    for (int i = 0; i < GSD_IN; i++) { dx[i] = 0.f; Xout[(size_t)n * GSD_IN + i] = x[i]; }
+    uint32_t keep = 0;
+    for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
+    const uint32_t row0 = first[n];
+    float gs[6], dgs[6] = { 0, 0, 0, 0, 0, 0 }, da[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)n + i];
+
+    // geometry of the offsets: xyz = anchor + offset * gs[0:3]
+    for (int k = 0; k < K; k++) {
+        float* dof = d_offsets + ((size_t)n * K + k) * 3;
+        if (!((keep >> k) & 1u)) { dof[0] = dof[1] = dof[2] = 0.f; continue; }
+        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        const float* of = offsets + ((size_t)n * K + k) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float g = g_xyz[3 * (size_t)r + c];
+            da[c] += g; dof[c] = g * gs[c]; dgs[c] += g * of[c];
+        }
+    }
+
+#pragma unroll 1
+    for (int m = 0; m < 4; m++) {
+        gsd_layer1(P, m, x, hs);
+        gsd_load_hidden(hs, h);
+#pragma unroll
+        for (int j = 0; j < GSD_HID; j++) { ds[j * GSD_THREADS + threadIdx.x] = 0.f; Hout[(size_t)n * 128 + m * 32 + j] = h[j]; }
+        const int per = m == 0 || m == 1 ? 1 : (m == 2 ? 3 : 7);
+        const int out_base = m == 0 ? 0 : (m == 1 ? K : (m == 2 ? 2 * K : 5 * K));
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const bool on = (keep >> k) & 1u;
+            const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+            float dz[7] = { 0, 0, 0, 0, 0, 0, 0 };  // dL/d(pre-activation) of this offset's outputs
+            if (on) {
+                if (m == 0) {  // opacity = tanh(z)
+                    const float t = tanhf(gsd_out(P, 0, k, h));
+                    dz[0] = g_opacity[r] * (1.0f - t * t);
+                } else if (m == 1) {  // sigmoid
+                    const float s = gsd_sigmoid(gsd_out(P, 1, k, h));
+                    dz[0] = g_unc[r] * s * (1.0f - s);
+                } else if (m == 2) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float s = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
+                        dz[c] = g_color[3 * (size_t)r + c] * s * (1.0f - s);
+                    }
+                } else {
+                    float sr[7];
+#pragma unroll
+                    for (int c = 0; c < 7; c++) sr[c] = gsd_out(P, 3, 7 * k + c, h);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {  // scaling = gs[3+c] * sigmoid(sr[c])
+                        const float s = gsd_sigmoid(sr[c]), g = g_scaling[3 * (size_t)r + c];
+                        dz[c] = g * gs[3 + c] * s * (1.0f - s);
+                        dgs[3 + c] += g * s;
+                    }
+                    // rot = q / max(|q|, eps): d q = (g - rot (rot . g)) / |q|
+                    const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);
+                    float gq[4], dot = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { gq[c] = g_rot[4 * (size_t)r + c]; dot += gq[c] * (sr[3 + c] / nrm); }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) dz[3 + c] = (gq[c] - (sr[3 + c] / nrm) * dot) / nrm;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                if (c >= per) break;
+                const int o = per * k + c;
+                D2[(size_t)n * OUT2 + out_base + o] = dz[c];
+                if (dz[c] != 0.0f) {
+                    const float* __restrict__ w = P.w2[m] + o * GSD_HID;
+#pragma unroll
+                    for (int j = 0; j < GSD_HID; j++) ds[j * GSD_THREADS + threadIdx.x] += w[j] * dz[c];
+                }
+            }
+        }
+        // through the ReLU and the first layer: d(pre1)[j] = ds[j] * (h[j] > 0);  dx += W1^T d(pre1)
+        const float* __restrict__ w1 = P.w1[m];
+#pragma unroll 1
+        for (int j = 0; j < GSD_HID; j++) {
+            const float d1 = hs[j * GSD_THREADS + threadIdx.x] > 0.0f ? ds[j * GSD_THREADS + threadIdx.x] : 0.0f;
+            D1[(size_t)n * 128 + m * 32 + j] = d1;
+#pragma unroll
+            for (int i = 0; i < GSD_IN; i++) dx[i] += w1[j * GSD_IN + i] * d1;
+        }
+    }
+    // input gradients: feat, and the view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist)
+#pragma unroll
+    for (int i = 0; i < GSD_F; i++) d_feat[(size_t)n * GSD_F + i] = dx[i];
+    {
+        const float ux = x[32], uy = x[33], uz = x[34];
+        const float gdot = dx[32] * ux + dx[33] * uy + dx[34] * uz;
+        da[0] += (dx[32] - ux * gdot) / dist + dx[35] * ux;
+        da[1] += (dx[33] - uy * gdot) / dist + dx[35] * uy;
+        da[2] += (dx[34] - uz * gdot) / dist + dx[35] * uz;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) d_anchor[3 * (size_t)n + c] = da[c];
+#pragma unroll
+    for (int i = 0; i < 6; i++) d_gscale[6 * (size_t)n + i] = dgs[i];
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+static GsdMlps gsd_pack(const float* const* w)  // w[16] = {w1[4], b1[4], w2[4], b2[4]}
+{
+    GsdMlps P;
+    for (int m = 0; m < 4; m++) { P.w1[m] = w[m]; P.b1[m] = w[4 + m]; P.w2[m] = w[8 + m]; P.b2[m] = w[12 + m]; }
+    return P;
+}
+
+hipError_t gsd_launch_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                            const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
+                            uint32_t* total, hipStream_t stream)
+{
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsd_count_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
+                       gsd_pack(weights), feat, anchor, campos, neural_opacity, mask, count);
+    hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, N, count, first, total);
+    return hipGetLastError();
+}
+
+hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                           const float* offsets, const float* gscale, const float* campos, const float* neural_opacity,
+                           const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,
+                           float* uncertainty, float* scaling, float* rot, hipStream_t stream)
+{
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsd_emit_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
+                       gsd_pack(weights), feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
+                       opacity, uncertainty, scaling, rot);
+    return hipGetLastError();
+}
+
+hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                               const float* offsets, const float* gscale, const float* campos, const uint8_t* mask,
+                               const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
+                               const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
+                               float* d_anchor, float* d_offsets, float* d_gscale, float* D2, float* D1, float* H, float* X,
+                               hipStream_t stream)
+{
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsd_backward_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
+                       gsd_pack(weights), feat, anchor, offsets, gscale, campos, mask, first, g_xyz, g_color, g_opacity,
+                       g_unc, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_gscale, D2, D1, H, X);
+    return hipGetLastError();
+}

@@ -1,0 +1,136 @@
+"""Fused neural-Gaussian decode on the HIP path -- SURVEY 8(f) rank 1, the step right before the rasterizer.
+
+`generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False)` mirrors GScream's
+gaussian_renderer/__init__.py:18-102 (same arguments, same return tuple, same row order) for a `pc` that exposes what
+the reference's GaussianModel does: `_anchor_feat`, `get_anchor`, `_offset`, `get_scaling`, `n_offsets`,
+`use_feat_bank`, `get_opacity_mlp`, `get_uncertainty_mlp`, `get_color_mlp`, `get_cov_mlp`
+(nn.Sequential(Linear(36,32), ReLU, Linear(32,out)[, act]) as in scene/gaussian_model.py:118-144).
+
+The visible-anchor gather (:25-28) stays in torch (four index ops); everything after it -- view vector, four MLPs,
+opacity mask, boolean-mask compaction, post-processing -- runs in `gsr_decode_count` / `gsr_decode_emit`
+(include/gsraster.h), and the backward in `gsr_decode_backward` + eight plain GEMMs for the weight gradients.
+`use_feat_bank=True` (off in every GScream config, arguments/__init__.py:57) raises NotImplementedError.
+No CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _native
+
+__all__ = ["generate_neural_gaussians", "decode"]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _weight_array(ws):
+    arr = (ctypes.c_void_p * 16)(*[w.data_ptr() for w in ws])
+    return arr
+
+
+class _Decode(torch.autograd.Function):
+    """inputs: feat[N,32], anchor[N,3], offsets[N,K,3], grid_scaling[N,6], campos[3], then 16 weight tensors in the order
+    {w1[4], b1[4], w2[4], b2[4]} for the MLPs {opacity, uncertainty, color, cov}."""
+
+    @staticmethod
+    def forward(ctx, feat, anchor, offsets, gscale, campos, *weights):
+        lib = _native.load()
+        if not feat.is_cuda:
+            raise RuntimeError("gscream_amd.neural_gaussians: tensors must be on a HIP device (no CPU fallback)")
+        N, K = int(anchor.shape[0]), int(offsets.shape[1])
+        if feat.shape[1] != 32:
+            raise NotImplementedError("feat_dim must be 32 (arguments/__init__.py:50)")
+        dev = feat.device
+        f32 = lambda t: t.detach().contiguous().float()
+        feat_c, anchor_c, off_c, gs_c, cam_c = f32(feat), f32(anchor), f32(offsets), f32(gscale), f32(campos)
+        ws = [f32(w) for w in weights]
+        warr = _weight_array(ws)
+        with torch.cuda.device(dev):
+            nop = torch.empty((N * K, 1), dtype=torch.float32, device=dev)
+            mask = torch.empty((N * K,), dtype=torch.uint8, device=dev)
+            count = torch.empty((max(N, 1),), dtype=torch.uint8, device=dev)
+            first = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
+            total = torch.zeros((1,), dtype=torch.int32, device=dev)
+            _native.check(lib.gsr_decode_count(N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(cam_c),
+                                               _native.ptr(nop), _native.ptr(mask), _native.ptr(count), _native.ptr(first),
+                                               _native.ptr(total), _stream()), "gsr_decode_count")
+            M = int(total.item())  # the reference's boolean-mask indexing synchronises here as well
+            e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+            xyz, color, opacity, unc, scaling, rot = e(M, 3), e(M, 3), e(M, 1), e(M, 1), e(M, 3), e(M, 4)
+            _native.check(lib.gsr_decode_emit(N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c),
+                                              _native.ptr(gs_c), _native.ptr(cam_c), _native.ptr(nop), _native.ptr(mask), _native.ptr(first),
+                                              _native.ptr(xyz), _native.ptr(color), _native.ptr(opacity), _native.ptr(unc),
+                                              _native.ptr(scaling), _native.ptr(rot), _stream()), "gsr_decode_emit")
+        ctx.save_for_backward(feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws)
+        ctx.dims = (N, K, M)
+        ctx.in_shapes = [tuple(t.shape) for t in (feat, anchor, offsets, gscale)] + [tuple(w.shape) for w in weights]
+        bmask = mask.bool()
+        ctx.mark_non_differentiable(nop, bmask)
+        return xyz, color, opacity, unc, scaling, rot, nop, bmask
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_color, g_opacity, g_unc, g_scaling, g_rot, _g_nop, _g_mask):
+        lib = _native.load()
+        feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws = ctx.saved_tensors
+        N, K, M = ctx.dims
+        dev = feat_c.device
+        z = lambda g, c: (torch.zeros((M, c), dtype=torch.float32, device=dev) if g is None else g.detach().contiguous().float())
+        g_xyz, g_color, g_opacity, g_unc, g_scaling, g_rot = z(g_xyz, 3), z(g_color, 3), z(g_opacity, 1), z(g_unc, 1), z(g_scaling, 3), z(g_rot, 4)
+        warr = _weight_array(ws)
+        with torch.cuda.device(dev):
+            e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+            d_feat, d_anchor, d_off, d_gs = e(N, 32), e(N, 3), e(N, K, 3), e(N, 6)
+            D2, D1, H, X = e(N, 12 * K), e(N, 128), e(N, 128), e(N, 36)
+            _native.check(lib.gsr_decode_backward(
+                N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c), _native.ptr(cam_c),
+                _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
+                _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
+                _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(D2), _native.ptr(D1), _native.ptr(H), _native.ptr(X),
+                _stream()), "gsr_decode_backward")
+            # weight gradients: plain library GEMMs over the per-anchor deltas (delta^T @ activations)
+            outs = (K, K, 3 * K, 7 * K)
+            base = (0, K, 2 * K, 5 * K)
+            gw1, gb1, gw2, gb2 = [], [], [], []
+            for m in range(4):
+                d2 = D2[:, base[m]:base[m] + outs[m]]
+                d1 = D1[:, 32 * m:32 * m + 32]
+                gw2.append(d2.t() @ H[:, 32 * m:32 * m + 32])
+                gb2.append(d2.sum(0))
+                gw1.append(d1.t() @ X)
+                gb1.append(d1.sum(0))
+        grads_w = gw1 + gb1 + gw2 + gb2
+        sh = ctx.in_shapes
+        return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None,
+                *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
+
+
+def _mlp_tensors(mlp):
+    lin = [m for m in mlp if isinstance(m, torch.nn.Linear)]
+    if len(lin) != 2 or lin[0].in_features != 36 or lin[0].out_features != 32 or lin[1].in_features != 32:
+        raise NotImplementedError("expected Sequential(Linear(36,32), ReLU, Linear(32,out)[, act]) (scene/gaussian_model.py:118-144)")
+    return lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias
+
+
+def decode(feat, anchor, offsets, grid_scaling, campos, opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp):
+    """-> xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask for already-gathered anchor tensors."""
+    t = [_mlp_tensors(m) for m in (opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp)]
+    weights = [t[m][i] for i in range(4) for m in range(4)]  # {w1[4], b1[4], w2[4], b2[4]}
+    return _Decode.apply(feat, anchor, offsets, grid_scaling, campos, *weights)
+
+
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
+    if getattr(pc, "use_feat_bank", False):
+        raise NotImplementedError("use_feat_bank=True is not implemented (False in every GScream config)")
+    if visible_mask is None:  # gaussian_renderer/__init__.py:20-21
+        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
+    feat = pc._anchor_feat[visible_mask]          # :25-28
+    anchor = pc.get_anchor[visible_mask]
+    grid_offsets = pc._offset[visible_mask]
+    grid_scaling = pc.get_scaling[visible_mask]
+    xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask = decode(
+        feat, anchor, grid_offsets, grid_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,
+        pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp)
+    if is_training:  # :98-102
+        return xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask
+    return xyz, color, opacity, uncertainty, scaling, rot

@@ -176,6 +176,33 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
                      uint8_t* present, void* stream);
 
 /*
+ * ---- fused neural-Gaussian decode + compaction, the step right before the rasterizer ----------
+ * Replaces the body of gaussian_renderer/__init__.py:18-102 generate_neural_gaussians after the visible-anchor
+ * gather: view vector/distance, the four MLPs 36->32->{K, K, 3K, 7K} (scene/gaussian_model.py:118-144: opacity+Tanh,
+ * uncertainty+Sigmoid, color+Sigmoid, cov linear), the opacity>0 mask, the boolean-mask compaction and the
+ * post-processing.  N anchors, K = n_offsets <= 10, feat_dim = 32.  All pointers are device pointers, fp32
+ * contiguous: feat[N,32], anchor[N,3], offsets[N,K,3], grid_scaling[N,6] (= exp(_scaling)), campos[3].
+ * weights[16] = { w1[4], b1[4], w2[4], b2[4] } for the MLPs {opacity, uncertainty, color, cov} (torch Linear layout).
+ *   gsr_decode_count : neural_opacity[N*K], mask[N*K] (u8), count[N] (u8), first[N] (u32, exclusive scan), total[1] (u32)
+ *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
+ *                      scaling[M,3], rot[M,4]
+ *   gsr_decode_backward : upstream gradients of those rows -> d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3],
+ *                      d_grid_scaling[N,6], plus the per-anchor layer deltas D2[N,12K] / D1[N,128] and activations H[N,128],
+ *                      X[N,36] from which the caller forms the weight gradients with plain GEMMs (D^T @ A).
+ */
+int gsr_decode_count(int N, int K, const float* const* weights, const float* feat, const float* anchor, const float* campos,
+                     float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first, uint32_t* total, void* stream);
+int gsr_decode_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor, const float* offsets,
+                    const float* grid_scaling, const float* campos, const float* neural_opacity /* from gsr_decode_count */,
+                    const uint8_t* mask, const uint32_t* first, float* xyz,
+                    float* color, float* opacity, float* uncertainty, float* scaling, float* rot, void* stream);
+int gsr_decode_backward(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+                        const float* offsets, const float* grid_scaling, const float* campos, const uint8_t* mask,
+                        const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
+                        const float* g_uncertainty, const float* g_scaling, const float* g_rot, float* d_feat, float* d_anchor,
+                        float* d_offsets, float* d_grid_scaling, float* D2, float* D1, float* H, float* X, void* stream);
+
+/*
  * ---- the image-space RGB loss that follows the rasterizer ----------------------------------
  * Fused weighted L1 + weighted SSIM (11x11 Gaussian window, sigma 1.5, zero padding), value and gradient:
  *     L = a_l1 * mean(|img - gt| * m) + a_ssim * mean(ssim_map(img, gt) * m),   m = weight[H,W] (1 when NULL),

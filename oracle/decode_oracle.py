@@ -1,0 +1,79 @@
+"""CPU oracle for the neural-Gaussian decode.  TEST INFRASTRUCTURE ONLY.
+
+`generate_neural_gaussians` below restates gaussian_renderer/__init__.py:18-102 line by line in plain torch (the
+feature-bank branch :39-49 omitted: use_feat_bank is False in every GScream config); `make_model` builds a stand-in for
+the parts of scene/gaussian_model.py the function touches (MLPs as :118-144, activations :43-54).
+
+PARITY UNPINNED: the reference module cannot be imported here (it imports einops' `repeat` -- present -- but also
+scene.gaussian_model, which needs simple_knn / plyfile / torch_scatter builds that are absent), and the reference
+ships no vectors for it; the restatement follows the cited lines one to one."""
+import torch
+from torch import nn
+
+
+class Camera:
+    def __init__(self, center):
+        self.camera_center = center
+
+
+class Model(nn.Module):
+    """What generate_neural_gaussians reads from GaussianModel."""
+
+    def __init__(self, N, K=10, feat_dim=32, seed=0, dtype=torch.float64, spread=3.0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+        self.n_offsets, self.use_feat_bank = K, False
+        self._anchor = nn.Parameter((r(N, 3) * spread).to(dtype))
+        self._anchor_feat = nn.Parameter((r(N, feat_dim) * 0.5).to(dtype))
+        self._offset = nn.Parameter((r(N, K, 3) * 0.3).to(dtype))
+        self._scaling = nn.Parameter((r(N, 6) * 0.3 - 2.0).to(dtype))
+        mk = lambda out, act: nn.Sequential(nn.Linear(feat_dim + 3 + 1, feat_dim), nn.ReLU(True), nn.Linear(feat_dim, out),
+                                            *([act] if act is not None else [])).to(dtype)
+        torch.manual_seed(seed + 1)
+        self.mlp_opacity = mk(K, nn.Tanh())             # scene/gaussian_model.py:118-123
+        self.mlp_uncertainty = mk(K, nn.Sigmoid())       # :125-131
+        self.mlp_cov = mk(7 * K, None)                   # :133-137
+        self.mlp_color = mk(3 * K, nn.Sigmoid())         # :139-144
+        self.rotation_activation = torch.nn.functional.normalize  # :54
+
+    get_anchor = property(lambda self: self._anchor)
+    get_scaling = property(lambda self: 1.0 * torch.exp(self._scaling))  # :241-242
+    get_opacity_mlp = property(lambda self: self.mlp_opacity)
+    get_uncertainty_mlp = property(lambda self: self.mlp_uncertainty)
+    get_cov_mlp = property(lambda self: self.mlp_cov)
+    get_color_mlp = property(lambda self: self.mlp_color)
+
+
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
+    if visible_mask is None:
+        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
+    feat = pc._anchor_feat[visible_mask]
+    anchor = pc.get_anchor[visible_mask]
+    grid_offsets = pc._offset[visible_mask]
+    grid_scaling = pc.get_scaling[visible_mask]
+    ob_view = anchor - viewpoint_camera.camera_center                     # :31
+    ob_dist = ob_view.norm(dim=1, keepdim=True)                           # :33
+    ob_view = ob_view / ob_dist                                           # :35
+    cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)           # :52
+    neural_opacity = pc.get_opacity_mlp(cat_local_view)                   # :55
+    neural_opacity = neural_opacity.reshape([-1, 1])                      # :58
+    mask = (neural_opacity > 0.0).view(-1)                                # :59-60
+    opacity = neural_opacity[mask]                                        # :63
+    K = pc.n_offsets
+    uncertainty = pc.get_uncertainty_mlp(cat_local_view).reshape([anchor.shape[0] * K, 1])   # :66-67
+    color = pc.get_color_mlp(cat_local_view).reshape([anchor.shape[0] * K, 3])               # :70-71
+    scale_rot = pc.get_cov_mlp(cat_local_view).reshape([anchor.shape[0] * K, 7])             # :74-75
+    offsets = grid_offsets.view([-1, 3])                                  # :78
+    concatenated = torch.cat([grid_scaling, anchor], dim=-1)              # :81
+    concatenated_repeated = concatenated.repeat_interleave(K, dim=0)      # :82 einops 'n (c) -> (n k) (c)'
+    concatenated_all = torch.cat([concatenated_repeated, uncertainty, color, scale_rot, offsets], dim=-1)  # :84
+    masked = concatenated_all[mask]                                       # :85
+    scaling_repeat, repeat_anchor, uncertainty, color, scale_rot, offsets = masked.split([6, 3, 1, 3, 7, 3], dim=-1)  # :87
+    scaling = scaling_repeat[:, 3:] * torch.sigmoid(scale_rot[:, :3])     # :90
+    rot = pc.rotation_activation(scale_rot[:, 3:7])                       # :91
+    offsets = offsets * scaling_repeat[:, :3]                             # :94
+    xyz = repeat_anchor + offsets                                         # :95
+    if is_training:
+        return xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask
+    return xyz, color, opacity, uncertainty, scaling, rot

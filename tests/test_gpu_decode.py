@@ -1,0 +1,110 @@
+"""GPU parity of the fused neural-Gaussian decode (gscream_amd.neural_gaussians -> gsr_decode_*) against the CPU
+oracle (float64 restatement of gaussian_renderer/__init__.py:18-102).
+
+Tolerances (fp32 kernels vs fp64 oracle): forward values 2e-5 abs/rel, gradients 2e-4 of the largest entry of each
+tensor.  The compaction mask is `tanh(z) > 0`: an fp32 pre-activation within rounding of zero may legitimately flip,
+so the mask is required to agree wherever |neural_opacity| > 1e-5 and the row-wise comparison uses seeds where it
+agrees everywhere (checked)."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import decode_oracle as DO  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+CAM = [0.3, -0.2, -6.0]
+
+
+def _pair(N, K, seed):
+    ref = DO.Model(N, K, seed=seed, dtype=torch.float64)
+    dut = copy.deepcopy(ref).float().cuda()
+    return ref, dut
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.numel():
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(1.0, b.abs().max().item()), (what, err)
+
+
+@pytest.mark.parametrize("N,K,seed,vis", [(3000, 10, 1, False), (2571, 10, 2, True), (700, 4, 3, False), (1, 10, 4, False)])
+def test_forward_and_backward_against_oracle(N, K, seed, vis):
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    ref, dut = _pair(N, K, seed)
+    g = torch.Generator().manual_seed(seed)
+    vm = (torch.rand(N, generator=g) > 0.35) if vis else None
+    cam_r = DO.Camera(torch.tensor(CAM, dtype=torch.float64))
+    cam_d = DO.Camera(torch.tensor(CAM, dtype=torch.float32, device="cuda"))
+    out_r = DO.generate_neural_gaussians(cam_r, ref, vm, True)
+    out_d = generate_neural_gaussians(cam_d, dut, None if vm is None else vm.cuda(), True)
+    names = ("xyz", "color", "opacity", "uncertainty", "scaling", "rot", "neural_opacity", "mask")
+    nop_r, mask_r, mask_d = out_r[6].view(-1), out_r[7], out_d[7].cpu()
+    sure = nop_r.abs() > 1e-5
+    assert torch.equal(mask_r[sure], mask_d[sure]), "mask differs away from zero"
+    assert torch.equal(mask_r, mask_d), "seed chosen so that no pre-activation sits within fp32 rounding of zero"
+    for nm, a, b in zip(names[:7], out_d[:7], out_r[:7]):
+        _close(a, b, 2e-5, nm)
+    assert out_d[7].dtype == torch.bool and out_d[2].shape[1] == 1 and out_d[6].shape == (out_r[6].shape[0], 1)
+    # backward: random upstream gradients on the six differentiable outputs
+    ups = [torch.randn(o.shape, generator=g, dtype=torch.float64) for o in out_r[:6]]
+    (sum((o * u).sum() for o, u in zip(out_r[:6], ups))).backward()
+    (sum((o * u.float().cuda()).sum() for o, u in zip(out_d[:6], ups))).backward()
+    pr, pd = dict(ref.named_parameters()), dict(dut.named_parameters())
+    for k in pr:
+        assert pd[k].grad is not None, k
+        _close(pd[k].grad, pr[k].grad, 2e-4, "grad " + k)
+
+
+def test_eval_path_empty_and_errors():
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    ref, dut = _pair(500, 10, 7)
+    cam_d = DO.Camera(torch.tensor(CAM, device="cuda"))
+    with torch.no_grad():
+        out = generate_neural_gaussians(cam_d, dut, None, False)
+    assert len(out) == 6 and out[0].shape[1] == 3 and out[5].shape[1] == 4
+    assert torch.allclose(out[5].norm(dim=1), torch.ones_like(out[5][:, 0]), atol=1e-5)
+    none = generate_neural_gaussians(cam_d, dut, torch.zeros(500, dtype=torch.bool, device="cuda"), True)
+    assert none[0].shape == (0, 3) and none[6].shape == (0, 1) and none[7].shape == (0,)
+    dut.use_feat_bank = True
+    with pytest.raises(NotImplementedError):
+        generate_neural_gaussians(cam_d, dut, None, False)
+    dut.use_feat_bank = False
+    with pytest.raises(RuntimeError):
+        generate_neural_gaussians(DO.Camera(torch.tensor(CAM)), copy.deepcopy(ref).float(), None, False)
+
+
+def test_feeds_the_rasterizer_at_scale():
+    """200k anchors x 10 offsets -> ~1M Gaussians straight into the rasterizer (the two rows back to back);
+    size-independent checks: row count = mask count, rows follow boolean-mask order, unit quaternions."""
+    from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer, synthetic as S
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    dut = DO.Model(200_000, 10, seed=11, dtype=torch.float32, spread=1.5).cuda()
+    cam = DO.Camera(torch.tensor([0.0, 0.0, -6.0], device="cuda"))
+    xyz, color, opacity, unc, scaling, rot, nop, mask = generate_neural_gaussians(cam, dut, None, True)
+    M = int(mask.sum())
+    assert xyz.shape == (M, 3) and opacity.shape == (M, 1) and 0 < M < 2_000_000
+    assert torch.equal(opacity.view(-1), nop.view(-1)[mask]), "rows are in boolean-mask order"
+    assert torch.allclose(rot.norm(dim=1), torch.ones(M, device="cuda"), atol=1e-5) and (opacity > 0).all()
+    W, H = 1008, 567
+    w2c = np.eye(4, dtype=np.float32)
+    w2c[2, 3] = 6.0  # camera at z = -6 looking down +z
+    view, proj, campos = S.camera_matrices(0.6, 0.6 * H / W, w2c)
+    assert np.allclose(campos, [0, 0, -6], atol=1e-5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=0.6, tanfovy=0.6 * H / W, bg=torch.zeros(3, device="cuda"),
+                                       scale_modifier=1.0, viewmatrix=t(view), projmatrix=t(proj), sh_degree=1, campos=t(campos),
+                                       prefiltered=False, debug=False)
+    img, depth, feat, radii = GaussianRasterizer(rs)(means3D=xyz, means2D=torch.zeros_like(xyz, requires_grad=True), opacities=opacity,
+                                                     uncertainties=unc, colors_precomp=color, scales=scaling, rotations=rot)
+    assert img.shape == (3, H, W) and torch.isfinite(img).all() and (radii > 0).any()
+    img.mean().backward()
+    assert dut._anchor_feat.grad is not None and torch.isfinite(dut._anchor_feat.grad).all() and dut._anchor_feat.grad.abs().sum() > 0
+    assert dut.mlp_color[2].weight.grad.abs().sum() > 0
