@@ -196,6 +196,59 @@ def knn_row(dev, with_cpu, P=1_000_000):
     return row
 
 
+def decode_row(dev, steps, with_cpu, N=200_000, K=10):
+    """SURVEY 8(f) rank 1 (the step before the rasterizer): fused neural-Gaussian decode + compaction,
+    200k anchors x 10 offsets (-> ~1M Gaussians), forward and forward+backward."""
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    from oracle import decode_oracle as DO
+    model = DO.Model(N, K, seed=11, dtype=torch.float32, spread=1.5).to(dev)
+    cam = DO.Camera(torch.tensor([0.0, 0.0, -6.0], device=dev))
+    params = [p for p in model.parameters()]
+
+    def run(fn, backward):
+        out = fn(cam, model, None, True)
+        if backward:
+            loss = sum(o.sum() for o in out[:6])
+            torch.autograd.grad(loss, params, allow_unused=True)
+        return out
+
+    def timed(fn, backward, n):
+        for _ in range(2):
+            run(fn, backward)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            out = run(fn, backward)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, int(out[0].shape[0])
+
+    n = max(5, steps // 5)
+    f_ms, M = timed(generate_neural_gaussians, False, n)
+    fb_ms, _ = timed(generate_neural_gaussians, True, n)
+    ef_ms, _ = timed(DO.generate_neural_gaussians, False, n)
+    efb_ms, _ = timed(DO.generate_neural_gaussians, True, n)
+    row = {"what": f"generate_neural_gaussians: {N} anchors x {K} offsets -> {M} Gaussians (gsr_decode_*), through the autograd API",
+           "forward_ms": round(f_ms, 3), "forward_backward_ms": round(fb_ms, 3),
+           "torch_eager_same_gpu": {"forward_ms": round(ef_ms, 3), "forward_backward_ms": round(efb_ms, 3)},
+           "speedup_vs_torch_eager": {"forward": round(ef_ms / f_ms, 1), "forward_backward": round(efb_ms / fb_ms, 1)},
+           "MFLOP_forward": round(N * 2 * (4 * 36 * 32 + 32 * 12 * K) / 1e6, 1)}
+    if with_cpu:
+        cpu = DO.Model(20_000, K, seed=11, dtype=torch.float32, spread=1.5)
+        camc = DO.Camera(torch.tensor([0.0, 0.0, -6.0]))
+        t0, it = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 3.0:
+            out = DO.generate_neural_gaussians(camc, cpu, None, True)
+            torch.autograd.grad(sum(o.sum() for o in out[:6]), list(cpu.parameters()), allow_unused=True)
+            it += 1
+        dt = time.perf_counter() - t0
+        row["cpu_baseline"] = {"value": round(20_000 * it / dt / 1e6, 3), "unit": "M anchors/s (forward+backward)", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"oracle/decode_oracle.py fp32 on 20000 anchors, {it} iterations in {dt:.1f}s"}
+        row["M_anchors_per_s_forward_backward"] = round(N / fb_ms / 1e3, 2)
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,6 +380,10 @@ def main():
                 out["next_rows"] = {"rgb_loss": loss_row(dev, H, W, args.steps, not args.no_cpu_baseline)}
             except Exception as e:  # noqa: BLE001
                 out["next_rows"] = {"rgb_loss": {"error": repr(e)}}
+            try:
+                out["next_rows"]["neural_gaussian_decode"] = decode_row(dev, args.steps, not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                out["next_rows"]["neural_gaussian_decode"] = {"error": repr(e)}
             try:
                 out["next_rows"]["simple_knn"] = knn_row(dev, not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001

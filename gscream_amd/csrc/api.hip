@@ -436,15 +436,16 @@ static int gsr_check_decode(int N, int K, const float* const* weights)
 
 extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
                                 const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
-                                uint32_t* total, void* stream)
+                                uint32_t* total, uint32_t* block_scratch, void* stream)
 {
     int rc = gsr_check_decode(N, K, weights);
     if (rc) return rc;
     if (!total) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: total is NULL");
     if (N == 0) { GSR_HIP(hipMemsetAsync(total, 0, 4, (hipStream_t)stream), "decode total"); return GSR_OK; }
-    if (!feat || !anchor || !campos || !neural_opacity || !mask || !count || !first)
+    if (!feat || !anchor || !campos || !neural_opacity || !mask || !count || !first || !block_scratch)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_count(N, K, weights, feat, anchor, campos, neural_opacity, mask, count, first, total, (hipStream_t)stream),
+    GSR_HIP(gsd_launch_count(N, K, weights, feat, anchor, campos, neural_opacity, mask, count, first, total, block_scratch,
+                             (hipStream_t)stream),
             "decode count");
     return GSR_OK;
 }

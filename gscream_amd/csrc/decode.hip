@@ -9,10 +9,9 @@
 // but the compacted per-Gaussian outputs reaches HBM in the forward.
 //
 // Mapping.  Thread = anchor.  The MLP weights are wave-uniform operands: rows are fetched with scalar loads and
-// feed v_fma with an SGPR source, so a multiply-accumulate is one VALU op per 64 anchors.  Layer 1 walks its 32 rows
-// in a real loop (36 unrolled FMAs per row against the register-resident input) and parks each hidden unit in LDS
-// ([32][256], conflict-free); layer 2 pulls the 32 hidden units back into registers once and walks its output rows in
-// a real loop -- no dynamically indexed register arrays, ~70 FMA bodies of code instead of 8 400.
+// feed v_fma with an SGPR source, so a multiply-accumulate is one VALU op per 64 anchors.  Layer 1 (32 x 36) is fully
+// unrolled against the register-resident input -- every index is a compile-time constant and the scalar loads can be
+// batched far ahead of their use; layer 2 walks its output rows in a real loop against the 32 hidden registers.  No LDS.
 //   pass A  gsd_count_kernel : opacity MLP only -> neural_opacity[N*K], mask[N*K], per-anchor survivor count
 //   scan    gsd_scan_kernel  : exclusive scan of the counts (one block; N ~ 2e5) -> first output row per anchor, total
 //   pass B  gsd_emit_kernel  : all four MLPs, writes the surviving offsets' rows in the reference's order
@@ -57,23 +56,19 @@ __device__ __forceinline__ void gsd_input(const float* __restrict__ feat, const 
     x[32] = vx / dist; x[33] = vy / dist; x[34] = vz / dist; x[35] = dist;
 }
 
-// layer 1 of MLP m: hidden units -> LDS column of this thread (post-ReLU); hs is [GSD_HID][GSD_THREADS]
-__device__ __forceinline__ void gsd_layer1(const GsdMlps& P, int m, const float x[GSD_IN], float* hs)
+// layer 1 of MLP m, fully unrolled into registers (post-ReLU).  The 32 x 36 weights arrive through scalar loads that
+// the compiler is free to batch far ahead of their use (limited by the SGPR file only); no LDS, no dynamic indices.
+__device__ __forceinline__ void gsd_layer1(const GsdMlps& P, int m, const float x[GSD_IN], float h[GSD_HID])
 {
     const float* __restrict__ w = P.w1[m];
     const float* __restrict__ b = P.b1[m];
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < GSD_HID; j++) {
         float s = b[j];
 #pragma unroll
         for (int i = 0; i < GSD_IN; i++) s += w[j * GSD_IN + i] * x[i];
-        hs[j * GSD_THREADS + threadIdx.x] = fmaxf(s, 0.0f);
+        h[j] = fmaxf(s, 0.0f);
     }
-}
-__device__ __forceinline__ void gsd_load_hidden(const float* hs, float h[GSD_HID])
-{
-#pragma unroll
-    for (int j = 0; j < GSD_HID; j++) h[j] = hs[j * GSD_THREADS + threadIdx.x];
 }
 __device__ __forceinline__ float gsd_out(const GsdMlps& P, int m, int o, const float h[GSD_HID])
 {
@@ -89,44 +84,67 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
                                                                 const float* __restrict__ anchor,
                                                                 const float* __restrict__ campos,
                                                                 float* __restrict__ neural_opacity,
-                                                                uint8_t* __restrict__ mask, uint8_t* __restrict__ count)
+                                                                uint8_t* __restrict__ mask, uint8_t* __restrict__ count,
+                                                                uint32_t* __restrict__ block_sum)
 {
-    __shared__ float hs[GSD_HID * GSD_THREADS];
+    __shared__ uint32_t bs;
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
-    if (n >= N) return;
-    float x[GSD_IN], dist, h[GSD_HID];
-    gsd_input(feat, anchor, campos, n, x, dist);
-    gsd_layer1(P, 0, x, hs);
-    gsd_load_hidden(hs, h);
+    if (threadIdx.x == 0) bs = 0u;
+    __syncthreads();
     int c = 0;
+    if (n < N) {
+        float x[GSD_IN], dist, h[GSD_HID];
+        gsd_input(feat, anchor, campos, n, x, dist);
+        gsd_layer1(P, 0, x, h);
 #pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        const float op = tanhf(gsd_out(P, 0, k, h));
-        const bool keep = op > 0.0f;  // gaussian_renderer/__init__.py:59
-        neural_opacity[(size_t)n * K + k] = op;
-        mask[(size_t)n * K + k] = keep ? 1 : 0;
-        c += keep ? 1 : 0;
+        for (int k = 0; k < K; k++) {
+            const float op = tanhf(gsd_out(P, 0, k, h));
+            const bool keep = op > 0.0f;  // gaussian_renderer/__init__.py:59
+            neural_opacity[(size_t)n * K + k] = op;
+            mask[(size_t)n * K + k] = keep ? 1 : 0;
+            c += keep ? 1 : 0;
+        }
+        count[n] = (uint8_t)c;
     }
-    count[n] = (uint8_t)c;
+    // survivors of this block of 256 anchors: the scan below only has to cover N/256 block totals
+    const uint32_t ws = gsr_wave_scan_add((uint32_t)c);
+    if ((threadIdx.x & 63) == 63 && ws != 0u) atomicAdd(&bs, ws);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = bs;
 }
 
-// ---- exclusive scan of the per-anchor counts (single block of 1024; each thread owns a contiguous chunk) ---------
-__global__ void __launch_bounds__(1024) gsd_scan_kernel(int N, const uint8_t* __restrict__ count, uint32_t* __restrict__ first,
+// ---- exclusive scan of the block totals (single block of 1024; thread i owns a contiguous run of them) -------------
+__global__ void __launch_bounds__(1024) gsd_scan_kernel(int nblocks, uint32_t* __restrict__ block_sum /* in place -> exclusive */,
                                                         uint32_t* __restrict__ total)
 {
     __shared__ uint32_t wsum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (N + 1023) / 1024, i0 = threadIdx.x * per;
+    const int per = (nblocks + 1023) / 1024, i0 = threadIdx.x * per;
     uint32_t s = 0;
-    for (int i = 0; i < per; i++) s += i0 + i < N ? count[i0 + i] : 0u;
+    for (int i = 0; i < per; i++) s += i0 + i < nblocks ? block_sum[i0 + i] : 0u;
     const uint32_t incl = gsr_wave_scan_add(s);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t run = incl - s, tot = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) { const uint32_t sw = wsum[w]; run += w < wave ? sw : 0u; tot += sw; }
-    for (int i = 0; i < per && i0 + i < N; i++) { first[i0 + i] = run; run += count[i0 + i]; }
+    for (int i = 0; i < per && i0 + i < nblocks; i++) { const uint32_t v = block_sum[i0 + i]; block_sum[i0 + i] = run; run += v; }
     if (threadIdx.x == 0) total[0] = tot;
+}
+
+// first output row of every anchor = its block's base + the exclusive scan of the counts inside the block
+__global__ void __launch_bounds__(GSD_THREADS) gsd_first_kernel(int N, const uint8_t* __restrict__ count,
+                                                                const uint32_t* __restrict__ block_base, uint32_t* __restrict__ first)
+{
+    __shared__ uint32_t wsum[GSD_THREADS / 64];
+    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
+    const uint32_t c = n < N ? count[n] : 0u;
+    const uint32_t incl = gsr_wave_scan_add(c);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = block_base[blockIdx.x] + incl - c;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
+    if (n < N) first[n] = run;
 }
 
 // ---- pass B: full decode, compacted output ------------------------------------------------------------------------
@@ -137,7 +155,6 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
     const uint32_t* __restrict__ first, float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity, float* __restrict__ uncertainty,
     float* __restrict__ scaling, float* __restrict__ rot)
 {
-    __shared__ float hs[GSD_HID * GSD_THREADS];
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
     float x[GSD_IN], dist, h[GSD_HID];
@@ -162,16 +179,14 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
         xyz[3 * (size_t)r + 1] = ay + of[1] * gs[1];
         xyz[3 * (size_t)r + 2] = az + of[2] * gs[2];
     }
-    gsd_layer1(P, 1, x, hs);
-    gsd_load_hidden(hs, h);
+    gsd_layer1(P, 1, x, h);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         if (!((keep >> k) & 1u)) continue;
         const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
         uncertainty[r] = gsd_sigmoid(gsd_out(P, 1, k, h));
     }
-    gsd_layer1(P, 2, x, hs);
-    gsd_load_hidden(hs, h);
+    gsd_layer1(P, 2, x, h);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         if (!((keep >> k) & 1u)) continue;
@@ -179,8 +194,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
 #pragma unroll
         for (int c = 0; c < 3; c++) color[3 * (size_t)r + c] = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
     }
-    gsd_layer1(P, 3, x, hs);
-    gsd_load_hidden(hs, h);
+    gsd_layer1(P, 3, x, h);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         if (!((keep >> k) & 1u)) continue;
@@ -199,9 +213,10 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
 // ---- backward -------------------------------------------------------------------------------------------------------
 // Per anchor: upstream gradients of its surviving rows -> d(out) of the four second layers -> d(hidden) -> d(input).
 // Writes d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3], d_gscale[N,6] and, for the weight-gradient GEMMs of the caller,
-//   D2[N, 12K] (opacity K | uncertainty K | color 3K | cov 7K)   = dL/d(second-layer pre-activations)
-//   D1[N, 128], H[N, 128]  (four blocks of 32)                    = dL/d(first-layer pre-activations), hidden activations
-//   X [N, 36]                                                     = the MLP input
+//   D2[12K, N] (opacity K | uncertainty K | color 3K | cov 7K)   = dL/d(second-layer pre-activations)
+//   D1[128, N], H[128, N]  (four blocks of 32)                    = dL/d(first-layer pre-activations), hidden activations
+//   X [36, N]                                                     = the MLP input
+// all feature-major, so that the 64 anchors of a wave store 64 consecutive floats
 __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
     int N, int K, GsdMlps P, const float* __restrict__ feat, const float* __restrict__ anchor,
     const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
@@ -211,15 +226,12 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
     float* __restrict__ d_anchor, float* __restrict__ d_offsets, float* __restrict__ d_gscale, float* __restrict__ D2,
     float* __restrict__ D1, float* __restrict__ Hout, float* __restrict__ Xout)
 {
-    __shared__ float hs[GSD_HID * GSD_THREADS];   // hidden activations of the current MLP
-    __shared__ float ds[GSD_HID * GSD_THREADS];   // dL/d(hidden) accumulators of the current MLP
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
-    const int OUT2 = 12 * K;
     float x[GSD_IN], dist, h[GSD_HID], dx[GSD_IN];
     gsd_input(feat, anchor, campos, n, x, dist);
 #pragma unroll
-    for (int i = 0; i < GSD_IN; i++) { dx[i] = 0.f; Xout[(size_t)n * GSD_IN + i] = x[i]; }
+    for (int i = 0; i < GSD_IN; i++) { dx[i] = 0.f; Xout[(size_t)i * N + n] = x[i]; }
     uint32_t keep = 0;
     for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
     const uint32_t row0 = first[n];
@@ -242,10 +254,12 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
 
 #pragma unroll 1
     for (int m = 0; m < 4; m++) {
-        gsd_layer1(P, m, x, hs);
-        gsd_load_hidden(hs, h);
+        gsd_layer1(P, m, x, h);
 #pragma unroll
-        for (int j = 0; j < GSD_HID; j++) { ds[j * GSD_THREADS + threadIdx.x] = 0.f; Hout[(size_t)n * 128 + m * 32 + j] = h[j]; }
+        for (int j = 0; j < GSD_HID; j++) Hout[(size_t)(m * 32 + j) * N + n] = h[j];
+        float dh[GSD_HID];  // dL/d(hidden), accumulated in registers (constant indices: the j loops below are unrolled)
+#pragma unroll
+        for (int j = 0; j < GSD_HID; j++) dh[j] = 0.f;
         const int per = m == 0 || m == 1 ? 1 : (m == 2 ? 3 : 7);
         const int out_base = m == 0 ? 0 : (m == 1 ? K : (m == 2 ? 2 * K : 5 * K));
 #pragma unroll 1
@@ -289,20 +303,20 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
             for (int c = 0; c < 7; c++) {
                 if (c >= per) break;
                 const int o = per * k + c;
-                D2[(size_t)n * OUT2 + out_base + o] = dz[c];
+                D2[(size_t)(out_base + o) * N + n] = dz[c];
                 if (dz[c] != 0.0f) {
                     const float* __restrict__ w = P.w2[m] + o * GSD_HID;
 #pragma unroll
-                    for (int j = 0; j < GSD_HID; j++) ds[j * GSD_THREADS + threadIdx.x] += w[j] * dz[c];
+                    for (int j = 0; j < GSD_HID; j++) dh[j] += w[j] * dz[c];
                 }
             }
         }
-        // through the ReLU and the first layer: d(pre1)[j] = ds[j] * (h[j] > 0);  dx += W1^T d(pre1)
+        // through the ReLU and the first layer: d(pre1)[j] = dh[j] * (h[j] > 0);  dx += W1^T d(pre1)   (fully unrolled)
         const float* __restrict__ w1 = P.w1[m];
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < GSD_HID; j++) {
-            const float d1 = hs[j * GSD_THREADS + threadIdx.x] > 0.0f ? ds[j * GSD_THREADS + threadIdx.x] : 0.0f;
-            D1[(size_t)n * 128 + m * 32 + j] = d1;
+            const float d1 = h[j] > 0.0f ? dh[j] : 0.0f;
+            D1[(size_t)(m * 32 + j) * N + n] = d1;
 #pragma unroll
             for (int i = 0; i < GSD_IN; i++) dx[i] += w1[j * GSD_IN + i] * d1;
         }
@@ -333,12 +347,14 @@ static GsdMlps gsd_pack(const float* const* w)  // w[16] = {w1[4], b1[4], w2[4],
 
 hipError_t gsd_launch_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
                             const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
-                            uint32_t* total, hipStream_t stream)
+                            uint32_t* total, uint32_t* block_scratch, hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsd_count_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
-                       gsd_pack(weights), feat, anchor, campos, neural_opacity, mask, count);
-    hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, N, count, first, total);
+    const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
+    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), feat, anchor, campos,
+                       neural_opacity, mask, count, block_scratch);
+    hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, block_scratch, total);
+    hipLaunchKernelGGL(gsd_first_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, count, block_scratch, first);
     return hipGetLastError();
 }
 

@@ -193,7 +193,7 @@ hipError_t gsk_launch(int P, const float* points, float* mean_dist2, void* works
 // ---- decode.hip ----
 hipError_t gsd_launch_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
                             const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
-                            uint32_t* total, hipStream_t stream);
+                            uint32_t* total, uint32_t* block_scratch, hipStream_t stream);
 hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor,
                            const float* offsets, const float* gscale, const float* campos, const float* neural_opacity,
                            const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,

@@ -52,9 +52,10 @@ class _Decode(torch.autograd.Function):
             count = torch.empty((max(N, 1),), dtype=torch.uint8, device=dev)
             first = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
             total = torch.zeros((1,), dtype=torch.int32, device=dev)
+            scratch = torch.empty((N // 256 + 2,), dtype=torch.int32, device=dev)
             _native.check(lib.gsr_decode_count(N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(cam_c),
                                                _native.ptr(nop), _native.ptr(mask), _native.ptr(count), _native.ptr(first),
-                                               _native.ptr(total), _stream()), "gsr_decode_count")
+                                               _native.ptr(total), _native.ptr(scratch), _stream()), "gsr_decode_count")
             M = int(total.item())  # the reference's boolean-mask indexing synchronises here as well
             e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
             xyz, color, opacity, unc, scaling, rot = e(M, 3), e(M, 3), e(M, 1), e(M, 1), e(M, 3), e(M, 4)
@@ -81,28 +82,46 @@ class _Decode(torch.autograd.Function):
         with torch.cuda.device(dev):
             e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
             d_feat, d_anchor, d_off, d_gs = e(N, 32), e(N, 3), e(N, K, 3), e(N, 6)
-            D2, D1, H, X = e(N, 12 * K), e(N, 128), e(N, 128), e(N, 36)
+            D2, D1, H, X = e(12 * K, N), e(128, N), e(128, N), e(36, N)  # feature-major: coalesced stores, D @ A^T GEMMs
             _native.check(lib.gsr_decode_backward(
                 N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c), _native.ptr(cam_c),
                 _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
                 _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
                 _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(D2), _native.ptr(D1), _native.ptr(H), _native.ptr(X),
                 _stream()), "gsr_decode_backward")
-            # weight gradients: plain library GEMMs over the per-anchor deltas (delta^T @ activations)
+            # weight gradients: two plain library GEMMs over the per-anchor deltas, D @ A^T with the anchors as the
+            # reduction dimension (split-K through bmm: a [120 x 2e5] x [2e5 x 128] product is all reduction), whose
+            # diagonal blocks are the four MLPs' gradients; biases are row sums.
+            G2 = _reduce_gemm(D2, H)          # [12K, 128]
+            G1 = _reduce_gemm(D1, X)          # [128, 36]
+            s2, s1 = D2.sum(1), D1.sum(1)
             outs = (K, K, 3 * K, 7 * K)
             base = (0, K, 2 * K, 5 * K)
             gw1, gb1, gw2, gb2 = [], [], [], []
             for m in range(4):
-                d2 = D2[:, base[m]:base[m] + outs[m]]
-                d1 = D1[:, 32 * m:32 * m + 32]
-                gw2.append(d2.t() @ H[:, 32 * m:32 * m + 32])
-                gb2.append(d2.sum(0))
-                gw1.append(d1.t() @ X)
-                gb1.append(d1.sum(0))
+                gw2.append(G2[base[m]:base[m] + outs[m], 32 * m:32 * m + 32])
+                gb2.append(s2[base[m]:base[m] + outs[m]])
+                gw1.append(G1[32 * m:32 * m + 32])
+                gb1.append(s1[32 * m:32 * m + 32])
         grads_w = gw1 + gb1 + gw2 + gb2
         sh = ctx.in_shapes
         return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None,
                 *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
+
+
+def _reduce_gemm(D, A, chunk=1024):
+    """D[a, N] @ A[b, N]^T with N (anchors) as the reduction dimension, as a batched GEMM over N/chunk slices."""
+    N = D.shape[1]
+    S = N // chunk
+    if S < 8:
+        return D @ A.t()
+    main = S * chunk
+    d = D[:, :main].reshape(D.shape[0], S, chunk).permute(1, 0, 2)
+    a = A[:, :main].reshape(A.shape[0], S, chunk).permute(1, 2, 0)
+    out = torch.bmm(d, a).sum(0)
+    if main < N:
+        out = out + D[:, main:] @ A[:, main:].t()
+    return out
 
 
 def _mlp_tensors(mlp):

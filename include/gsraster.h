@@ -183,15 +183,17 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * post-processing.  N anchors, K = n_offsets <= 10, feat_dim = 32.  All pointers are device pointers, fp32
  * contiguous: feat[N,32], anchor[N,3], offsets[N,K,3], grid_scaling[N,6] (= exp(_scaling)), campos[3].
  * weights[16] = { w1[4], b1[4], w2[4], b2[4] } for the MLPs {opacity, uncertainty, color, cov} (torch Linear layout).
- *   gsr_decode_count : neural_opacity[N*K], mask[N*K] (u8), count[N] (u8), first[N] (u32, exclusive scan), total[1] (u32)
+ *   gsr_decode_count : neural_opacity[N*K], mask[N*K] (u8), count[N] (u8), first[N] (u32, exclusive scan), total[1] (u32);
+ *                      block_scratch: ceil(N/256) u32 of scratch
  *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
  *                      scaling[M,3], rot[M,4]
  *   gsr_decode_backward : upstream gradients of those rows -> d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3],
- *                      d_grid_scaling[N,6], plus the per-anchor layer deltas D2[N,12K] / D1[N,128] and activations H[N,128],
- *                      X[N,36] from which the caller forms the weight gradients with plain GEMMs (D^T @ A).
+ *                      d_grid_scaling[N,6], plus the per-anchor layer deltas D2[12K,N] / D1[128,N] and activations H[128,N],
+ *                      X[36,N] (feature-major) from which the caller forms the weight gradients with plain GEMMs (D @ A^T).
  */
 int gsr_decode_count(int N, int K, const float* const* weights, const float* feat, const float* anchor, const float* campos,
-                     float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first, uint32_t* total, void* stream);
+                     float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first, uint32_t* total,
+                     uint32_t* block_scratch, void* stream);
 int gsr_decode_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor, const float* offsets,
                     const float* grid_scaling, const float* campos, const float* neural_opacity /* from gsr_decode_count */,
                     const uint8_t* mask, const uint32_t* first, float* xyz,
