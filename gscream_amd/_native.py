@@ -95,11 +95,11 @@ def load():
     lib.gsr_knn_mean_dist2.restype = _c_int
     lib.gsr_knn_mean_dist2.argtypes = [_c_int, _vp, _vp, _vp, _vp]
     lib.gsr_decode_count.restype = _c_int
-    lib.gsr_decode_count.argtypes = [_c_int, _c_int] + [_vp] * 11
+    lib.gsr_decode_count.argtypes = [_c_int, _c_int] + [_vp] * 12
     lib.gsr_decode_emit.restype = _c_int
-    lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 16
+    lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 17
     lib.gsr_decode_backward.restype = _c_int
-    lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 23
+    lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 24
     _lib = lib
     return lib
 

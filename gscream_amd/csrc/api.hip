@@ -434,7 +434,7 @@ static int gsr_check_decode(int N, int K, const float* const* weights)
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
                                 const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
                                 uint32_t* total, uint32_t* block_scratch, void* stream)
 {
@@ -444,13 +444,13 @@ extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const
     if (N == 0) { GSR_HIP(hipMemsetAsync(total, 0, 4, (hipStream_t)stream), "decode total"); return GSR_OK; }
     if (!feat || !anchor || !campos || !neural_opacity || !mask || !count || !first || !block_scratch)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_count(N, K, weights, feat, anchor, campos, neural_opacity, mask, count, first, total, block_scratch,
+    GSR_HIP(gsd_launch_count(N, K, weights, visible, feat, anchor, campos, neural_opacity, mask, count, first, total, block_scratch,
                              (hipStream_t)stream),
             "decode count");
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
                                const float* offsets, const float* grid_scaling, const float* campos,
                                const float* neural_opacity, const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity, float* uncertainty,
                                float* scaling, float* rot, void* stream)
@@ -460,12 +460,12 @@ extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const 
     if (N == 0) return GSR_OK;
     if (!feat || !anchor || !offsets || !grid_scaling || !campos || !neural_opacity || !mask || !first)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_emit(N, K, weights, feat, anchor, offsets, grid_scaling, campos, neural_opacity, mask, first, xyz, color, opacity,
+    GSR_HIP(gsd_launch_emit(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, neural_opacity, mask, first, xyz, color, opacity,
                             uncertainty, scaling, rot, (hipStream_t)stream), "decode emit");
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
                                    const float* offsets, const float* grid_scaling, const float* campos,
                                    const uint8_t* mask, const uint32_t* first, const float* g_xyz, const float* g_color,
                                    const float* g_opacity, const float* g_uncertainty, const float* g_scaling,
@@ -478,7 +478,7 @@ extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, co
     if (!feat || !anchor || !offsets || !grid_scaling || !campos || !mask || !first || !d_feat || !d_anchor || !d_offsets ||
         !d_grid_scaling || !D2 || !D1 || !H || !X)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_backward(N, K, weights, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
+    GSR_HIP(gsd_launch_backward(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
                                 g_opacity, g_uncertainty, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_grid_scaling, D2,
                                 D1, H, X, (hipStream_t)stream), "decode backward");
     return GSR_OK;

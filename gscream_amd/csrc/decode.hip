@@ -43,15 +43,16 @@ __device__ __forceinline__ float gsd_sigmoid(float x) { return 1.0f / (1.0f + ex
 
 // input vector of one anchor (gaussian_renderer/__init__.py:30-47): [feat(32), ob_view(3), ob_dist]
 __device__ __forceinline__ void gsd_input(const float* __restrict__ feat, const float* __restrict__ anchor,
-                                          const float* __restrict__ campos, int n, float x[GSD_IN], float& dist)
+                                          const float* __restrict__ campos, int a /* row in the model's tensors */,
+                                          float x[GSD_IN], float& dist)
 {
-    const float4* f4 = reinterpret_cast<const float4*>(feat + (size_t)n * GSD_F);
+    const float4* f4 = reinterpret_cast<const float4*>(feat + (size_t)a * GSD_F);
 #pragma unroll
     for (int i = 0; i < GSD_F / 4; i++) {
         const float4 v = f4[i];
         x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
     }
-    const float vx = anchor[3 * (size_t)n] - campos[0], vy = anchor[3 * (size_t)n + 1] - campos[1], vz = anchor[3 * (size_t)n + 2] - campos[2];
+    const float vx = anchor[3 * (size_t)a] - campos[0], vy = anchor[3 * (size_t)a + 1] - campos[1], vz = anchor[3 * (size_t)a + 2] - campos[2];
     dist = sqrtf(vx * vx + vy * vy + vz * vz);
     x[32] = vx / dist; x[33] = vy / dist; x[34] = vz / dist; x[35] = dist;
 }
@@ -80,7 +81,8 @@ __device__ __forceinline__ float gsd_out(const GsdMlps& P, int m, int o, const f
 }
 
 // ---- pass A: opacity MLP, mask, count ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, GsdMlps P, const float* __restrict__ feat,
+__global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, GsdMlps P, const int32_t* __restrict__ vis,
+                                                                const float* __restrict__ feat,
                                                                 const float* __restrict__ anchor,
                                                                 const float* __restrict__ campos,
                                                                 float* __restrict__ neural_opacity,
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
     int c = 0;
     if (n < N) {
         float x[GSD_IN], dist, h[GSD_HID];
-        gsd_input(feat, anchor, campos, n, x, dist);
+        gsd_input(feat, anchor, campos, vis ? vis[n] : n, x, dist);
         gsd_layer1(P, 0, x, h);
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_first_kernel(int N, const uin
 
 // ---- pass B: full decode, compacted output ------------------------------------------------------------------------
 __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
-    int N, int K, GsdMlps P, const float* __restrict__ feat, const float* __restrict__ anchor,
+    int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
     const float* __restrict__ offsets /*[N,K,3]*/, const float* __restrict__ gscale /*[N,6]*/,
     const float* __restrict__ campos, const float* __restrict__ neural_opacity, const uint8_t* __restrict__ mask,
     const uint32_t* __restrict__ first, float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity, float* __restrict__ uncertainty,
@@ -157,16 +159,17 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
 {
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
+    const int a = vis ? vis[n] : n;  // visible-anchor gather (gaussian_renderer/__init__.py:25-28) folded in
     float x[GSD_IN], dist, h[GSD_HID];
-    gsd_input(feat, anchor, campos, n, x, dist);
+    gsd_input(feat, anchor, campos, a, x, dist);
     uint32_t keep = 0;
     for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
     if (keep == 0u) return;
     const uint32_t row0 = first[n];
-    const float ax = anchor[3 * (size_t)n], ay = anchor[3 * (size_t)n + 1], az = anchor[3 * (size_t)n + 2];
+    const float ax = anchor[3 * (size_t)a], ay = anchor[3 * (size_t)a + 1], az = anchor[3 * (size_t)a + 2];
     float gs[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)n + i];
+    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)a + i];
 
     // opacity = neural_opacity[mask] (:63): copied from pass A, bit for bit; geometry of the offsets
 #pragma unroll 1
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
         if (!((keep >> k) & 1u)) continue;
         const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
         opacity[r] = neural_opacity[(size_t)n * K + k];
-        const float* of = offsets + ((size_t)n * K + k) * 3;
+        const float* of = offsets + ((size_t)a * K + k) * 3;
         xyz[3 * (size_t)r] = ax + of[0] * gs[0];       // :94-95
         xyz[3 * (size_t)r + 1] = ay + of[1] * gs[1];
         xyz[3 * (size_t)r + 2] = az + of[2] * gs[2];
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
 //   X [36, N]                                                     = the MLP input
 // all feature-major, so that the 64 anchors of a wave store 64 consecutive floats
 __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
-    int N, int K, GsdMlps P, const float* __restrict__ feat, const float* __restrict__ anchor,
+    int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
     const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
     const uint8_t* __restrict__ mask, const uint32_t* __restrict__ first, const float* __restrict__ g_xyz,
     const float* __restrict__ g_color, const float* __restrict__ g_opacity, const float* __restrict__ g_unc,
@@ -228,8 +231,9 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
 {
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
+    const int a = vis ? vis[n] : n;  // gradients go to row a of the model-sized tensors (pre-zeroed by the caller)
     float x[GSD_IN], dist, h[GSD_HID], dx[GSD_IN];
-    gsd_input(feat, anchor, campos, n, x, dist);
+    gsd_input(feat, anchor, campos, a, x, dist);
 #pragma unroll
     for (int i = 0; i < GSD_IN; i++) { dx[i] = 0.f; Xout[(size_t)i * N + n] = x[i]; }
     uint32_t keep = 0;
@@ -237,14 +241,14 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
     const uint32_t row0 = first[n];
     float gs[6], dgs[6] = { 0, 0, 0, 0, 0, 0 }, da[3] = { 0, 0, 0 };
 #pragma unroll
-    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)n + i];
+    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)a + i];
 
     // geometry of the offsets: xyz = anchor + offset * gs[0:3]
     for (int k = 0; k < K; k++) {
-        float* dof = d_offsets + ((size_t)n * K + k) * 3;
+        float* dof = d_offsets + ((size_t)a * K + k) * 3;
         if (!((keep >> k) & 1u)) { dof[0] = dof[1] = dof[2] = 0.f; continue; }
         const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        const float* of = offsets + ((size_t)n * K + k) * 3;
+        const float* of = offsets + ((size_t)a * K + k) * 3;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float g = g_xyz[3 * (size_t)r + c];
@@ -323,7 +327,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
     }
     // input gradients: feat, and the view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist)
 #pragma unroll
-    for (int i = 0; i < GSD_F; i++) d_feat[(size_t)n * GSD_F + i] = dx[i];
+    for (int i = 0; i < GSD_F; i++) d_feat[(size_t)a * GSD_F + i] = dx[i];
     {
         const float ux = x[32], uy = x[33], uz = x[34];
         const float gdot = dx[32] * ux + dx[33] * uy + dx[34] * uz;
@@ -332,9 +336,9 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
         da[2] += (dx[34] - uz * gdot) / dist + dx[35] * uz;
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) d_anchor[3 * (size_t)n + c] = da[c];
+    for (int c = 0; c < 3; c++) d_anchor[3 * (size_t)a + c] = da[c];
 #pragma unroll
-    for (int i = 0; i < 6; i++) d_gscale[6 * (size_t)n + i] = dgs[i];
+    for (int i = 0; i < 6; i++) d_gscale[6 * (size_t)a + i] = dgs[i];
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -345,32 +349,32 @@ static GsdMlps gsd_pack(const float* const* w)  // w[16] = {w1[4], b1[4], w2[4],
     return P;
 }
 
-hipError_t gsd_launch_count(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
                             const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
                             uint32_t* total, uint32_t* block_scratch, hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
     const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
-    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), feat, anchor, campos,
+    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), vis, feat, anchor, campos,
                        neural_opacity, mask, count, block_scratch);
     hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, block_scratch, total);
     hipLaunchKernelGGL(gsd_first_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, count, block_scratch, first);
     return hipGetLastError();
 }
 
-hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
                            const float* offsets, const float* gscale, const float* campos, const float* neural_opacity,
                            const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsd_emit_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
-                       gsd_pack(weights), feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
+                       gsd_pack(weights), vis, feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
                        opacity, uncertainty, scaling, rot);
     return hipGetLastError();
 }
 
-hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
                                const float* offsets, const float* gscale, const float* campos, const uint8_t* mask,
                                const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
                                const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
@@ -379,7 +383,7 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
 {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsd_backward_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
-                       gsd_pack(weights), feat, anchor, offsets, gscale, campos, mask, first, g_xyz, g_color, g_opacity,
+                       gsd_pack(weights), vis, feat, anchor, offsets, gscale, campos, mask, first, g_xyz, g_color, g_opacity,
                        g_unc, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_gscale, D2, D1, H, X);
     return hipGetLastError();
 }

@@ -6,8 +6,8 @@ the reference's GaussianModel does: `_anchor_feat`, `get_anchor`, `_offset`, `ge
 `use_feat_bank`, `get_opacity_mlp`, `get_uncertainty_mlp`, `get_color_mlp`, `get_cov_mlp`
 (nn.Sequential(Linear(36,32), ReLU, Linear(32,out)[, act]) as in scene/gaussian_model.py:118-144).
 
-The visible-anchor gather (:25-28) stays in torch (four index ops); everything after it -- view vector, four MLPs,
-opacity mask, boolean-mask compaction, post-processing -- runs in `gsr_decode_count` / `gsr_decode_emit`
+The visible-anchor gather (:25-28) is folded into the kernels (the mask becomes a row list once); view vector, four
+MLPs, opacity mask, boolean-mask compaction, post-processing run in `gsr_decode_count` / `gsr_decode_emit`
 (include/gsraster.h), and the backward in `gsr_decode_backward` + eight plain GEMMs for the weight gradients.
 `use_feat_bank=True` (off in every GScream config, arguments/__init__.py:57) raises NotImplementedError.
 No CPU fallback."""
@@ -34,11 +34,13 @@ class _Decode(torch.autograd.Function):
     {w1[4], b1[4], w2[4], b2[4]} for the MLPs {opacity, uncertainty, color, cov}."""
 
     @staticmethod
-    def forward(ctx, feat, anchor, offsets, gscale, campos, *weights):
+    def forward(ctx, feat, anchor, offsets, gscale, campos, vis_idx, *weights):
         lib = _native.load()
         if not feat.is_cuda:
             raise RuntimeError("gscream_amd.neural_gaussians: tensors must be on a HIP device (no CPU fallback)")
-        N, K = int(anchor.shape[0]), int(offsets.shape[1])
+        K = int(offsets.shape[1])
+        N = int(anchor.shape[0]) if vis_idx is None else int(vis_idx.shape[0])  # anchors decoded
+        vis = None if vis_idx is None else vis_idx.detach().contiguous().int()
         if feat.shape[1] != 32:
             raise NotImplementedError("feat_dim must be 32 (arguments/__init__.py:50)")
         dev = feat.device
@@ -53,17 +55,18 @@ class _Decode(torch.autograd.Function):
             first = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
             total = torch.zeros((1,), dtype=torch.int32, device=dev)
             scratch = torch.empty((N // 256 + 2,), dtype=torch.int32, device=dev)
-            _native.check(lib.gsr_decode_count(N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(cam_c),
+            _native.check(lib.gsr_decode_count(N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(cam_c),
                                                _native.ptr(nop), _native.ptr(mask), _native.ptr(count), _native.ptr(first),
                                                _native.ptr(total), _native.ptr(scratch), _stream()), "gsr_decode_count")
             M = int(total.item())  # the reference's boolean-mask indexing synchronises here as well
             e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
             xyz, color, opacity, unc, scaling, rot = e(M, 3), e(M, 3), e(M, 1), e(M, 1), e(M, 3), e(M, 4)
-            _native.check(lib.gsr_decode_emit(N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c),
+            _native.check(lib.gsr_decode_emit(N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c),
                                               _native.ptr(gs_c), _native.ptr(cam_c), _native.ptr(nop), _native.ptr(mask), _native.ptr(first),
                                               _native.ptr(xyz), _native.ptr(color), _native.ptr(opacity), _native.ptr(unc),
                                               _native.ptr(scaling), _native.ptr(rot), _stream()), "gsr_decode_emit")
         ctx.save_for_backward(feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws)
+        ctx.vis = vis
         ctx.dims = (N, K, M)
         ctx.in_shapes = [tuple(t.shape) for t in (feat, anchor, offsets, gscale)] + [tuple(w.shape) for w in weights]
         bmask = mask.bool()
@@ -81,11 +84,14 @@ class _Decode(torch.autograd.Function):
         warr = _weight_array(ws)
         with torch.cuda.device(dev):
             e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-            d_feat, d_anchor, d_off, d_gs = e(N, 32), e(N, 3), e(N, K, 3), e(N, 6)
+            vis = ctx.vis
+            full = feat_c.shape[0]  # model-sized gradients; rows outside `vis` stay zero
+            mk = (lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)) if vis is not None else e
+            d_feat, d_anchor, d_off, d_gs = mk(full, 32), mk(full, 3), mk(full, K, 3), mk(full, 6)
             D2, D1, H, X = e(12 * K, N), e(128, N), e(128, N), e(36, N)  # feature-major: coalesced stores, D @ A^T GEMMs
             _native.check(lib.gsr_decode_backward(
-                N, K, warr, _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c), _native.ptr(cam_c),
-                _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
+                N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c),
+                _native.ptr(cam_c), _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
                 _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
                 _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(D2), _native.ptr(D1), _native.ptr(H), _native.ptr(X),
                 _stream()), "gsr_decode_backward")
@@ -105,7 +111,7 @@ class _Decode(torch.autograd.Function):
                 gb1.append(s1[32 * m:32 * m + 32])
         grads_w = gw1 + gb1 + gw2 + gb2
         sh = ctx.in_shapes
-        return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None,
+        return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None, None,
                 *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
 
 
@@ -131,25 +137,23 @@ def _mlp_tensors(mlp):
     return lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias
 
 
-def decode(feat, anchor, offsets, grid_scaling, campos, opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp):
-    """-> xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask for already-gathered anchor tensors."""
+def decode(feat, anchor, offsets, grid_scaling, campos, opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp, visible_idx=None):
+    """-> xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask.  `visible_idx` (int tensor of anchor rows,
+    ascending) folds the reference's visible-anchor gather into the kernels; None decodes every row."""
     t = [_mlp_tensors(m) for m in (opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp)]
     weights = [t[m][i] for i in range(4) for m in range(4)]  # {w1[4], b1[4], w2[4], b2[4]}
-    return _Decode.apply(feat, anchor, offsets, grid_scaling, campos, *weights)
+    return _Decode.apply(feat, anchor, offsets, grid_scaling, campos, visible_idx, *weights)
 
 
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
     if getattr(pc, "use_feat_bank", False):
         raise NotImplementedError("use_feat_bank=True is not implemented (False in every GScream config)")
-    if visible_mask is None:  # gaussian_renderer/__init__.py:20-21
-        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
-    feat = pc._anchor_feat[visible_mask]          # :25-28
-    anchor = pc.get_anchor[visible_mask]
-    grid_offsets = pc._offset[visible_mask]
-    grid_scaling = pc.get_scaling[visible_mask]
+    # gaussian_renderer/__init__.py:20-28: `x[visible_mask]` for four tensors.  Here the mask becomes a row list once
+    # and the kernels read (and, in the backward, write) the model-sized tensors through it; no mask = every row.
+    vis_idx = None if visible_mask is None else torch.nonzero(visible_mask, as_tuple=False).view(-1).int()
     xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask = decode(
-        feat, anchor, grid_offsets, grid_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,
-        pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp)
+        pc._anchor_feat, pc.get_anchor, pc._offset, pc.get_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,
+        pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp, vis_idx)
     if is_training:  # :98-102
         return xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask
     return xyz, color, opacity, uncertainty, scaling, rot

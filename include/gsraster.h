@@ -183,6 +183,9 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * post-processing.  N anchors, K = n_offsets <= 10, feat_dim = 32.  All pointers are device pointers, fp32
  * contiguous: feat[N,32], anchor[N,3], offsets[N,K,3], grid_scaling[N,6] (= exp(_scaling)), campos[3].
  * weights[16] = { w1[4], b1[4], w2[4], b2[4] } for the MLPs {opacity, uncertainty, color, cov} (torch Linear layout).
+ * visible (optional): int32[N] rows of the model-sized tensors to decode -- the visible-anchor gather (:25-28) folded
+ * in; NULL = rows 0..N-1.  With `visible`, feat/anchor/offsets/grid_scaling and the four d_* outputs are MODEL-sized
+ * (the backward writes the visible rows only: pre-zero them).
  *   gsr_decode_count : neural_opacity[N*K], mask[N*K] (u8), count[N] (u8), first[N] (u32, exclusive scan), total[1] (u32);
  *                      block_scratch: ceil(N/256) u32 of scratch
  *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
@@ -191,14 +194,14 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *                      d_grid_scaling[N,6], plus the per-anchor layer deltas D2[12K,N] / D1[128,N] and activations H[128,N],
  *                      X[36,N] (feature-major) from which the caller forms the weight gradients with plain GEMMs (D @ A^T).
  */
-int gsr_decode_count(int N, int K, const float* const* weights, const float* feat, const float* anchor, const float* campos,
+int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor, const float* campos,
                      float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first, uint32_t* total,
                      uint32_t* block_scratch, void* stream);
-int gsr_decode_emit(int N, int K, const float* const* weights, const float* feat, const float* anchor, const float* offsets,
+int gsr_decode_emit(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor, const float* offsets,
                     const float* grid_scaling, const float* campos, const float* neural_opacity /* from gsr_decode_count */,
                     const uint8_t* mask, const uint32_t* first, float* xyz,
                     float* color, float* opacity, float* uncertainty, float* scaling, float* rot, void* stream);
-int gsr_decode_backward(int N, int K, const float* const* weights, const float* feat, const float* anchor,
+int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
                         const float* offsets, const float* grid_scaling, const float* campos, const uint8_t* mask,
                         const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
                         const float* g_uncertainty, const float* g_scaling, const float* g_rot, float* d_feat, float* d_anchor,
