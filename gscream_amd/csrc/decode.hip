@@ -16,10 +16,10 @@
 //   scan    gsd_scan_kernel  : exclusive scan of the counts (one block; N ~ 2e5) -> first output row per anchor, total
 //   pass B  gsd_emit_kernel  : all four MLPs, writes the surviving offsets' rows in the reference's order
 //                              (anchor-major, offset-minor = boolean-mask order)
-//   bwd     gsd_backward_kernel : recomputes the activations, turns the per-Gaussian upstream gradients into
-//                              gradients of feat / anchor / offsets / grid scaling, and writes the per-anchor layer
-//                              deltas + activations; the WEIGHT gradients are then four pairs of plain GEMMs
-//                              (delta^T @ activations) done by the caller with the library GEMM.
+//   bwd     gsd_backward_mlp_kernel<M> x4 : recompute MLP M's activations, turn the per-Gaussian upstream gradients into
+//                              its layer deltas (stored feature-major with the activations for the caller's weight-
+//                              gradient GEMMs, delta @ activations^T);
+//           gsd_backward_input_kernel : W1^T deltas -> gradients of feat / anchor, and the offset / grid-scaling geometry.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -220,30 +220,139 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
 //   D1[128, N], H[128, N]  (four blocks of 32)                    = dL/d(first-layer pre-activations), hidden activations
 //   X [36, N]                                                     = the MLP input
 // all feature-major, so that the 64 anchors of a wave store 64 consecutive floats
-__global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
+// One MLP per launch (template M): keeps the live state at input + hidden + d(hidden) registers, so several
+// waves fit per SIMD (the all-in-one version needed 256 VGPRs + 51 AGPRs and spilled SGPRs: one wave per SIMD).
+template <int M>
+__global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
     int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
-    const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
-    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ first, const float* __restrict__ g_xyz,
-    const float* __restrict__ g_color, const float* __restrict__ g_opacity, const float* __restrict__ g_unc,
-    const float* __restrict__ g_scaling, const float* __restrict__ g_rot, float* __restrict__ d_feat,
-    float* __restrict__ d_anchor, float* __restrict__ d_offsets, float* __restrict__ d_gscale, float* __restrict__ D2,
-    float* __restrict__ D1, float* __restrict__ Hout, float* __restrict__ Xout)
+    const float* __restrict__ gscale, const float* __restrict__ campos, const uint8_t* __restrict__ mask,
+    const uint32_t* __restrict__ first, const float* __restrict__ g_color, const float* __restrict__ g_opacity,
+    const float* __restrict__ g_unc, const float* __restrict__ g_scaling, const float* __restrict__ g_rot,
+    float* __restrict__ d_gscale, float* __restrict__ D2, float* __restrict__ D1, float* __restrict__ Hout,
+    float* __restrict__ Xout)
 {
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
-    const int a = vis ? vis[n] : n;  // gradients go to row a of the model-sized tensors (pre-zeroed by the caller)
-    float x[GSD_IN], dist, h[GSD_HID], dx[GSD_IN];
+    const int a = vis ? vis[n] : n;
+    float x[GSD_IN], dist, h[GSD_HID], dh[GSD_HID];
     gsd_input(feat, anchor, campos, a, x, dist);
+    if (M == 0) {
 #pragma unroll
-    for (int i = 0; i < GSD_IN; i++) { dx[i] = 0.f; Xout[(size_t)i * N + n] = x[i]; }
+        for (int i = 0; i < GSD_IN; i++) Xout[(size_t)i * N + n] = x[i];
+    }
     uint32_t keep = 0;
     for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
     const uint32_t row0 = first[n];
-    float gs[6], dgs[6] = { 0, 0, 0, 0, 0, 0 }, da[3] = { 0, 0, 0 };
+    float gs3[3] = { 0, 0, 0 }, dgs3[3] = { 0, 0, 0 };
+    if (M == 3) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)a + i];
+        for (int c = 0; c < 3; c++) gs3[c] = gscale[6 * (size_t)a + 3 + c];
+    }
+    gsd_layer1(P, M, x, h);
+#pragma unroll
+    for (int j = 0; j < GSD_HID; j++) { Hout[(size_t)(M * 32 + j) * N + n] = h[j]; dh[j] = 0.f; }
+    constexpr int per = M == 0 || M == 1 ? 1 : (M == 2 ? 3 : 7);
+    const int out_base = M == 0 ? 0 : (M == 1 ? K : (M == 2 ? 2 * K : 5 * K));
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        const bool on = (keep >> k) & 1u;
+        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        float dz[per];  // dL/d(pre-activation) of this offset's outputs
+#pragma unroll
+        for (int c = 0; c < per; c++) dz[c] = 0.f;
+        if (on) {
+            if (M == 0) {  // opacity = tanh(z)
+                const float t = tanhf(gsd_out(P, 0, k, h));
+                dz[0] = g_opacity[r] * (1.0f - t * t);
+            } else if (M == 1) {  // sigmoid
+                const float sg = gsd_sigmoid(gsd_out(P, 1, k, h));
+                dz[0] = g_unc[r] * sg * (1.0f - sg);
+            } else if (M == 2) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float sg = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
+                    dz[c % per] = g_color[3 * (size_t)r + c] * sg * (1.0f - sg);
+                }
+            } else {
+                float sr[7];
+#pragma unroll
+                for (int c = 0; c < 7; c++) {
+                    sr[c] = gsd_out(P, 3, 7 * k + c, h);
+                    __builtin_amdgcn_sched_barrier(0);  // one weight row in flight at a time: 7 x 32 live scalars do not fit
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {  // scaling = gs[3+c] * sigmoid(sr[c])
+                    const float sg = gsd_sigmoid(sr[c]), g = g_scaling[3 * (size_t)r + c];
+                    dz[c % per] = g * gs3[c] * sg * (1.0f - sg);
+                    dgs3[c] += g * sg;
+                }
+                // rot = q / max(|q|, eps): d q = (g - rot (rot . g)) / |q|
+                const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);
+                float gq[4], dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) { gq[c] = g_rot[4 * (size_t)r + c]; dot += gq[c] * (sr[3 + c] / nrm); }
+#pragma unroll
+                for (int c = 0; c < 4; c++) dz[(3 + c) % per] = (gq[c] - (sr[3 + c] / nrm) * dot) / nrm;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < per; c++) {
+            const int o = per * k + c;
+            D2[(size_t)(out_base + o) * N + n] = dz[c];
+            const float* __restrict__ w = P.w2[M] + o * GSD_HID;
+#pragma unroll
+            for (int j = 0; j < GSD_HID; j++) dh[j] += w[j] * dz[c];
+            if (per > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GSD_HID; j++) D1[(size_t)(M * 32 + j) * N + n] = h[j] > 0.0f ? dh[j] : 0.0f;  // through the ReLU
+    if (M == 3) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) d_gscale[6 * (size_t)a + 3 + c] = dgs3[c];
+    }
+}
 
-    // geometry of the offsets: xyz = anchor + offset * gs[0:3]
+// dL/d(input) = sum over the four MLPs of W1^T d(pre1) (read back feature-major, coalesced), then feature / anchor
+// gradients; also the geometry part: xyz = anchor + offset * gs[0:3].
+__global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
+    int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ anchor,
+    const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
+    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ first, const float* __restrict__ g_xyz,
+    const float* __restrict__ D1, float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_offsets,
+    float* __restrict__ d_gscale)
+{
+    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const int a = vis ? vis[n] : n;
+    float dx[GSD_IN];
+#pragma unroll
+    for (int i = 0; i < GSD_IN; i++) dx[i] = 0.f;
+#pragma unroll 1
+    for (int m = 0; m < 4; m++) {
+        const float* __restrict__ w1 = P.w1[m];
+#pragma unroll 4
+        for (int j = 0; j < GSD_HID; j++) {
+            const float d1 = D1[(size_t)(m * 32 + j) * N + n];
+#pragma unroll
+            for (int i = 0; i < GSD_IN; i++) dx[i] += w1[j * GSD_IN + i] * d1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GSD_F; i++) d_feat[(size_t)a * GSD_F + i] = dx[i];
+    // view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist)
+    const float vx = anchor[3 * (size_t)a] - campos[0], vy = anchor[3 * (size_t)a + 1] - campos[1], vz = anchor[3 * (size_t)a + 2] - campos[2];
+    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float ux = vx / dist, uy = vy / dist, uz = vz / dist;
+    const float gdot = dx[32] * ux + dx[33] * uy + dx[34] * uz;
+    float da[3] = { (dx[32] - ux * gdot) / dist + dx[35] * ux, (dx[33] - uy * gdot) / dist + dx[35] * uy,
+                    (dx[34] - uz * gdot) / dist + dx[35] * uz };
+    uint32_t keep = 0;
+    for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
+    const uint32_t row0 = first[n];
+    float gs[3], dgs[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 3; c++) gs[c] = gscale[6 * (size_t)a + c];
     for (int k = 0; k < K; k++) {
         float* dof = d_offsets + ((size_t)a * K + k) * 3;
         if (!((keep >> k) & 1u)) { dof[0] = dof[1] = dof[2] = 0.f; continue; }
@@ -255,90 +364,8 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_kernel(
             da[c] += g; dof[c] = g * gs[c]; dgs[c] += g * of[c];
         }
     }
-
-#pragma unroll 1
-    for (int m = 0; m < 4; m++) {
-        gsd_layer1(P, m, x, h);
 #pragma unroll
-        for (int j = 0; j < GSD_HID; j++) Hout[(size_t)(m * 32 + j) * N + n] = h[j];
-        float dh[GSD_HID];  // dL/d(hidden), accumulated in registers (constant indices: the j loops below are unrolled)
-#pragma unroll
-        for (int j = 0; j < GSD_HID; j++) dh[j] = 0.f;
-        const int per = m == 0 || m == 1 ? 1 : (m == 2 ? 3 : 7);
-        const int out_base = m == 0 ? 0 : (m == 1 ? K : (m == 2 ? 2 * K : 5 * K));
-#pragma unroll 1
-        for (int k = 0; k < K; k++) {
-            const bool on = (keep >> k) & 1u;
-            const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-            float dz[7] = { 0, 0, 0, 0, 0, 0, 0 };  // dL/d(pre-activation) of this offset's outputs
-            if (on) {
-                if (m == 0) {  // opacity = tanh(z)
-                    const float t = tanhf(gsd_out(P, 0, k, h));
-                    dz[0] = g_opacity[r] * (1.0f - t * t);
-                } else if (m == 1) {  // sigmoid
-                    const float s = gsd_sigmoid(gsd_out(P, 1, k, h));
-                    dz[0] = g_unc[r] * s * (1.0f - s);
-                } else if (m == 2) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float s = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
-                        dz[c] = g_color[3 * (size_t)r + c] * s * (1.0f - s);
-                    }
-                } else {
-                    float sr[7];
-#pragma unroll
-                    for (int c = 0; c < 7; c++) sr[c] = gsd_out(P, 3, 7 * k + c, h);
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {  // scaling = gs[3+c] * sigmoid(sr[c])
-                        const float s = gsd_sigmoid(sr[c]), g = g_scaling[3 * (size_t)r + c];
-                        dz[c] = g * gs[3 + c] * s * (1.0f - s);
-                        dgs[3 + c] += g * s;
-                    }
-                    // rot = q / max(|q|, eps): d q = (g - rot (rot . g)) / |q|
-                    const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);
-                    float gq[4], dot = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) { gq[c] = g_rot[4 * (size_t)r + c]; dot += gq[c] * (sr[3 + c] / nrm); }
-#pragma unroll
-                    for (int c = 0; c < 4; c++) dz[3 + c] = (gq[c] - (sr[3 + c] / nrm) * dot) / nrm;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 7; c++) {
-                if (c >= per) break;
-                const int o = per * k + c;
-                D2[(size_t)(out_base + o) * N + n] = dz[c];
-                if (dz[c] != 0.0f) {
-                    const float* __restrict__ w = P.w2[m] + o * GSD_HID;
-#pragma unroll
-                    for (int j = 0; j < GSD_HID; j++) dh[j] += w[j] * dz[c];
-                }
-            }
-        }
-        // through the ReLU and the first layer: d(pre1)[j] = dh[j] * (h[j] > 0);  dx += W1^T d(pre1)   (fully unrolled)
-        const float* __restrict__ w1 = P.w1[m];
-#pragma unroll
-        for (int j = 0; j < GSD_HID; j++) {
-            const float d1 = h[j] > 0.0f ? dh[j] : 0.0f;
-            D1[(size_t)(m * 32 + j) * N + n] = d1;
-#pragma unroll
-            for (int i = 0; i < GSD_IN; i++) dx[i] += w1[j * GSD_IN + i] * d1;
-        }
-    }
-    // input gradients: feat, and the view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist)
-#pragma unroll
-    for (int i = 0; i < GSD_F; i++) d_feat[(size_t)a * GSD_F + i] = dx[i];
-    {
-        const float ux = x[32], uy = x[33], uz = x[34];
-        const float gdot = dx[32] * ux + dx[33] * uy + dx[34] * uz;
-        da[0] += (dx[32] - ux * gdot) / dist + dx[35] * ux;
-        da[1] += (dx[33] - uy * gdot) / dist + dx[35] * uy;
-        da[2] += (dx[34] - uz * gdot) / dist + dx[35] * uz;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) d_anchor[3 * (size_t)a + c] = da[c];
-#pragma unroll
-    for (int i = 0; i < 6; i++) d_gscale[6 * (size_t)a + i] = dgs[i];
+    for (int c = 0; c < 3; c++) { d_anchor[3 * (size_t)a + c] = da[c]; d_gscale[6 * (size_t)a + c] = dgs[c]; }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -382,8 +409,14 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
                                hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsd_backward_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
-                       gsd_pack(weights), vis, feat, anchor, offsets, gscale, campos, mask, first, g_xyz, g_color, g_opacity,
-                       g_unc, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_gscale, D2, D1, H, X);
+    const dim3 grid((N + GSD_THREADS - 1) / GSD_THREADS), block(GSD_THREADS);
+    const GsdMlps P = gsd_pack(weights);
+#define GSD_BWD(M)                                                                                                          \
+    hipLaunchKernelGGL(gsd_backward_mlp_kernel<M>, grid, block, 0, stream, N, K, P, vis, feat, anchor, gscale, campos, mask,  \
+                       first, g_color, g_opacity, g_unc, g_scaling, g_rot, d_gscale, D2, D1, H, X)
+    GSD_BWD(0); GSD_BWD(1); GSD_BWD(2); GSD_BWD(3);
+#undef GSD_BWD
+    hipLaunchKernelGGL(gsd_backward_input_kernel, grid, block, 0, stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
+                       first, g_xyz, D1, d_feat, d_anchor, d_offsets, d_gscale);
     return hipGetLastError();
 }
