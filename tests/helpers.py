@@ -142,13 +142,14 @@ def grad_report(got, ref, tol=GRAD_REL_TOL):
     return dict(max=float(rel.max()), p999=float(np.quantile(rel, 0.999)), n_bad=int((rel > tol).sum()), n=int(rel.size))
 
 
-def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-4, min_bad_allowed=2):
+def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-4, min_bad_allowed=4):
     """Every gradient family within `tol` rel (denominator |ref| + 1e-3 max|ref|) on all but a bounded
     handful of elements.  The handful exists because a (pixel, Gaussian) pair whose alpha sits within an
     ulp of 1/255 (or whose T sits at 1e-4) can be blended by one implementation and skipped by the other
     (exp() and FMA contraction differ by ulps); that moves one pixel's worth of gradient for that Gaussian.
-    Measured on the GPU box: 0-9 such elements out of 240k (tools/grad_diag.py).  The 99.9th percentile
-    must be inside `tol` regardless."""
+    Measured on the GPU box: 0-9 such elements out of 240k (tools/grad_diag.py).  One flipped pair moves ALL components
+    of that Gaussian's gradient (4 for the quaternion), hence at least 4 elements are tolerated per family.  The 99.9th
+    percentile must be inside `tol` regardless."""
     rep = {}
     for k in keys:
         if k not in ref or k not in got:
