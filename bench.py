@@ -249,6 +249,51 @@ def decode_row(dev, steps, with_cpu, N=200_000, K=10):
     return row
 
 
+def pipeline_row(dev, steps, W=1008, H=567, N=200_000, K=10):
+    """The three HIP rows back to back, as one training iteration of the renderer: neural-Gaussian decode ->
+    rasterizer -> fused RGB loss -> backward to the MLP weights / anchor parameters (SURVEY 3.1 minus the optimiser)."""
+    import numpy as np
+    from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer, synthetic as S
+    from gscream_amd import loss_utils as L
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    from oracle import decode_oracle as DO
+    model = DO.Model(N, K, seed=11, dtype=torch.float32, spread=1.5).to(dev)
+    w2c = np.eye(4, dtype=np.float32)
+    w2c[2, 3] = 6.0
+    view, proj, campos = S.camera_matrices(0.6, 0.6 * H / W, w2c)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = DO.Camera(t(campos))
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=0.6, tanfovy=0.6 * H / W, bg=torch.zeros(3, device=dev),
+                                       scale_modifier=1.0, viewmatrix=t(view), projmatrix=t(proj), sh_degree=1, campos=t(campos),
+                                       prefiltered=False, debug=False)
+    rast = GaussianRasterizer(rs)
+    gt = torch.rand((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    params = list(model.parameters())
+
+    def step():
+        xyz, color, opacity, unc, scaling, rot, nop, mask = generate_neural_gaussians(cam, model, None, True)
+        means2D = torch.zeros_like(xyz, requires_grad=True)
+        img, depth, feat, radii = rast(means3D=xyz, means2D=means2D, opacities=opacity, uncertainties=unc, colors_precomp=color,
+                                       scales=scaling, rotations=rot)
+        loss = L.rgb_loss(img, gt, None, 0.2, 1.0)
+        torch.autograd.grad(loss, params, allow_unused=True)
+        return int(xyz.shape[0])
+
+    for _ in range(3):
+        M = step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = max(5, steps // 2)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return {"what": f"decode ({N} anchors x {K}) -> rasterize {M} Gaussians @ {W}x{H} -> fused L1+SSIM loss -> backward to the MLP weights, all on the HIP rows",
+            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,6 +429,10 @@ def main():
                 out["next_rows"]["neural_gaussian_decode"] = decode_row(dev, args.steps, not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 out["next_rows"]["neural_gaussian_decode"] = {"error": repr(e)}
+            try:
+                out["next_rows"]["pipeline_decode_raster_loss"] = pipeline_row(dev, args.steps)
+            except Exception as e:  # noqa: BLE001
+                out["next_rows"]["pipeline_decode_raster_loss"] = {"error": repr(e)}
             try:
                 out["next_rows"]["simple_knn"] = knn_row(dev, not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
