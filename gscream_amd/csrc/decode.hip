@@ -8,10 +8,10 @@
 // The torch path materialises ~20 intermediates of up to [N*K, 23] floats; here one thread owns one anchor, nothing
 // but the compacted per-Gaussian outputs reaches HBM in the forward.
 //
-// Mapping.  Thread = anchor.  The MLP weights are wave-uniform operands: rows are fetched with scalar loads and
-// feed v_fma with an SGPR source, so a multiply-accumulate is one VALU op per 64 anchors.  Layer 1 (32 x 36) is fully
-// unrolled against the register-resident input -- every index is a compile-time constant and the scalar loads can be
-// batched far ahead of their use; layer 2 walks its output rows in a real loop against the 32 hidden registers.  No LDS.
+// Mapping.  Thread = anchor.  The MLP weights are wave-uniform operands, staged once per workgroup in LDS and read as
+// broadcasts, so a multiply-accumulate is one VALU op per 64 anchors.  Layer 1 (32 x 36) is fully unrolled against the
+// register-resident input -- every index is a compile-time constant; layer 2 walks its output rows in a real loop
+// against the 32 hidden registers.
 //   pass A  gsd_count_kernel : opacity MLP only -> neural_opacity[N*K], mask[N*K], per-anchor survivor count
 //   scan    gsd_scan_kernel  : exclusive scan of the counts (one block; N ~ 2e5) -> first output row per anchor, total
 //   pass B  gsd_emit_kernel  : all four MLPs, writes the surviving offsets' rows in the reference's order
@@ -57,12 +57,43 @@ __device__ __forceinline__ void gsd_input(const float* __restrict__ feat, const 
     x[32] = vx / dist; x[33] = vy / dist; x[34] = vz / dist; x[35] = dist;
 }
 
-// layer 1 of MLP m, fully unrolled into registers (post-ReLU).  The 32 x 36 weights arrive through scalar loads that
-// the compiler is free to batch far ahead of their use (limited by the SGPR file only); no LDS, no dynamic indices.
-__device__ __forceinline__ void gsd_layer1(const GsdMlps& P, int m, const float x[GSD_IN], float h[GSD_HID])
+// The weights of the MLPs a kernel needs are staged in LDS once per workgroup and read back as broadcasts
+// (same address in every lane: one ds_read_b128 feeds four FMAs of 64 anchors each).  Scalar loads were measured
+// first: they keep the FMA at one VALU op per 64 anchors too, but every 16-weight s_load is a ~200-cycle round trip
+// the wave has to wait out, and the kernels ran at a quarter of their VALU bound.
+struct GsdLds {  // offsets (floats) into the staging buffer
+    int w1[4], b1[4], w2[4], b2[4];
+};
+#define GSD_LDS_FLOATS(K) (4 * GSD_HID * GSD_IN + 4 * GSD_HID + 12 * (K) * GSD_HID + 12 * (K))
+__device__ __forceinline__ GsdLds gsd_stage_weights(const GsdMlps& P, int K, float* sw, int m_lo, int m_hi, bool first_layer_only = false)
 {
-    const float* __restrict__ w = P.w1[m];
-    const float* __restrict__ b = P.b1[m];
+    GsdLds L;
+    int off = 0;
+    const int outs[4] = { K, K, 3 * K, 7 * K };
+#pragma unroll
+    for (int m = 0; m < 4; m++) { L.w1[m] = off; off += GSD_HID * GSD_IN; }
+#pragma unroll
+    for (int m = 0; m < 4; m++) { L.b1[m] = off; off += GSD_HID; }
+#pragma unroll
+    for (int m = 0; m < 4; m++) { L.w2[m] = off; off += outs[m] * GSD_HID; }
+#pragma unroll
+    for (int m = 0; m < 4; m++) { L.b2[m] = off; off += outs[m]; }
+    for (int m = m_lo; m <= m_hi; m++) {
+        for (int i = threadIdx.x; i < GSD_HID * GSD_IN; i += blockDim.x) sw[L.w1[m] + i] = P.w1[m][i];
+        if (first_layer_only) continue;
+        for (int i = threadIdx.x; i < GSD_HID; i += blockDim.x) sw[L.b1[m] + i] = P.b1[m][i];
+        for (int i = threadIdx.x; i < outs[m] * GSD_HID; i += blockDim.x) sw[L.w2[m] + i] = P.w2[m][i];
+        for (int i = threadIdx.x; i < outs[m]; i += blockDim.x) sw[L.b2[m] + i] = P.b2[m][i];
+    }
+    __syncthreads();
+    return L;
+}
+
+// layer 1 of MLP m, fully unrolled into registers (post-ReLU): every index is a compile-time constant.
+__device__ __forceinline__ void gsd_layer1(const float* sw, const GsdLds& L, int m, const float x[GSD_IN], float h[GSD_HID])
+{
+    const float* w = sw + L.w1[m];
+    const float* b = sw + L.b1[m];
 #pragma unroll
     for (int j = 0; j < GSD_HID; j++) {
         float s = b[j];
@@ -71,10 +102,10 @@ __device__ __forceinline__ void gsd_layer1(const GsdMlps& P, int m, const float 
         h[j] = fmaxf(s, 0.0f);
     }
 }
-__device__ __forceinline__ float gsd_out(const GsdMlps& P, int m, int o, const float h[GSD_HID])
+__device__ __forceinline__ float gsd_out(const float* sw, const GsdLds& L, int m, int o, const float h[GSD_HID])
 {
-    const float* __restrict__ w = P.w2[m] + o * GSD_HID;
-    float s = P.b2[m][o];
+    const float* w = sw + L.w2[m] + o * GSD_HID;
+    float s = sw[L.b2[m] + o];
 #pragma unroll
     for (int j = 0; j < GSD_HID; j++) s += w[j] * h[j];
     return s;
@@ -90,17 +121,18 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
                                                                 uint32_t* __restrict__ block_sum)
 {
     __shared__ uint32_t bs;
+    extern __shared__ __attribute__((aligned(16))) float sw[];
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (threadIdx.x == 0) bs = 0u;
-    __syncthreads();
+    const GsdLds L = gsd_stage_weights(P, K, sw, 0, 0);  // (contains the barrier)
     int c = 0;
     if (n < N) {
         float x[GSD_IN], dist, h[GSD_HID];
         gsd_input(feat, anchor, campos, vis ? vis[n] : n, x, dist);
-        gsd_layer1(P, 0, x, h);
+        gsd_layer1(sw, L, 0, x, h);
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
-            const float op = tanhf(gsd_out(P, 0, k, h));
+            const float op = tanhf(gsd_out(sw, L, 0, k, h));
             const bool keep = op > 0.0f;  // gaussian_renderer/__init__.py:59
             neural_opacity[(size_t)n * K + k] = op;
             mask[(size_t)n * K + k] = keep ? 1 : 0;
@@ -157,6 +189,8 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
     const uint32_t* __restrict__ first, float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity, float* __restrict__ uncertainty,
     float* __restrict__ scaling, float* __restrict__ rot)
 {
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    const GsdLds L = gsd_stage_weights(P, K, sw, 1, 3);
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
     const int a = vis ? vis[n] : n;  // visible-anchor gather (gaussian_renderer/__init__.py:25-28) folded in
@@ -182,29 +216,29 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
         xyz[3 * (size_t)r + 1] = ay + of[1] * gs[1];
         xyz[3 * (size_t)r + 2] = az + of[2] * gs[2];
     }
-    gsd_layer1(P, 1, x, h);
+    gsd_layer1(sw, L, 1, x, h);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         if (!((keep >> k) & 1u)) continue;
         const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        uncertainty[r] = gsd_sigmoid(gsd_out(P, 1, k, h));
+        uncertainty[r] = gsd_sigmoid(gsd_out(sw, L, 1, k, h));
     }
-    gsd_layer1(P, 2, x, h);
+    gsd_layer1(sw, L, 2, x, h);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         if (!((keep >> k) & 1u)) continue;
         const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
 #pragma unroll
-        for (int c = 0; c < 3; c++) color[3 * (size_t)r + c] = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
+        for (int c = 0; c < 3; c++) color[3 * (size_t)r + c] = gsd_sigmoid(gsd_out(sw, L, 2, 3 * k + c, h));
     }
-    gsd_layer1(P, 3, x, h);
+    gsd_layer1(sw, L, 3, x, h);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         if (!((keep >> k) & 1u)) continue;
         const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
         float sr[7];
 #pragma unroll
-        for (int c = 0; c < 7; c++) sr[c] = gsd_out(P, 3, 7 * k + c, h);
+        for (int c = 0; c < 7; c++) sr[c] = gsd_out(sw, L, 3, 7 * k + c, h);
 #pragma unroll
         for (int c = 0; c < 3; c++) scaling[3 * (size_t)r + c] = gs[3 + c] * gsd_sigmoid(sr[c]);  // :90
         const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);  // F.normalize
@@ -231,6 +265,8 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
     float* __restrict__ d_gscale, float* __restrict__ D2, float* __restrict__ D1, float* __restrict__ Hout,
     float* __restrict__ Xout)
 {
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    const GsdLds L = gsd_stage_weights(P, K, sw, M, M);
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
     const int a = vis ? vis[n] : n;
@@ -248,7 +284,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
 #pragma unroll
         for (int c = 0; c < 3; c++) gs3[c] = gscale[6 * (size_t)a + 3 + c];
     }
-    gsd_layer1(P, M, x, h);
+    gsd_layer1(sw, L, M, x, h);
 #pragma unroll
     for (int j = 0; j < GSD_HID; j++) { Hout[(size_t)(M * 32 + j) * N + n] = h[j]; dh[j] = 0.f; }
     constexpr int per = M == 0 || M == 1 ? 1 : (M == 2 ? 3 : 7);
@@ -262,22 +298,22 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
         for (int c = 0; c < per; c++) dz[c] = 0.f;
         if (on) {
             if (M == 0) {  // opacity = tanh(z)
-                const float t = tanhf(gsd_out(P, 0, k, h));
+                const float t = tanhf(gsd_out(sw, L, 0, k, h));
                 dz[0] = g_opacity[r] * (1.0f - t * t);
             } else if (M == 1) {  // sigmoid
-                const float sg = gsd_sigmoid(gsd_out(P, 1, k, h));
+                const float sg = gsd_sigmoid(gsd_out(sw, L, 1, k, h));
                 dz[0] = g_unc[r] * sg * (1.0f - sg);
             } else if (M == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const float sg = gsd_sigmoid(gsd_out(P, 2, 3 * k + c, h));
+                    const float sg = gsd_sigmoid(gsd_out(sw, L, 2, 3 * k + c, h));
                     dz[c % per] = g_color[3 * (size_t)r + c] * sg * (1.0f - sg);
                 }
             } else {
                 float sr[7];
 #pragma unroll
                 for (int c = 0; c < 7; c++) {
-                    sr[c] = gsd_out(P, 3, 7 * k + c, h);
+                    sr[c] = gsd_out(sw, L, 3, 7 * k + c, h);
                     __builtin_amdgcn_sched_barrier(0);  // one weight row in flight at a time: 7 x 32 live scalars do not fit
                 }
 #pragma unroll
@@ -299,7 +335,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
         for (int c = 0; c < per; c++) {
             const int o = per * k + c;
             D2[(size_t)(out_base + o) * N + n] = dz[c];
-            const float* __restrict__ w = P.w2[M] + o * GSD_HID;
+            const float* w = sw + L.w2[M] + o * GSD_HID;
 #pragma unroll
             for (int j = 0; j < GSD_HID; j++) dh[j] += w[j] * dz[c];
             if (per > 1) __builtin_amdgcn_sched_barrier(0);
@@ -322,6 +358,8 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
     const float* __restrict__ D1, float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_offsets,
     float* __restrict__ d_gscale)
 {
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    const GsdLds L = gsd_stage_weights(P, K, sw, 0, 3, true);
     const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
     if (n >= N) return;
     const int a = vis ? vis[n] : n;
@@ -330,7 +368,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
     for (int i = 0; i < GSD_IN; i++) dx[i] = 0.f;
 #pragma unroll 1
     for (int m = 0; m < 4; m++) {
-        const float* __restrict__ w1 = P.w1[m];
+        const float* w1 = sw + L.w1[m];
 #pragma unroll 4
         for (int j = 0; j < GSD_HID; j++) {
             const float d1 = D1[(size_t)(m * 32 + j) * N + n];
@@ -382,7 +420,7 @@ hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int
 {
     if (N <= 0) return hipSuccess;
     const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
-    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), vis, feat, anchor, campos,
+    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb), dim3(GSD_THREADS), GSD_LDS_FLOATS(K) * sizeof(float), stream, N, K, gsd_pack(weights), vis, feat, anchor, campos,
                        neural_opacity, mask, count, block_scratch);
     hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, block_scratch, total);
     hipLaunchKernelGGL(gsd_first_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, count, block_scratch, first);
@@ -395,7 +433,7 @@ hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int3
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsd_emit_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), 0, stream, N, K,
+    hipLaunchKernelGGL(gsd_emit_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), GSD_LDS_FLOATS(K) * sizeof(float), stream, N, K,
                        gsd_pack(weights), vis, feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
                        opacity, uncertainty, scaling, rot);
     return hipGetLastError();
@@ -412,11 +450,11 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
     const dim3 grid((N + GSD_THREADS - 1) / GSD_THREADS), block(GSD_THREADS);
     const GsdMlps P = gsd_pack(weights);
 #define GSD_BWD(M)                                                                                                          \
-    hipLaunchKernelGGL(gsd_backward_mlp_kernel<M>, grid, block, 0, stream, N, K, P, vis, feat, anchor, gscale, campos, mask,  \
+    hipLaunchKernelGGL(gsd_backward_mlp_kernel<M>, grid, block, GSD_LDS_FLOATS(K) * sizeof(float), stream, N, K, P, vis, feat, anchor, gscale, campos, mask,  \
                        first, g_color, g_opacity, g_unc, g_scaling, g_rot, d_gscale, D2, D1, H, X)
     GSD_BWD(0); GSD_BWD(1); GSD_BWD(2); GSD_BWD(3);
 #undef GSD_BWD
-    hipLaunchKernelGGL(gsd_backward_input_kernel, grid, block, 0, stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
+    hipLaunchKernelGGL(gsd_backward_input_kernel, grid, block, 4 * GSD_HID * GSD_IN * sizeof(float), stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
                        first, g_xyz, D1, d_feat, d_anchor, d_offsets, d_gscale);
     return hipGetLastError();
 }
