@@ -17,32 +17,6 @@
 typedef unsigned long long u64;
 
 // ---------------------------------------------------------------------------------------------
-// Block-wide exclusive scan helper (256 threads)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t gsr_block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds /*[8]*/)
-{
-    // wave-level inclusive scan with DPP-free shuffles (4 waves of 64), then across waves in LDS
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) lds[wave] = x;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t s = lds[w];
-        if (w < wave) base += s;
-    }
-    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
-    __syncthreads();
-    return base + x - v;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Tile histogram per chunk of Gaussians  (one counting-sort pass on the tile id, in LDS)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gsr_chunk_bounds(int P, int nchunks, int chunk, int& lo, int& hi)
@@ -402,9 +376,7 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     // the scatter left the tile's 64-bit keys (depth bits, Gaussian id) in its segment of seg_keys
     for (uint32_t i = threadIdx.x; i < n; i += 256) keys[GSR_PAD(i)] = seg_keys[rg.x + i];
     __syncthreads();
-#ifndef GSR_EXP_NOSORT
     gsr_sort_lds_fused(keys, n, 256);
-#endif
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
 }
 

@@ -88,13 +88,9 @@ __device__ __forceinline__ float gsr_pair_step(float a, float b, bool hi)
     return keep + gsr_dpp<CTRL>(send);
 }
 
-// ---- A/B switch (compile-time; the default is the measured winner, see profiles/) ----
-//   GSR_PREFETCH = 1 : software-pipeline the instance loop: the wave's list indices sit one per lane (v_readlane
-//                      instead of a dependent LDS read) and the operands of instance k+1 are in flight while
-//                      instance k is computed.
-#ifndef GSR_PREFETCH
-#define GSR_PREFETCH 1
-#endif
+// The instance loops are software-pipelined: the wave's list indices sit one per lane (v_readlane instead of a
+// dependent LDS read) and the operands of instance k+1 are in flight while instance k is computed (measured winner
+// against the plain loop, profiles/).
 
 // 4-bit mask of the 8x8 quadrants of tile (tx, ty) in which the Gaussian can reach alpha >= 1/255.
 __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const float4 B, const float tau, int tx, int ty,
@@ -302,13 +298,8 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     // slot traffic and of the batch loads disappear.
 
     // back to front, in batches of 256 instances; local j = 0 is the backmost instance of the batch
-#ifdef GSR_EXP_ALLSLOTS
-    for (int hi = n; hi > 0; hi -= GSR_BATCH) {
-#else
     for (int hi = nproc; hi > 0; hi -= GSR_BATCH) {
-#endif
         const int lo = max(0, hi - GSR_BATCH), cnt = hi - lo;
-        constexpr bool active = true;
         if (t < cnt) {
             const uint32_t id = point_list[rg.x + (hi - 1 - t)];
             const GsrRec* r = rec + id;
@@ -326,25 +317,18 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
         }
         __syncthreads();
 
-        if (active) {
+        {
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
             const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [=](int i) { return hi - 1 - i < wmax; });
             __builtin_amdgcn_wave_barrier();
             for (int c0 = 0; c0 < nw; c0 += 64) {
                 const int m = min(64, nw - c0);
-#if GSR_PREFETCH
                 const int jj = mylist[min(c0 + lane, nw - 1)];
                 int j = __builtin_amdgcn_readlane(jj, 0);
                 float4 A = sA[j], B = sB[j];
-#endif
                 for (int k = 0; k < m; k++) {
-#if GSR_PREFETCH
                     const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
                     const float4 An = sA[jn], Bn = sB[jn];
-#else
-                    const int j = mylist[c0 + k];
-                    const float4 A = sA[j], B = sB[j];
-#endif
                     const int p = hi - 1 - j;
                     const float dx = A.x - pxf, dy = A.y - pyf;
                     const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the falloff
@@ -429,9 +413,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                         // lane -> accumulator field: AUX: identity (0..10); else {0,1,2,5,6,7,8,9,10}
                         if (lane < (AUX ? 11 : 9)) atomicAdd(acc + j * GSR_SLOT_FLOATS + (AUX || lane < 3 ? lane : lane + 2), x);
                     }
-#if GSR_PREFETCH
                     j = jn; A = An; B = Bn;
-#endif
                 }
             }
         }

@@ -144,11 +144,7 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
         }
     }
     double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
-#ifdef GSR_EXP_NOSLOTS
-    for (uint32_t base = S0; base < S0; base += FCH) {
-#else
     for (uint32_t base = S0; base < S1; base += FCH) {
-#endif
         const uint32_t nf = min(S1 - base, (uint32_t)FCH);
         uint8_t f[FCH / 64];
 #pragma unroll
@@ -202,11 +198,7 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     float gop = (float)acc[10];
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
 
-#ifdef GSR_EXP_NOMATH
-    if (vis && gop == 12345.f) {
-#else
     if (vis) {
-#endif
         float cov3D[6];
         if (cov3D_precomp) {
 #pragma unroll

@@ -5,6 +5,7 @@ Bars (BASELINE.json north_star): integer results (radii, num_rendered, per-tile 
 images within 1e-4 abs; gradients within 1e-3 rel (denominator |ref| + 1e-3 max|ref|)."""
 import os
 import sys
+import zlib
 
 import numpy as np
 import pytest
@@ -384,7 +385,7 @@ def _vs_oracle(s, grads, name, img_frac=2e-4):
 @pytest.mark.parametrize("variant", ["scale_modifier", "sh_deg0", "sh_deg1", "sh_deg2", "huge_gaussians", "opacity_edges",
                                      "thin_image", "tall_image", "tiny_gaussians"])
 def test_more_cases_against_live_oracle(variant):
-    rng = np.random.default_rng(hash(variant) % 1000)
+    rng = np.random.default_rng(zlib.crc32(variant.encode()) % 1000)  # (str hash() is salted per process: not a seed)
     if variant == "scale_modifier":
         s = S.scene_config1(seed=80, P=1500, W=120, H=90)
         s["scale_modifier"] = 0.6
