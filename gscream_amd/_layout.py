@@ -8,7 +8,7 @@ def _align(x):
 
 
 def num_chunks(P):
-    return max(1, min(256, (P + 2047) // 2048))
+    return max(1, min(512, (P + 2047) // 2048))  # GSR_MAX_CHUNKS
 
 
 def _take(buf, off, nbytes, dtype, shape):

@@ -78,18 +78,19 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
 }
 
 // Column pass over table[nchunks][T]: for every tile, exclusive prefix over chunks (in place) and the
-// tile total.  Block = 64 tiles x 4 chunk groups.
-__global__ void __launch_bounds__(256) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
-                                                                uint32_t* __restrict__ tile_count)
+// tile total.  Block = 64 tiles x 8 chunk groups.
+#define GSR_COLSCAN_GROUPS 8  // chunk groups per workgroup: 64 tiles x 8 groups = 512 threads, <= 64 rows per thread
+__global__ void __launch_bounds__(64 * GSR_COLSCAN_GROUPS) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
+                                                                                    uint32_t* __restrict__ tile_count)
 {
-    __shared__ uint32_t part[4][64];
+    __shared__ uint32_t part[GSR_COLSCAN_GROUPS][64];
     const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int tile = blockIdx.x * 64 + tl;
-    const int per = (nchunks + 3) / 4;
+    const int per = (nchunks + GSR_COLSCAN_GROUPS - 1) / GSR_COLSCAN_GROUPS;
     const int c0 = grp * per, c1 = min(nchunks, c0 + per);
     // each thread owns <= 64 table rows of one tile: keep them in registers between the two passes (the loads of
     // the first pass are independent, so they are all in flight together; the second pass needs no re-read)
-    constexpr int MAXR = GSR_MAX_CHUNKS / 4;
+    constexpr int MAXR = GSR_MAX_CHUNKS / GSR_COLSCAN_GROUPS;
     uint32_t v[MAXR];
     uint32_t s = 0;
 #pragma unroll
@@ -101,8 +102,13 @@ __global__ void __launch_bounds__(256) gsr_table_colscan_kernel(int T, int nchun
     for (int r = 0; r < MAXR; r++) s += v[r];
     part[grp][tl] = s;
     __syncthreads();
-    uint32_t run = 0;
-    for (int g2 = 0; g2 < grp; g2++) run += part[g2][tl];
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int g2 = 0; g2 < GSR_COLSCAN_GROUPS; g2++) {
+        const uint32_t pv = part[g2][tl];
+        run += g2 < grp ? pv : 0u;
+        total += pv;
+    }
     if (tile < T) {
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(256) gsr_table_colscan_kernel(int T, int nchun
             if (c < c1) table[(size_t)c * T + tile] = run;
             run += v[r];
         }
-        if (grp == 3) tile_count[tile] = part[0][tl] + part[1][tl] + part[2][tl] + part[3][tl];
+        if (grp == 0) tile_count[tile] = total;
     }
 }
 
@@ -169,8 +175,23 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (!GLOBAL) {
+        // cursor = tile start + this chunk's offset inside the tile; eight entries per thread per trip with all loads
+        // issued before the first LDS store (one memory round trip per trip instead of one per entry)
         const uint32_t* row = table + (size_t)blockIdx.x * T;
-        for (int t = threadIdx.x; t < T; t += blockDim.x) cursor[t] = ranges[t].x + row[t];
+        for (int t0 = threadIdx.x; t0 < T; t0 += blockDim.x * 8) {
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int t = t0 + k * (int)blockDim.x;
+                a[k] = t < T ? ranges[t].x : 0u;
+                b[k] = t < T ? row[t] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int t = t0 + k * (int)blockDim.x;
+                if (t < T) cursor[t] = a[k] + b[k];
+            }
+        }
     }
     if (threadIdx.x == 0) chunk_first = 0u;
     __syncthreads();
@@ -435,7 +456,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
         hipLaunchKernelGGL(gsr_tile_hist_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx,
                            nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums);
         // (2) column scan -> per-(chunk, tile) offsets + tile totals
-        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, stream, T, nchunks, image.table,
+        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(64 * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
                            image.tile_count);
     }
     // (3) tile scan -> ranges, info

@@ -29,7 +29,7 @@
 #include "../../include/gsraster.h"
 
 #define GSR_TILE 16
-#define GSR_MAX_CHUNKS 256       // NB: rows of the (chunk, tile) count table
+#define GSR_MAX_CHUNKS 512       // NB: rows of the (chunk, tile) count table (<= GSR_HIST_THREADS: the scatter sums them in one pass)
 #ifndef GSR_HIST_THREADS
 #define GSR_HIST_THREADS 512
 #endif
