@@ -11,7 +11,7 @@
 //   * Morton order by rocPRIM's radix sort (a plain library sort; keys + permutation, 8 B per point),
 //   * the sorted coordinates are GATHERED once into a contiguous float4 array, so the search streams coalesced
 //     16-byte loads instead of chasing `points[indices[i]]`,
-//   * boxes of 64 points (one wavefront's worth: finer pruning than 1024),
+//   * boxes of 64 points (one wavefront's worth: finer pruning than 1024) under super-boxes of 64 boxes,
 //   * one 256-thread workgroup per 256 consecutive points: candidate boxes are tested against the bounding box of the
 //     whole group and the group's largest reject radius (wave-uniform control flow), then opened cooperatively: the
 //     64 points of a box are staged in LDS once and read by all threads as broadcasts.
@@ -114,6 +114,28 @@ __global__ void __launch_bounds__(GSK_BOX) gsk_box_kernel(int P, const float4* _
     }
 }
 
+// bounding boxes of runs of 64 boxes (4096 points): a coarse level the search rejects 64 boxes at a time with
+__global__ void __launch_bounds__(GSK_BOX) gsk_superbox_kernel(int nboxes, const GskBox* __restrict__ boxes, GskBox* __restrict__ sboxes)
+{
+    const int i = blockIdx.x * GSK_BOX + threadIdx.x;
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    if (i < nboxes) {
+        const GskBox b = boxes[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = b.lo[k]; hi[k] = b.hi[k]; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], d, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d, 64)); }
+    if (threadIdx.x == 0) {
+        GskBox b;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { b.lo[k] = lo[k]; b.hi[k] = hi[k]; }
+        sboxes[blockIdx.x] = b;
+    }
+}
+
 __device__ __forceinline__ void gsk_update3(float dist, float best[3])  // simple_knn.cu:120-132 updateKBest<3>
 {
 #pragma unroll
@@ -141,6 +163,7 @@ __device__ __forceinline__ float gsk_box_box(const float lo[3], const float hi[3
 
 __global__ void __launch_bounds__(GSK_GROUP) gsk_search_kernel(int P, int nboxes, const float4* __restrict__ sp,
                                                                const GskBox* __restrict__ boxes,
+                                                               const GskBox* __restrict__ sboxes,
                                                                float* __restrict__ mean_dist2)
 {
     __shared__ float4 cand[GSK_BOX];
@@ -181,6 +204,10 @@ __global__ void __launch_bounds__(GSK_GROUP) gsk_search_kernel(int P, int nboxes
     const float greject = grp[6];
 
     for (int b = 0; b < nboxes; b++) {
+        if ((b & (GSK_BOX - 1)) == 0 && gsk_box_box(glo, ghi, sboxes[b / GSK_BOX]) > greject) {  // 64 boxes rejected at once
+            b += GSK_BOX - 1;
+            continue;
+        }
         const GskBox box = boxes[b];  // uniform address: scalar loads
         if (gsk_box_box(glo, ghi, box) > greject) continue;  // workgroup-uniform: no member can need this box
         __syncthreads();  // previous candidates consumed
@@ -214,7 +241,7 @@ __global__ void __launch_bounds__(GSK_GROUP) gsk_search_kernel(int P, int nboxes
 struct GskWorkspace {
     uint32_t *codes, *codes_sorted, *ids, *ids_sorted;
     float4* sp;
-    GskBox* boxes;
+    GskBox *boxes, *sboxes;
     float* part;
     void* sort_temp;
     size_t sort_temp_bytes, bytes;
@@ -233,6 +260,7 @@ static GskWorkspace gsk_carve(void* base, int P)
     w.ids_sorted = (uint32_t*)(b + off); off += gsr_align(p * 4);
     w.sp = (float4*)(b + off); off += gsr_align(p * 16);
     w.boxes = (GskBox*)(b + off); off += gsr_align(((p + GSK_BOX - 1) / GSK_BOX) * sizeof(GskBox));
+    w.sboxes = (GskBox*)(b + off); off += gsr_align(((p + GSK_BOX * GSK_BOX - 1) / (GSK_BOX * GSK_BOX)) * sizeof(GskBox));
     w.part = (float*)(b + off); off += gsr_align(GSK_MINMAX_BLOCKS * 6 * 4);
     // rocPRIM's radix sort scratch (histograms / block offsets; the key + value buffers above are ours): provisioned
     // generously and verified against rocPRIM's own figure at call time
@@ -263,7 +291,8 @@ hipError_t gsk_launch(int P, const float* points, float* mean_dist2, void* works
     const int nboxes = (P + GSK_BOX - 1) / GSK_BOX;
     hipLaunchKernelGGL(gsk_gather_kernel, dim3(nb256), dim3(256), 0, stream, P, points, w.ids_sorted, w.sp);
     hipLaunchKernelGGL(gsk_box_kernel, dim3(nboxes), dim3(GSK_BOX), 0, stream, P, w.sp, w.boxes);
+    hipLaunchKernelGGL(gsk_superbox_kernel, dim3((nboxes + GSK_BOX - 1) / GSK_BOX), dim3(GSK_BOX), 0, stream, nboxes, w.boxes, w.sboxes);
     hipLaunchKernelGGL(gsk_search_kernel, dim3((P + GSK_GROUP - 1) / GSK_GROUP), dim3(GSK_GROUP), 0, stream, P, nboxes, w.sp,
-                       w.boxes, mean_dist2);
+                       w.boxes, w.sboxes, mean_dist2);
     return hipGetLastError();
 }
