@@ -312,6 +312,52 @@ def copy_ceiling(dev):
     return round(2 * 4 * n / 1e9 / (ms / 1e3), 1)
 
 
+def depth_loss_row(dev, H, W, steps):
+    """The depth terms of the loss (train.py:548-573): scale/shift fit + L1 + four-scale gradient loss, fwd + bwd."""
+    import ctypes
+    from gscream_amd import _native
+    from gscream_amd import loss_utils as L
+    from oracle import loss_oracle as LO
+    lib = _native.load()
+    g = torch.Generator(device=dev).manual_seed(9)
+    y = torch.rand((1, H, W), device=dev, generator=g) * 4 + 1
+    d = (0.6 * y + 0.4 + 0.05 * torch.randn(y.shape, device=dev, generator=g)).requires_grad_(True)
+    m = (torch.rand((1, H, W), device=dev, generator=g) > 0.3).float()
+    ws = torch.empty((lib.gsr_depth_loss_workspace_bytes(H, W),), dtype=torch.uint8, device=dev)
+    out5, grad = torch.empty(5, device=dev), torch.empty((H, W), device=dev)
+    dd, stream = d.detach().reshape(H, W).contiguous(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def native():
+        _native.check(lib.gsr_depth_loss_forward(H, W, _native.ptr(dd), _native.ptr(y), _native.ptr(m), _native.ptr(m), _native.ptr(m),
+                                                 1.0, 0.5, _native.ptr(ws), _native.ptr(out5), stream), "depth loss forward")
+        _native.check(lib.gsr_depth_loss_backward(H, W, _native.ptr(dd), _native.ptr(y), _native.ptr(m), _native.ptr(ws), None,
+                                                  _native.ptr(grad), stream), "depth loss backward")
+
+    def eager():
+        loss = LO.depth_loss(d, y, m, m, m, 1.0, 0.5)[0]
+        return torch.autograd.grad(loss, d)[0]
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ms, ms_eager = timed(native, steps), timed(eager, max(5, steps // 5))
+    nbytes = H * W * (4 * 4 + 4 * 5 + 4 + 4 * 4 + 4)  # sums: d,y,m,g; stencil: d,y,w,g (+neighbours from cache) + G; backward: d,y,m,G + out
+    return {"what": f"depth loss (scale/shift fit, L1, 4-scale gradient loss), forward + backward, {H}x{W} (gsr_depth_loss_*)",
+            "ms": round(ms, 4), "algorithmic_bytes": nbytes,
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / 1e9 / (ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(nbytes / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)},
+            "torch_eager_same_gpu_ms": round(ms_eager, 4), "speedup_vs_torch_eager": round(ms_eager / ms, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -451,6 +497,10 @@ def main():
                 out["next_rows"] = {"rgb_loss": loss_row(dev, H, W, args.steps, not args.no_cpu_baseline)}
             except Exception as e:  # noqa: BLE001
                 out["next_rows"] = {"rgb_loss": {"error": repr(e)}}
+            try:
+                out["next_rows"]["depth_loss"] = depth_loss_row(dev, H, W, args.steps)
+            except Exception as e:  # noqa: BLE001
+                out["next_rows"]["depth_loss"] = {"error": repr(e)}
             try:
                 out["next_rows"]["neural_gaussian_decode"] = decode_row(dev, args.steps, not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001

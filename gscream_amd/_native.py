@@ -17,6 +17,7 @@ EXPORTED_SYMBOLS = (
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
+    "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward",
 )
 NUM_STAGES = 7
 
@@ -100,6 +101,12 @@ def load():
     lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 17
     lib.gsr_decode_backward.restype = _c_int
     lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 24
+    lib.gsr_depth_loss_workspace_bytes.restype = ctypes.c_size_t
+    lib.gsr_depth_loss_workspace_bytes.argtypes = [_c_int, _c_int]
+    lib.gsr_depth_loss_forward.restype = _c_int
+    lib.gsr_depth_loss_forward.argtypes = [_c_int, _c_int] + [_vp] * 5 + [_c_float, _c_float, _vp, _vp, _vp]
+    lib.gsr_depth_loss_backward.restype = _c_int
+    lib.gsr_depth_loss_backward.argtypes = [_c_int, _c_int] + [_vp] * 7
     _lib = lib
     return lib
 

@@ -484,3 +484,26 @@ extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, co
     return GSR_OK;
 }
 
+// ---- depth loss (depth_loss.hip) ----
+extern "C" size_t gsr_depth_loss_workspace_bytes(int H, int W) { return gdl_workspace_bytes(H, W); }
+
+extern "C" int gsr_depth_loss_forward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
+                                      const float* l1_weight, const float* grad_mask, float lambda_l1, float lambda_smooth,
+                                      void* workspace, float* out5, void* stream)
+{
+    if (H < 1 || W < 1 || (long long)H * W > 0x7fffffffLL) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "depth loss: bad size %dx%d", W, H);
+    if (!depth || !target || !workspace || !out5) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "depth loss: a required pointer is NULL");
+    GSR_HIP(gdl_launch_forward(H, W, depth, target, lsq_mask, l1_weight, grad_mask, lambda_l1, lambda_smooth, workspace, out5,
+                               (hipStream_t)stream), "depth loss forward");
+    return GSR_OK;
+}
+
+extern "C" int gsr_depth_loss_backward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
+                                       const void* workspace, const float* upstream, float* dL_ddepth, void* stream)
+{
+    if (H < 1 || W < 1 || (long long)H * W > 0x7fffffffLL) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "depth loss: bad size %dx%d", W, H);
+    if (!depth || !target || !workspace || !dL_ddepth) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "depth loss: a required pointer is NULL");
+    GSR_HIP(gdl_launch_backward(H, W, depth, target, lsq_mask, workspace, upstream, dL_ddepth, (hipStream_t)stream), "depth loss backward");
+    return GSR_OK;
+}
+

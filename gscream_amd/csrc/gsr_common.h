@@ -204,3 +204,11 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
                                const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
                                float* d_anchor, float* d_offsets, float* d_gscale, float* D2, float* D1, float* H, float* X,
                                hipStream_t stream);
+
+// ---- depth_loss.hip (depth terms) ----
+size_t gdl_workspace_bytes(int H, int W);
+hipError_t gdl_launch_forward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
+                              const float* l1_weight, const float* grad_mask, float lambda_l1, float lambda_smooth,
+                              void* workspace, float* out5, hipStream_t stream);
+hipError_t gdl_launch_backward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
+                               const void* workspace, const float* upstream, float* dL_ddepth, hipStream_t stream);

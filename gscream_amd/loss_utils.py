@@ -23,7 +23,7 @@ import torch
 
 from . import _native
 
-__all__ = ["l1_loss", "l1_loss_masked", "ssim", "ssim_masked", "rgb_loss"]
+__all__ = ["l1_loss", "l1_loss_masked", "ssim", "ssim_masked", "rgb_loss", "depth_loss"]
 
 
 def _prep(img, gt, weight):
@@ -115,3 +115,51 @@ def rgb_loss(image, gt, weight=None, lambda_dssim=0.2, scale=1.0, return_parts=F
     loss, parts = _FusedLoss.apply(image, gt, weight, scale * (1.0 - lambda_dssim), -scale * lambda_dssim)
     loss = loss + scale * lambda_dssim
     return (loss, parts[1], parts[2]) if return_parts else loss
+
+
+class _DepthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, target, lsq_mask, l1_weight, grad_mask, lambda_l1, lambda_smooth):
+        lib = _native.load()
+        if not depth.is_cuda:
+            raise RuntimeError("gscream_amd.loss_utils: tensors must be on a HIP device (there is no CPU fallback)")
+        H, W = depth.shape[-2:]
+        if depth.numel() != H * W or target.numel() != H * W:
+            raise ValueError("depth and target must be [1,H,W] / [H,W] maps of the same size")
+        f = lambda t: None if t is None else t.detach().reshape(H, W).contiguous().float()
+        d, y, m, w, g = f(depth), f(target), f(lsq_mask), f(l1_weight), f(grad_mask)
+        with torch.cuda.device(d.device):
+            ws = torch.empty((lib.gsr_depth_loss_workspace_bytes(H, W),), dtype=torch.uint8, device=d.device)
+            out = torch.empty((5,), dtype=torch.float32, device=d.device)
+            _native.check(lib.gsr_depth_loss_forward(H, W, _native.ptr(d), _native.ptr(y), _native.ptr(m), _native.ptr(w),
+                                                     _native.ptr(g), float(lambda_l1), float(lambda_smooth), _native.ptr(ws),
+                                                     _native.ptr(out), _stream()), "gsr_depth_loss_forward")
+        ctx.save_for_backward(d, y, m if m is not None else torch.empty(0, device=d.device), ws)
+        ctx.in_shape = tuple(depth.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        lib = _native.load()
+        d, y, m, ws = ctx.saved_tensors
+        H, W = d.shape
+        up = g_loss.detach().reshape(1).float().contiguous()
+        with torch.cuda.device(d.device):
+            grad = torch.empty_like(d)
+            _native.check(lib.gsr_depth_loss_backward(H, W, _native.ptr(d), _native.ptr(y), _native.ptr(m), _native.ptr(ws),
+                                                      _native.ptr(up), _native.ptr(grad), _stream()), "gsr_depth_loss_backward")
+        return grad.reshape(ctx.in_shape), None, None, None, None, None, None
+
+
+def depth_loss(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0,
+               return_parts=False):
+    """The depth terms of train.py:548-573 in one forward and one backward:
+        scale, shift = compute_scale_and_shift(depth, target, lsq_mask); aligned = |scale| * depth + shift
+        lambda_l1 * l1_loss[_masked](aligned, target[, l1_weight])
+          + sum_{k<4} 0.5 * lambda_smooth * gradient_loss(aligned[:, ::2^k, ::2^k], target[...], grad_mask[...])
+    (reference view: l1_weight = grad_mask = None; other views: both = valid_mask).  Gradients flow to `depth`, through
+    the alignment as well.  return_parts -> (loss, (loss, l1 mean, smooth part, scale, shift))."""
+    loss, parts = _DepthLoss.apply(depth, target, lsq_mask, l1_weight, grad_mask, lambda_l1, lambda_smooth)
+    return (loss, parts) if return_parts else loss
+

@@ -224,6 +224,21 @@ int gsr_rgb_loss_backward(int C, int H, int W, const float* img, const float* gt
                           float a_ssim, const void* workspace, const float* upstream, float* dL_dimg, void* stream);
 
 /*
+ * The depth terms of the same loss (train.py:548-573): least-squares scale/shift alignment of the rendered depth to the
+ * target over lsq_mask (utils/loss_utils.py:77-104), scale = |scale|, then
+ *     L = lambda_l1 * mean(|a - y| * l1_weight) + sum_{k=0..3} 0.5 * lambda_smooth * gradient_loss(a[::2^k], y[::2^k], grad_mask[::2^k])
+ * (utils/loss_utils.py:26-30, 40-49, 58-74), a = scale * depth + shift.  The gradient includes the path through the
+ * fit.  depth, target, masks: [H,W] fp32 (masks may be NULL = ones).  out5 (device): {L, mean(|a-y| w), smooth part,
+ * scale, shift}.  The forward keeps what the backward needs in the workspace.
+ */
+size_t gsr_depth_loss_workspace_bytes(int H, int W);
+int gsr_depth_loss_forward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
+                           const float* l1_weight, const float* grad_mask, float lambda_l1, float lambda_smooth,
+                           void* workspace, float* out5, void* stream);
+int gsr_depth_loss_backward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
+                            const void* workspace, const float* upstream, float* dL_ddepth, void* stream);
+
+/*
  * ---- SURVEY 8(f) rank 4 (init-only): simple_knn ------------------------------------------------------------------
  * mean_dist2[i] = mean of the three smallest squared fp32 distances from point i to the OTHER points.  Replaces
  * simple_knn._C.distCUDA2 (submodules/simple-knn/simple_knn.cu:185-220, spatial.cu), called once by

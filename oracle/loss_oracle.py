@@ -77,3 +77,56 @@ def value_and_grad(image, gt, weight=None, lambda_dssim=0.2, scale=1.0, dtype=to
         l1 = l1_loss(x, y) if w is None else l1_loss_masked(x, y, w)
         ss = ssim(x, y) if w is None else ssim_masked(x, y, w)
     return float(loss.detach()), float(l1), float(ss), x.grad.numpy()
+
+
+# ---- depth terms (train.py:548-573) -------------------------------------------------------------------------------
+def compute_scale_and_shift(prediction, target, mask):  # loss_utils.py:77-104
+    a_00 = torch.sum(mask * prediction * prediction, (1, 2))
+    a_01 = torch.sum(mask * prediction, (1, 2))
+    a_11 = torch.sum(mask, (1, 2))
+    b_0 = torch.sum(mask * prediction * target, (1, 2))
+    b_1 = torch.sum(mask * target, (1, 2))
+    x_0, x_1 = torch.zeros_like(b_0), torch.zeros_like(b_1)
+    det = a_00 * a_11 - a_01 * a_01
+    valid = det.nonzero()
+    x_0[valid] = (a_11[valid] * b_0[valid] - a_01[valid] * b_1[valid]) / det[valid]
+    x_1[valid] = (-a_01[valid] * b_0[valid] + a_00[valid] * b_1[valid]) / det[valid]
+    return x_0, x_1
+
+
+def reduction_batch_based(image_loss, M):  # :40-49
+    divisor = torch.sum(M)
+    return 0 if divisor == 0 else torch.sum(image_loss) / divisor
+
+
+def gradient_loss(prediction, target, mask):  # :58-74
+    M = torch.sum(mask, (1, 2))
+    diff = torch.mul(mask, prediction - target)
+    grad_x = torch.abs(diff[:, :, 1:] - diff[:, :, :-1]) * torch.mul(mask[:, :, 1:], mask[:, :, :-1])
+    grad_y = torch.abs(diff[:, 1:, :] - diff[:, :-1, :]) * torch.mul(mask[:, 1:, :], mask[:, :-1, :])
+    return reduction_batch_based(torch.sum(grad_x, (1, 2)) + torch.sum(grad_y, (1, 2)), M)
+
+
+def depth_loss(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0):
+    """train.py:548-561 (reference view: weights None) / :563-573 (other views: l1_weight = grad_mask = valid_mask)."""
+    ones = torch.ones_like(depth)
+    m = ones if lsq_mask is None else lsq_mask
+    scale, shift = compute_scale_and_shift(depth, target, m)          # train.py:551
+    scale = torch.abs(scale)                                          # :552
+    aligned = scale.view(-1, 1, 1) * depth + shift.view(-1, 1, 1)     # :553
+    loss = lambda_l1 * (l1_loss(aligned, target) if l1_weight is None else l1_loss_masked(aligned, target, l1_weight))
+    g = ones if grad_mask is None else grad_mask
+    for k in range(4):                                                # :558-561
+        step = pow(2, k)
+        loss = loss + 0.5 * lambda_smooth * gradient_loss(aligned[:, ::step, ::step], target[:, ::step, ::step], g[:, ::step, ::step])
+    return loss, scale, shift
+
+
+def depth_value_and_grad(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0,
+                         dtype=torch.float64):
+    t = lambda a: None if a is None else torch.as_tensor(a).to(dtype).reshape(1, *torch.as_tensor(a).shape[-2:])
+    d = t(depth).clone().requires_grad_(True)
+    loss, scale, shift = depth_loss(d, t(target), t(lsq_mask), t(l1_weight), t(grad_mask), lambda_l1, lambda_smooth)
+    loss.backward()
+    return float(loss.detach()), float(scale.detach()), float(shift.detach()), d.grad[0].numpy()
+

@@ -34,7 +34,26 @@ def make_inputs(c):
     return img, gt, w
 
 
+def depth_cases():
+    return {"depth_ref_view": dict(seed=11, H=33, W=47, masked=False, l1=1.0, sm=0.5),
+            "depth_other_view": dict(seed=12, H=40, W=29, masked=True, l1=0.7, sm=0.4)}
+
+
+def make_depth_inputs(c):
+    rng = np.random.default_rng(c["seed"])
+    y = (rng.random((c["H"], c["W"])) * 5 + 1).astype(np.float32)
+    d = (0.6 * y + 0.4 + 0.08 * rng.standard_normal(y.shape)).astype(np.float32)
+    m = (rng.random(y.shape) > 0.3).astype(np.float32)
+    return d, y, m, (m if c["masked"] else None)
+
+
 def main():
+    for name, c in depth_cases().items():
+        d, y, m, wg = make_depth_inputs(c)
+        loss, s, t, grad = LO.depth_value_and_grad(d, y, m, wg, wg, c["l1"], c["sm"])
+        np.savez_compressed(os.path.join(HERE, "loss_" + name + ".npz"), loss=np.float64(loss), scale=np.float64(s), shift=np.float64(t),
+                            grad=grad.astype(np.float64))
+        print(name, loss, s, t)
     for name, c in cases().items():
         img, gt, w = make_inputs(c)
         loss, l1, ss, grad = LO.value_and_grad(img, gt, w, c["lam"], c["scale"])

@@ -97,3 +97,66 @@ def test_full_size_properties_and_reproducibility():
         fd = (float(L.rgb_loss(x + eps * d, y)) - float(L.rgb_loss(x - eps * d, y))) / (2 * eps)
     an = float((g1 * d).sum())
     assert an > 0 and abs(fd - an) < 5e-2 * an, (fd, an)
+
+
+# ---- depth terms --------------------------------------------------------------------------------------------------
+def _depth_case(seed, H, W, masked):
+    rng = np.random.default_rng(seed)
+    y = (rng.random((H, W)) * 5 + 1).astype(np.float32)                      # "midas" target
+    d = (0.6 * y + 0.4 + 0.08 * rng.standard_normal((H, W))).astype(np.float32)  # rendered depth: affine + noise
+    m = (rng.random((H, W)) > 0.3).astype(np.float32)
+    return d, y, m, (m if masked else None)
+
+
+@pytest.mark.parametrize("H,W,masked,seed", [(71, 112, False, 1), (142, 252, True, 2), (9, 17, True, 3), (1, 33, False, 4), (64, 64, True, 5)])
+def test_depth_loss_against_oracle(H, W, masked, seed):
+    """compute_scale_and_shift + |scale| + L1 + four-scale gradient loss, value and gradient through the fit."""
+    from gscream_amd import loss_utils as L
+    d, y, m, wg = _depth_case(seed, H, W, masked)
+    ref_loss, ref_s, ref_t, ref_g = LO.depth_value_and_grad(d, y, m, wg, wg, 0.7, 0.4)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda().reshape(1, H, W)
+    x = t(d).requires_grad_(True)
+    loss, parts = L.depth_loss(x, t(y), t(m), t(wg), t(wg), 0.7, 0.4, return_parts=True)
+    (1.5 * loss).backward()
+    assert abs(float(loss.detach()) - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    assert abs(float(parts[3]) - ref_s) < 2e-6 * max(1.0, abs(ref_s)) and abs(float(parts[4]) - ref_t) < 5e-6 * max(1.0, abs(ref_t))
+    got = x.grad.cpu().numpy().reshape(H, W) / 1.5
+    # |.| kinks: a pixel whose residual or edge difference sits within fp32 rounding of zero may take the other sign
+    bad = np.abs(got - ref_g) > 1e-4 * np.abs(ref_g).max()
+    assert bad.mean() <= 2e-3, float(bad.mean())
+
+
+def test_depth_loss_properties_full_size():
+    from gscream_amd import loss_utils as L
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = torch.rand((1, 567, 1008), device="cuda", generator=g) * 4 + 1
+    exact = (0.5 * y + 2.0)                       # exactly affine: the fit recovers it, every term vanishes
+    loss, parts = L.depth_loss(exact, y, None, None, None, 1.0, 1.0, return_parts=True)
+    assert float(loss) < 1e-5 and abs(float(parts[3]) - 2.0) < 1e-4 and abs(float(parts[4]) + 4.0) < 1e-3
+    d = (exact + 0.05 * torch.randn(y.shape, device="cuda", generator=g)).requires_grad_(True)
+    a = L.depth_loss(d, y, None, None, None, 1.0, 0.5)
+    a.backward()
+    g1 = d.grad.clone()
+    d.grad = None
+    b = L.depth_loss(d, y, None, None, None, 1.0, 0.5)
+    b.backward()
+    assert float(a) == float(b) and torch.equal(g1, d.grad), "bit-reproducible"
+    # the loss is invariant to an affine change of the input depth (the fit absorbs it): gradient is orthogonal to 1 and d
+    assert abs(float(g1.sum())) < 1e-4 * float(g1.abs().sum()) and abs(float((g1 * d.detach()).sum())) < 1e-4 * float((g1.abs() * d.detach().abs()).sum())
+
+
+@pytest.mark.parametrize("name", sorted(MLG.depth_cases().keys()))
+def test_depth_golden(name):
+    from gscream_amd import loss_utils as L
+    c = MLG.depth_cases()[name]
+    d, y, m, wg = MLG.make_depth_inputs(c)
+    exp = np.load(os.path.join(ROOT, "tests", "golden", "loss_" + name + ".npz"))
+    H, W = d.shape
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda().reshape(1, H, W)
+    x = t(d).requires_grad_(True)
+    loss, parts = L.depth_loss(x, t(y), t(m), t(wg), t(wg), c["l1"], c["sm"], return_parts=True)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(exp["loss"])) < 2e-6 and abs(float(parts[3]) - float(exp["scale"])) < 2e-6
+    bad = np.abs(x.grad.cpu().numpy().reshape(H, W) - exp["grad"]) > 1e-4 * np.abs(exp["grad"]).max()
+    assert bad.mean() <= 2e-3
+

@@ -69,3 +69,29 @@ def test_knn_oracle_against_brute_force():
     ref = np.sort(d2, axis=1)[:, :3].mean(1)
     assert np.allclose(KO.mean_dist2(pts), ref, rtol=1e-12, atol=1e-15)
     assert KO.mean_dist2(pts[:0]).shape == (0,) and np.all(KO.mean_dist2(pts[:3]) > 1e37)
+
+
+def test_depth_oracle_gradient_and_fixtures():
+    """The depth terms: autograd gradient (through the least-squares fit) against finite differences, the closed-form
+    fit against numpy's lstsq, and the committed fixtures."""
+    rng = np.random.default_rng(5)
+    y = rng.random((7, 9)) * 4 + 1
+    d = 0.8 * y - 0.3 + 0.1 * rng.standard_normal(y.shape)
+    m = (rng.random(y.shape) > 0.25).astype(np.float64)
+    loss, s, t, g = LO.depth_value_and_grad(d, y, m, m, m, 0.9, 0.6)
+    A = np.stack([d[m > 0], np.ones(int(m.sum()))], 1)
+    sol = np.linalg.lstsq(A, y[m > 0], rcond=None)[0]
+    assert abs(abs(sol[0]) - s) < 1e-9 and abs(sol[1] - t) < 1e-9
+    eps = 1e-6
+    for idx in [(0, 0), (3, 4), (6, 8), (2, 7)]:
+        dp, dm = d.copy(), d.copy()
+        dp[idx] += eps
+        dm[idx] -= eps
+        fd = (LO.depth_value_and_grad(dp, y, m, m, m, 0.9, 0.6)[0] - LO.depth_value_and_grad(dm, y, m, m, m, 0.9, 0.6)[0]) / (2 * eps)
+        assert abs(fd - g[idx]) < 1e-6 * max(1.0, abs(fd)), (idx, fd, g[idx])
+    for name, c in MLG.depth_cases().items():
+        dd, yy, mm, wg = MLG.make_depth_inputs(c)
+        exp = np.load(os.path.join(ROOT, "tests", "golden", "loss_" + name + ".npz"))
+        l2, s2, t2, g2 = LO.depth_value_and_grad(dd, yy, mm, wg, wg, c["l1"], c["sm"])
+        assert abs(l2 - float(exp["loss"])) < 1e-12 and np.allclose(g2, exp["grad"], rtol=0, atol=1e-14)
+
