@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = (
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
-    "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward",
+    "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward", "gsr_training_stats",
 )
 NUM_STAGES = 7
 
@@ -107,6 +107,8 @@ def load():
     lib.gsr_depth_loss_forward.argtypes = [_c_int, _c_int] + [_vp] * 5 + [_c_float, _c_float, _vp, _vp, _vp]
     lib.gsr_depth_loss_backward.restype = _c_int
     lib.gsr_depth_loss_backward.argtypes = [_c_int, _c_int] + [_vp] * 7
+    lib.gsr_training_stats.restype = _c_int
+    lib.gsr_training_stats.argtypes = [_c_int, _c_int] + [_vp] * 11
     _lib = lib
     return lib
 

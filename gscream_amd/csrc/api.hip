@@ -507,3 +507,20 @@ extern "C" int gsr_depth_loss_backward(int H, int W, const float* depth, const f
     return GSR_OK;
 }
 
+// ---- densification statistics (stats.hip) ----
+extern "C" int gsr_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity, const uint8_t* selection,
+                                  const uint32_t* first, const uint8_t* update_filter, const float* viewspace_grad,
+                                  float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
+                                  float* offset_denom, void* stream)
+{
+    if (Nv < 0 || K < 1) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "training stats: bad sizes Nv=%d K=%d", Nv, K);
+    if (Nv == 0) return GSR_OK;
+    if (!neural_opacity || !selection || !first || !opacity_accum || !anchor_demon || !offset_gradient_accum || !offset_denom)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "training stats: a required pointer is NULL");
+    // update_filter / viewspace_grad may be NULL only if no offset was selected (M = 0); the kernel then never reads them
+    GSR_HIP(gst_launch_training_stats(Nv, K, visible, neural_opacity, selection, first, update_filter, viewspace_grad,
+                                      opacity_accum, anchor_demon, offset_gradient_accum, offset_denom, (hipStream_t)stream),
+            "training stats");
+    return GSR_OK;
+}
+

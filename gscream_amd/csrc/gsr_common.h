@@ -212,3 +212,9 @@ hipError_t gdl_launch_forward(int H, int W, const float* depth, const float* tar
                               void* workspace, float* out5, hipStream_t stream);
 hipError_t gdl_launch_backward(int H, int W, const float* depth, const float* target, const float* lsq_mask,
                                const void* workspace, const float* upstream, float* dL_ddepth, hipStream_t stream);
+
+// ---- stats.hip (densification statistics) ----
+hipError_t gst_launch_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity,
+                                     const uint8_t* selection, const uint32_t* first, const uint8_t* update_filter,
+                                     const float* viewspace_grad, float* opacity_accum, float* anchor_demon,
+                                     float* offset_gradient_accum, float* offset_denom, hipStream_t stream);

@@ -1,0 +1,52 @@
+// stats.hip -- densification statistics of one training iteration (second half).
+//
+// Replaces the body of GScream's scene/gaussian_model.py:730-757 GaussianModel.training_statis: ~15 boolean-mask
+// indexing ops (each a nonzero + gather/scatter with a host sync) become one kernel, one thread per visible anchor:
+//   opacity_accum[a]        += sum_k max(neural_opacity[n, k], 0)                                   (:733-737)
+//   anchor_demon[a]         += 1                                                                    (:746)
+//   for every offset k the decode kept (selection mask) whose Gaussian passed the update filter (radii > 0):
+//     offset_gradient_accum[a*K + k] += |viewspace_grad[row, :2]|,   offset_denom[a*K + k] += 1     (:749-757)
+// with a = visible[n] the anchor's row in the model and row = first[n] + rank of k among the kept offsets -- the same
+// bookkeeping the decode produced (gsr_decode_count), so nothing is re-derived on the host.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr_common.h"
+
+__global__ void __launch_bounds__(256) gst_training_stats_kernel(
+    int Nv, int K, const int32_t* __restrict__ visible, const float* __restrict__ neural_opacity,
+    const uint8_t* __restrict__ selection, const uint32_t* __restrict__ first, const uint8_t* __restrict__ update_filter,
+    const float* __restrict__ viewspace_grad /*[M,3]*/, float* __restrict__ opacity_accum, float* __restrict__ anchor_demon,
+    float* __restrict__ offset_gradient_accum, float* __restrict__ offset_denom)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= Nv) return;
+    const int a = visible ? visible[n] : n;
+    float osum = 0.f;
+    uint32_t row = first[n];
+    for (int k = 0; k < K; k++) {
+        const float op = neural_opacity[(size_t)n * K + k];
+        osum += op < 0.f ? 0.f : op;
+        if (!selection[(size_t)n * K + k]) continue;
+        if (update_filter[row]) {
+            const float gx = viewspace_grad[3 * (size_t)row], gy = viewspace_grad[3 * (size_t)row + 1];
+            offset_gradient_accum[(size_t)a * K + k] += sqrtf(gx * gx + gy * gy);
+            offset_denom[(size_t)a * K + k] += 1.0f;
+        }
+        row++;
+    }
+    opacity_accum[a] += osum;
+    anchor_demon[a] += 1.0f;
+}
+
+hipError_t gst_launch_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity,
+                                     const uint8_t* selection, const uint32_t* first, const uint8_t* update_filter,
+                                     const float* viewspace_grad, float* opacity_accum, float* anchor_demon,
+                                     float* offset_gradient_accum, float* offset_denom, hipStream_t stream)
+{
+    if (Nv <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gst_training_stats_kernel, dim3((Nv + 255) / 256), dim3(256), 0, stream, Nv, K, visible, neural_opacity,
+                       selection, first, update_filter, viewspace_grad, opacity_accum, anchor_demon, offset_gradient_accum,
+                       offset_denom);
+    return hipGetLastError();
+}

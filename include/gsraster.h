@@ -208,6 +208,19 @@ int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t
                         float* d_offsets, float* d_grid_scaling, float* D2, float* D1, float* H, float* X, void* stream);
 
 /*
+ * Densification statistics of one training iteration: replaces the body of
+ * GaussianModel.training_statis (scene/gaussian_model.py:730-757).  Nv visible anchors, K offsets each.
+ * visible[Nv] (int32 rows of the model, NULL = identity), neural_opacity[Nv*K], selection[Nv*K] (u8, the decode's
+ * mask), first[Nv] (u32, first output row of each anchor: gsr_decode_count), update_filter[M] (u8: radii > 0 of the
+ * decoded Gaussians), viewspace_grad[M,3] (gradient of the screen-space means).  Accumulates IN PLACE into the
+ * model-sized opacity_accum[N], anchor_demon[N], offset_gradient_accum[N*K], offset_denom[N*K] (fp32).
+ */
+int gsr_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity, const uint8_t* selection,
+                       const uint32_t* first, const uint8_t* update_filter, const float* viewspace_grad,
+                       float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
+                       void* stream);
+
+/*
  * ---- the image-space RGB loss that follows the rasterizer ----------------------------------
  * Fused weighted L1 + weighted SSIM (11x11 Gaussian window, sigma 1.5, zero padding), value and gradient:
  *     L = a_l1 * mean(|img - gt| * m) + a_ssim * mean(ssim_map(img, gt) * m),   m = weight[H,W] (1 when NULL),

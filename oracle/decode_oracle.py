@@ -77,3 +77,20 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     if is_training:
         return xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask
     return xyz, color, opacity, uncertainty, scaling, rot
+
+
+def training_statis(self, viewspace_point_tensor, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
+    """scene/gaussian_model.py:730-757, restated (`self` needs n_offsets and the four accumulators)."""
+    temp_opacity = opacity.clone().view(-1).detach()
+    temp_opacity[temp_opacity < 0] = 0
+    temp_opacity = temp_opacity.view([-1, self.n_offsets])
+    self.opacity_accum[anchor_visible_mask] += temp_opacity.sum(dim=1, keepdim=True)
+    self.anchor_demon[anchor_visible_mask] += 1
+    anchor_visible_mask = anchor_visible_mask.unsqueeze(dim=1).repeat([1, self.n_offsets]).view(-1)
+    combined_mask = torch.zeros_like(self.offset_gradient_accum, dtype=torch.bool).squeeze(dim=1)
+    combined_mask[anchor_visible_mask] = offset_selection_mask
+    temp_mask = combined_mask.clone()
+    combined_mask[temp_mask] = update_filter
+    grad_norm = torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+    self.offset_gradient_accum[combined_mask] += grad_norm
+    self.offset_denom[combined_mask] += 1

@@ -108,3 +108,30 @@ def test_feeds_the_rasterizer_at_scale():
     img.mean().backward()
     assert dut._anchor_feat.grad is not None and torch.isfinite(dut._anchor_feat.grad).all() and dut._anchor_feat.grad.abs().sum() > 0
     assert dut.mlp_color[2].weight.grad.abs().sum() > 0
+
+
+def test_training_statistics_against_oracle():
+    """GaussianModel.training_statis (densification statistics) after a real decode + render + backward, twice
+    (the accumulators add up), against the restated reference on the CPU."""
+    import types
+    from gscream_amd.densify_stats import training_statis
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    N, K = 1200, 10
+    ref, dut = _pair(N, K, 31)
+    g = torch.Generator().manual_seed(31)
+    mk = lambda dev: types.SimpleNamespace(n_offsets=K, opacity_accum=torch.zeros(N, 1, device=dev), anchor_demon=torch.zeros(N, 1, device=dev),
+                                           offset_gradient_accum=torch.zeros(N * K, 1, device=dev), offset_denom=torch.zeros(N * K, 1, device=dev))
+    acc_d, acc_r = mk("cuda"), mk("cpu")
+    cam_d = DO.Camera(torch.tensor(CAM, device="cuda"))
+    for it in range(2):
+        vm = torch.rand(N, generator=g) > 0.3
+        xyz, color, opacity, unc, scaling, rot, nop, mask = generate_neural_gaussians(cam_d, dut, vm.cuda(), True)
+        M = xyz.shape[0]
+        update_filter = torch.rand(M, generator=g) > 0.4                      # stands for radii > 0
+        vsp = types.SimpleNamespace(grad=torch.randn(M, 3, generator=g))
+        training_statis(acc_d, types.SimpleNamespace(grad=vsp.grad.cuda()), nop, update_filter.cuda(), mask, vm.cuda())
+        DO.training_statis(acc_r, vsp, nop.detach().cpu(), update_filter, mask.cpu(), vm)
+    for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        a, b = getattr(acc_d, name).cpu(), getattr(acc_r, name)
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-6, atol=1e-7), name
+    assert acc_d.anchor_demon.max() == 2 and acc_d.offset_denom.sum() > 0
