@@ -203,7 +203,8 @@ def test_rgb_only_variant_matches_full_kernel(scene):
 
 
 @pytest.mark.parametrize("seed,P,W,H,use", [(1, 1_000_000, 1008, 567, (True, False, False)),   # config 2: RGB-only gradients
-                                            (2, 1_000_000, 1008, 567, (True, True, True))])    # config 3: all three maps
+                                            (2, 1_000_000, 1008, 567, (True, True, True)),     # config 3: all three maps
+                                            (3, 2_000_000, 1920, 1080, (True, True, True))])   # config 4: 2M @1080p
 def test_full_size_element_wise_parity(seed, P, W, H, use):
     """Direct element-wise parity at BASELINE's size: the OpenMP oracle does 1M Gaussians @1008x567 in about a second
     per pass on the GPU box's host cores.  Radii bit-exact for every Gaussian; images within 1e-4 except threshold
