@@ -22,7 +22,9 @@ import torch.nn as nn
 from . import _native
 
 _tuning = _native.Tuning()
-_capacity_hint = {}  # per-device: binning capacity that let the last forward run without a host round trip
+_capacity_hint = {}  # per-device: (binning capacity, longest-list provision) for the next speculative forward
+_recent = {}         # per-device: (num_rendered, max_tile_count) of the last few forwards (training hops between views)
+_RECENT_FRAMES = 8
 _pinned = {}  # per-device pinned int32[4] that receives gsr_stage1_result (truly asynchronous D2H copy)
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
@@ -35,6 +37,7 @@ def set_tuning(tile_cull=True, speculative=True):
     _tuning.disable_tile_cull = 0 if tile_cull else 1
     _tuning.disable_speculation = 0 if speculative else 1
     _capacity_hint.clear()
+    _recent.clear()
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -146,9 +149,15 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
                                         _native.ptr(img), _native.ptr(binning), *outs, _native.ctypes.byref(_tuning),
                                         debug, stream)
             _native.check(rc, "gsr_forward_stage2")
-        # second field: provision for the longest tile list (sizes the LDS of the per-tile sort; a tight value lets
-        # more sort workgroups be resident); exceeded -> GSR_NEED_CAPACITY -> stage 2 is redone above
-        _capacity_hint[dev.index] = (int(1.25 * R) + 65536, max(1024, int(1.25 * res.max_tile_count) + 64))
+        # Provision for the next call from the largest of the last few frames (a trainer hops between views, so the
+        # previous frame alone is a poor predictor): binning capacity, and the longest tile list (sizes the LDS of the
+        # per-tile sort; a tight value lets more sort workgroups be resident).  Exceeded -> GSR_NEED_CAPACITY -> stage 2
+        # is redone above.
+        hist = _recent.setdefault(dev.index, [])
+        hist.append((R, int(res.max_tile_count)))
+        del hist[:-_RECENT_FRAMES]
+        _capacity_hint[dev.index] = (int(1.25 * max(h[0] for h in hist)) + 65536,
+                                     max(1024, int(1.25 * max(h[1] for h in hist)) + 64))
     _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots),
                         binning_capacity=cap, speculative=done)
     return R, color, depth, unc, radii, geom, binning, img, cap
