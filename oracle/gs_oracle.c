@@ -12,6 +12,12 @@
  * cannot be built or run here without writing stand-ins for those headers -- which the
  * task forbids.  The only reference-derived numbers available are the five filter-API
  * known answers recorded in SURVEY.md Appendix B-6; tests/test_oracle.py checks them.
+ * Two pieces of the path ARE pinned by vectors the reference's own importable Python
+ * computed in the build container (tests/golden/make_reference_vectors.py ->
+ * tests/golden/ref_camera.npz, ref_sh.npz; checked by tests/test_reference_vectors.py):
+ * the camera-matrix convention (utils/graphics_utils.py:38-76 as composed by
+ * scene/cameras.py) and the SH colour expansion incl. the clamp flags
+ * (utils/sh_utils.py:57-115, the Python twin of forward.cu:19-71).
  * Everything else is pinned by (a) closed-form known answers derived from the reference
  * source and (b) an independent float64 autograd restatement (oracle/naive_torch.py).
  *

@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE ONLY -- see the header of gs_oracle.c.  Only tests/, the smoke check in
 __graft_entry__.py and bench.py's cpu_baseline leg import this module.  Parity status of the
 oracle itself: *parity unpinned* (the reference ships no golden vectors and cannot be built
-here); see DESIGN.md section "Oracle".
+here), except the camera convention and the SH colours, which tests/test_reference_vectors.py
+pins with vectors the reference's own Python helpers computed; see DESIGN.md section "Oracle".
 
 The call structure mirrors the reference's C++ entry points
 (DGR/rasterize_points.cu:35-122 forward, :124-211 backward, :213-373 filters), with numpy
