@@ -88,6 +88,48 @@ __device__ __forceinline__ float gsr_pair_step(float a, float b, bool hi)
     return keep + gsr_dpp<CTRL>(send);
 }
 
+// Row-level part of the transposing wave reduction of the backward blend.  A pair step merges two registers (a, b)
+// into one whose even banks (4-lane groups of a DPP row) hold a + rot(a) and whose odd banks hold b + rot(b): two
+// v_add_f32_dpp with complementary bank masks, no select.  The second step (row_ror:8) does the same with the bank
+// pairs {0,1} / {2,3}.  After both, bank k of the result holds, in each of its four lanes, the sum over the row's lanes
+// of equal (lane & 3) of one value: q0 = {s0, s1, s2, s3|s5}, q1 = {s4..s7 | s6..s9}, q2 = {s8, s9, s10, s10 | s10 x4}.
+// Inline assembly because the masked write of a DPP destination has no IR form; the s_nop cover the VALU-write ->
+// DPP-read hazard against the surrounding compiler-scheduled code (inside the block producers and consumers are
+// at least two instructions apart).
+#define GSR_PAIR4(dst, a, b)                                                     \
+    "v_add_f32_dpp " dst ", " a ", " a " row_ror:4 row_mask:0xf bank_mask:0x5\n\t" \
+    "v_add_f32_dpp " dst ", " b ", " b " row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+#define GSR_PAIR8(dst, a, b)                                                     \
+    "v_add_f32_dpp " dst ", " a ", " a " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+    "v_add_f32_dpp " dst ", " b ", " b " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+template <bool AUX>
+__device__ __forceinline__ void gsr_bank_reduce(const float (&s)[11], float& q0, float& q1, float& q2)
+{
+    if (AUX) {
+        float r0, r1, r2, r3, r4, r5;
+        asm volatile("s_nop 1\n\t"
+                     GSR_PAIR4("%3", "%9", "%10") GSR_PAIR4("%4", "%11", "%12") GSR_PAIR4("%5", "%13", "%14")
+                     GSR_PAIR4("%6", "%15", "%16") GSR_PAIR4("%7", "%17", "%18")
+                     "v_add_f32_dpp %8, %19, %19 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                     GSR_PAIR8("%0", "%3", "%4") GSR_PAIR8("%1", "%5", "%6") GSR_PAIR8("%2", "%7", "%8")
+                     "s_nop 1"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+                     : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]),
+                       "v"(s[9]), "v"(s[10]));
+    } else {
+        float r0, r1, r2, r3, r4;
+        asm volatile("s_nop 1\n\t"
+                     GSR_PAIR4("%3", "%8", "%9") GSR_PAIR4("%4", "%10", "%11") GSR_PAIR4("%5", "%12", "%13")
+                     GSR_PAIR4("%6", "%14", "%15")
+                     "v_add_f32_dpp %7, %16, %16 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                     GSR_PAIR8("%0", "%3", "%4") GSR_PAIR8("%1", "%5", "%6")
+                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+                     : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]));
+    }
+}
+
 // The instance loops are software-pipelined: the wave's list indices sit one per lane (v_readlane instead of a
 // dependent LDS read) and the operands of instance k+1 are in flight while instance k is computed (measured winner
 // against the plain loop, profiles/).
@@ -279,7 +321,6 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     if (AUX && inside) { gd = dL_ddepth[pid]; gu = dL_dfeature[pid]; }
     const float bgdot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, ard = 0.f, aru = 0.f;
-    float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcd = 0.f, lcu = 0.f;
 
     // wave-level and block-level maxima of the last contributor: nothing at a position >= them is blended
     int wmax = lastc;
@@ -292,6 +333,15 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     __syncthreads();
     const int nproc = min(n, sMax);
     uint16_t* mylist = sList[wave];
+    // accumulator field this lane reports after the wave reduction (see gsr_bank_reduce), -1: none
+    int accfield = -1;
+    {
+        const int row = lane >> 4, bank = (lane >> 2) & 3;
+        if ((lane & 3) == 0) {
+            if (AUX) accfield = row == 0 ? bank : row == 2 ? 4 + bank : (row == 1 && bank < 3) ? 8 + bank : -1;
+            else accfield = row == 0 ? (bank < 3 ? bank : 5) : row == 2 ? 6 + bank : (row == 1 && bank == 0) ? 10 : -1;
+        }
+    }
     // Instances at list positions >= nproc were blended by no pixel of the tile: they are not traversed and their
     // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots
     // exist.  On the bench scene lists hold ~1185 instances and pixels saturate after ~276, so three quarters of the
@@ -348,70 +398,55 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                         float w = 0.f, g = 0.f;
                         const float4 C = sC[j];
                         if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
-                            const float rinv = GSR_RCP(1.0f - alpha);
+                            const float oma = 1.0f - alpha;
+                            const float rinv = GSR_RCP(oma);
                             const float Tn = Tr * rinv;  // T / (1 - alpha)
                             w = alpha * Tn;
-                            const float oml = 1.0f - la;
-                            ar0 = la * lc0 + oml * ar0; ar1 = la * lc1 + oml * ar1; ar2 = la * lc2 + oml * ar2;
+                            // ar* = colour accumulated BEHIND this instance (DGR backward.cu:546,559,566 update it
+                            // lazily from last_alpha / last_color at the top of the next contribution; updating it
+                            // here, right after its use, is the same arithmetic without the four carried registers)
                             float dL_dalpha = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
+                            ar0 = alpha * C.x + oma * ar0; ar1 = alpha * C.y + oma * ar1; ar2 = alpha * C.z + oma * ar2;
                             if (AUX) {
-                                ard = la * lcd + oml * ard; aru = la * lcu + oml * aru;
                                 dL_dalpha += (B.z - ard) * gd + (B.w - aru) * gu;
-                                lcd = B.z; lcu = B.w;
+                                ard = alpha * B.z + oma * ard; aru = alpha * B.w + oma * aru;
                             }
                             dL_dalpha *= Tn;
                             dL_dalpha += (-Tf * rinv) * bgdot;
                             g = G * dL_dalpha;
-                            Tr = Tn; la = alpha;
-                            lc0 = C.x; lc1 = C.y; lc2 = C.z;
+                            Tr = Tn;
                         }
                         float s[11];
                         const float gdx = g * dx, gdy = g * dy;
                         s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
                         s[3] = AUX ? w * gd : 0.f; s[4] = AUX ? w * gu : 0.f;
                         s[5] = gdx; s[6] = gdy; s[7] = gdx * dx; s[8] = gdx * dy; s[9] = gdy * dy; s[10] = g;
-                        // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly: the xor-1 and xor-2 steps
-                        // merge registers pairwise (lane l of a quad ends up owning value l & 3 of each group of
-                        // four), two row_ror steps sum the four quads of a DPP row, two lane-aligned cross-row adds
-                        // (v_permlane32_swap / v_permlane16_swap, gfx950) finish the wave sum, and lanes 0..8 (0..10)
-                        // issue ONE ds_add_f32 with distinct addresses.  26-31 VALU ops instead of 45-55 for nine to
-                        // eleven independent 4-step DPP reductions, and one LDS atomic instead of 9-11 (an LDS
-                        // atomic instruction costs ~13 LDS cycles whatever its lane count; measured, profiles/).
-                        const bool p1 = lane & 1, p2 = lane & 2;
+                        // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly whose pair steps need no
+                        // selects: within a DPP row the two bank-level steps (row_ror:4, row_ror:8) write the two
+                        // halves of the destination with complementary bank masks (gsr_bank_reduce), the cross-row
+                        // steps are v_permlane32_swap / v_permlane16_swap of TWO different registers followed by one
+                        // add, and the two quad steps run last on the single remaining register.  23 (26) VALU ops
+                        // for nine (eleven) values, then ONE ds_add_f32 from 9 (11) lanes with distinct addresses
+                        // (an LDS atomic instruction costs ~13 LDS cycles whatever its lane count; measured).
                         float q0, q1, q2;
-                        if (AUX) {
-                            const float r0 = gsr_pair_step<0xB1>(s[0], s[1], p1), r1 = gsr_pair_step<0xB1>(s[2], s[3], p1);
-                            const float r2 = gsr_pair_step<0xB1>(s[4], s[5], p1), r3 = gsr_pair_step<0xB1>(s[6], s[7], p1);
-                            const float r4 = gsr_pair_step<0xB1>(s[8], s[9], p1), r5 = s[10] + gsr_dpp<0xB1>(s[10]);
-                            q0 = gsr_pair_step<0x4E>(r0, r1, p2); q1 = gsr_pair_step<0x4E>(r2, r3, p2);
-                            q2 = gsr_pair_step<0x4E>(r4, r5, p2);  // quad lanes: s8, s9, s10, s10
-                        } else {
-                            const float r0 = gsr_pair_step<0xB1>(s[0], s[1], p1), r1 = gsr_pair_step<0xB1>(s[2], s[5], p1);
-                            const float r2 = gsr_pair_step<0xB1>(s[6], s[7], p1), r3 = gsr_pair_step<0xB1>(s[8], s[9], p1);
-                            const float r4 = s[10] + gsr_dpp<0xB1>(s[10]);
-                            q0 = gsr_pair_step<0x4E>(r0, r1, p2); q1 = gsr_pair_step<0x4E>(r2, r3, p2);
-                            q2 = r4 + gsr_dpp<0x4E>(r4);
-                        }
-                        q0 += gsr_dpp<0x124>(q0); q1 += gsr_dpp<0x124>(q1); q2 += gsr_dpp<0x124>(q2);  // row_ror:4
-                        // row_ror:8 finishes the row sums.  Lanes l and l+8 are partners in it, so the register a lane
-                        // will report is chosen BEFORE the step wherever both partners choose alike (bit 2: q0 / q1):
-                        // select + add + add + select instead of three adds and a three-way select.
-                        const float y0 = (lane & 4) ? q1 : q0;
-                        const float y = y0 + gsr_dpp<0x128>(y0);
-                        const float z = q2 + gsr_dpp<0x128>(q2);
-                        float x = (lane & 8) ? z : y;  // row lanes 0-3: q0's values, 4-7: q1's, 8-11: q2's
-                        // swap(x, x) leaves {lower half twice, upper half twice}: the sum of BOTH results is the
-                        // cross-half sum in every lane, and x itself is dead afterwards (one register copy, not two)
+                        gsr_bank_reduce<AUX>(s, q0, q1, q2);
+                        float v0, v1;
                         {
-                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-                            x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(q0), __float_as_uint(q1), false, false);
+                            v0 = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows 0-1: q0 over halves, rows 2-3: q1
                         }
                         {
-                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-                            x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2), __float_as_uint(q2), false, false);
+                            v1 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
                         }
-                        // lane -> accumulator field: AUX: identity (0..10); else {0,1,2,5,6,7,8,9,10}
-                        if (lane < (AUX ? 11 : 9)) atomicAdd(acc + j * GSR_SLOT_FLOATS + (AUX || lane < 3 ? lane : lane + 2), x);
+                        float x;
+                        {
+                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                            x = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // row 0: q0, row 2: q1, rows 1 and 3: q2
+                        }
+                        x += gsr_dpp<0xB1>(x);
+                        x += gsr_dpp<0x4E>(x);
+                        if (accfield >= 0) atomicAdd(acc + j * GSR_SLOT_FLOATS + accfield, x);
                     }
                     j = jn; A = An; B = Bn;
                 }
