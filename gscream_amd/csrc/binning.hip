@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(64 * GSR_COLSCAN_GROUPS) gsr_table_colscan_ker
 // Single block of 1024: exclusive scan of the tile totals -> ranges[t] = [start, end); info = {R, max count}.
 // Thread i owns ceil(T/1024) consecutive tiles; one DPP wave scan + 16 wave totals in LDS.
 __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
-                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ info)
+                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ info,
+                                                             uint32_t* __restrict__ tile_work)
 {
     __shared__ uint32_t wsum[16], wmax[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
         if (t0 + i >= T) break;
         const uint32_t v = tile_count[t0 + i];
         ranges[t0 + i] = make_uint2(run, run + v);
+        tile_work[t0 + i] = 0u;  // the forward blend's quadrant wavefronts atomicMax their traversal depth into it
         run += v;
     }
     if (threadIdx.x == 0) { info[0] = total; info[1] = gmax; }
@@ -461,7 +463,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
     }
     // (3) tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
-                       image.info);
+                       image.info, image.tile_work);
     return hipGetLastError();
 }
 

@@ -2,37 +2,41 @@
 //
 // Replaces DGR forward.cu:441-568 renderCUDA (fwd) and backward.cu:409-604 renderCUDA (bwd).
 //
-// Mapping onto CDNA4.  One 256-thread workgroup (4 wavefronts of 64) per 16x16 screen tile; wavefront w owns
-// the 8x8 pixel QUADRANT (w & 1, w >> 1) of the tile, lane l the pixel (l & 7, l >> 3) inside it.
-//   * Tile lists are consumed in batches of 256 instances.  Thread i gathers the 64-byte record of instance i
-//     (three 16-byte loads fwd, four bwd) into LDS as float4 SoA arrays, and -- once per instance, not once per
-//     pixel -- tests the Gaussian's alpha >= 1/255 ellipse against the four quadrant boxes (gsr_box_min_q).
-//     Each wave then compacts, with ballot + mbcnt, the indices of the instances that can reach ITS quadrant
-//     into a private LDS list and walks only those: a typical splat touches 1-2 of the 4 quadrants, so the
-//     per-pixel test loop shrinks accordingly and the hit rate of what remains goes up.  The reference tests
-//     every instance of the tile against all 256 pixels (forward.cu:513-553).
-//   * Per-Gaussian operands are read back from LDS with same-address (broadcast) ds_read_b128, conflict-free,
-//     software-pipelined one instance ahead; the list index comes from a per-lane copy via v_readlane (no
-//     dependent LDS read).  The reference re-reads colour and depth from GLOBAL memory per contribution
-//     (forward.cu:545-546).  (Broadcasting the operands themselves with v_readlane was measured slower.)
-//   * Early-out: a wave leaves the batch when all its pixels are done (__all); in the backward a wave skips
-//     gradient math + reduction when none of its pixels blends the instance (__any); the block leaves when
-//     every wave is done (__syncthreads_and).
+// Mapping onto CDNA4.  16x16 screen tiles as in the reference; wavefront = one 8x8 pixel QUADRANT of a tile, lane l
+// the pixel (l & 7, l >> 3) inside it.
+//   * Forward: 4T independent single-wave workgroups (see gsr_blend_fwd_kernel).  Each walks its tile's list on its own
+//     in batches of 64 instances, tests every instance against ITS quadrant box (gsr_box_min_q: can alpha reach 1/255
+//     anywhere in the box?), writes the survivors in list order into LDS as PAIR records and evaluates two instances
+//     per loop iteration with packed fp32 instructions.  No workgroup barriers, no waiting for sibling quadrants.
+//     The reference tests every instance of the tile against all 256 pixels (forward.cu:513-553) and re-reads colour
+//     and depth from GLOBAL memory per contribution (forward.cu:545-546).
+//   * Backward: one 256-thread workgroup (4 wavefronts) per tile, because the four quadrants add into the same
+//     per-(instance, tile) gradient slot.  Lists are consumed in batches of 256 instances: thread i gathers the record of
+//     instance i into LDS as float4 SoA arrays and computes the 4-bit quadrant mask once per instance; each wave
+//     compacts, with ballot + mbcnt, the indices of the instances that can reach ITS quadrant into a private LDS
+//     list and walks only those.  Operands come back with same-address (broadcast) ds_read_b128, software-pipelined
+//     one instance ahead; the list index comes from a per-lane copy via v_readlane (no dependent LDS read).
+//   * Early-out: a forward wave stops when all its pixels are saturated; a backward wave skips gradient math +
+//     reduction when none of its pixels blends the instance, and instances behind the tile's deepest contributor are
+//     not even loaded.
 //   * Backward gradient scatter: the reference issues 11 global atomicAdd per (pixel, Gaussian) contribution
-//     (backward.cu:554-601).  Here each lane forms 11 partials (colour, depth, feature and six moments of
-//     G dL/dalpha), every partial is summed over the 16 lanes of a DPP row with 4 DPP adds, value i is kept in
-//     lane i, two lane-aligned cross-row adds (v_permlane32_swap / v_permlane16_swap) finish the wave sum, and
-//     lanes 0..10 add into an LDS accumulator [256][12] with ONE ds_add_f32 (built with
-//     -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch,
-//     thread i stores the 12 floats of instance i with three plain 16-byte stores into that instance's private
-//     gradient slot (slot = Gaussian's scan offset + tile position inside its rectangle); gauss_bwd.hip sums
-//     each Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a tile's 4 wavefronts
-//     are unordered, so two runs agree to rounding, not bit for bit.)
+//     (backward.cu:554-601).  Here each lane forms 9 (11) partials (colour, depth, feature and six moments of
+//     G dL/dalpha), the wave reduces them with a select-free transposing butterfly (gsr_bank_reduce + permlane swaps,
+//     23-26 VALU operations) and 9 (11) lanes add into an LDS accumulator [256][12] with ONE ds_add_f32 (built with
+//     -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch, thread i stores the
+//     12 floats of instance i with three plain 16-byte stores into that instance's private gradient slot (slot =
+//     Gaussian's scan offset + rank of the tile among the surviving tiles of its rectangle); gauss_bwd.hip sums each
+//     Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a tile's 4 wavefronts are unordered,
+//     so two runs agree to rounding, not bit for bit.)
 //   * AUX = false specialises the backward for "no gradient flows into the depth and feature maps" (GScream's
 //     RGB-only iterations): 9 instead of 11 reductions and no depth/feature recurrences.
 //   * XCD awareness: workgroup b runs on XCD b % 8 (observed dispatch rule); the block->tile map hands each
 //     XCD a contiguous band of tile rows so neighbouring tiles, which share most of their Gaussians, hit the
 //     same 4 MiB L2.  Pure speed: any placement gives the same result.
+//   * Scheduling (measured with the `make trace` build, tools/wave_trace.py): nearly all wavefronts of a launch are
+//     resident from the start, so a launch lasts as long as its most loaded SIMD; the backward is launched deepest
+//     tile first (gsr_tile_order_kernel), which hands every SIMD one tile of each depth stratum.
+#include <cstdlib>
 #include "gsr_math.h"
 
 #define GSR_BATCH 256
@@ -51,6 +55,29 @@
 // wave votes on lane masks the compiler already holds (HIP's __all/__any materialise a 0/1 VGPR first)
 #define GSR_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
 #define GSR_ALL(p) (__builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true))
+
+// -DGSR_TRACE (diagnostic build `make trace`, not shipped): every wavefront of the backward blend records its start and
+// end time (100 MHz wall clock) and the hardware slot it ran on (HW_ID, XCC_ID); tools/wave_trace.py reads them back.
+#ifdef GSR_TRACE
+__device__ unsigned long long gsr_trace_buf[2 * 4 * 4 * 36864];  // [backward | forward]
+#define GSR_TRACE_BEGIN const unsigned long long gsr_tr0 = wall_clock64();
+#define GSR_TRACE_END(NW) GSR_TRACE_END_AT(NW, 0)
+#define GSR_TRACE_END_AT(NW, BASE)                                                             \
+    if ((threadIdx.x & 63) == 0) {                                                             \
+        const size_t o = (size_t)(BASE) + ((size_t)blockIdx.x * (NW) + (threadIdx.x >> 6)) * 4; \
+        gsr_trace_buf[o] = gsr_tr0; gsr_trace_buf[o + 1] = wall_clock64();                     \
+        gsr_trace_buf[o + 2] = __builtin_amdgcn_s_getreg(63492); /* HW_ID, 32 bits */          \
+        gsr_trace_buf[o + 3] = __builtin_amdgcn_s_getreg(63508); /* XCC_ID */                  \
+    }
+extern "C" int gsr_debug_trace(void* host_dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gsr_trace_buf), bytes);
+}
+#else
+#define GSR_TRACE_BEGIN
+#define GSR_TRACE_END(NW)
+#define GSR_TRACE_END_AT(NW, BASE)
+#endif
 
 __device__ __forceinline__ int gsr_tile_of_block(int b, int T)
 {
@@ -171,102 +198,139 @@ __device__ __forceinline__ int gsr_compact(const uint32_t* sQ, uint16_t* list, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward
+// Forward, one independent wavefront per 8x8 quadrant, two instances per loop iteration.
+//
+// A 64-thread workgroup owns ONE quadrant of a tile and walks the tile's list on its own: lane i fetches the record of
+// instance i of the current 64-instance batch (the next batch's loads are in flight while this one is blended), tests
+// it against the quadrant box, and the survivors are written, in list order, to LDS as PAIR records
+//     {x_a, x_b, y_a, y_b} {hA_a, hA_b, hB_a, hB_b} {hC_a, hC_b, op_a, op_b} {i_a, i_b, feature_a, feature_b}
+// so that four same-address ds_read_b128 hand the alpha evaluation of two instances to v_pk_* instructions
+// (16 VALU operations for two instances instead of 14 for one) and give each wave two independent dependency chains.
+// Nothing is shared between the quadrants of a tile: no workgroup barriers, a quadrant whose pixels are saturated stops
+// while its siblings go on, and the launch consists of 4T independently scheduled wavefronts instead of T groups of
+// four that wait for each other.  Each record is fetched by the four quadrant waves of its tile (L2 hits: the four
+// run on the same XCD).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
+#define GSR_FWB 64
+typedef float gsr_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gsr_f2 gsr_splat(float v) { gsr_f2 r = {v, v}; return r; }
+__device__ __forceinline__ gsr_f2 gsr_fma2(gsr_f2 a, gsr_f2 b, gsr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_work, uint32_t capacity, uint32_t longest_sorted)
 {
-    __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
-    __shared__ uint32_t sQ[GSR_BATCH];
-    __shared__ uint16_t sList[4][GSR_BATCH];
+    __shared__ float4 sPair[GSR_FWB / 2][4];
+    __shared__ float4 sC[GSR_FWB];
 
-    const int tile = gsr_tile_of_block(blockIdx.x, T);
+    GSR_TRACE_BEGIN
+    const int u = gsr_tile_of_block(blockIdx.x, 4 * T);  // quadrant tasks in tile order, one contiguous band per XCD
+    const int tile = u >> 2, quad = u & 3;
     const int tx = tile % gx, ty = tile / gx;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int lane = threadIdx.x;
+    const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
+    if (qx0 >= W || qy0 >= H) return;  // quadrant entirely off the image
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)qx0, by0 = (float)qy0, bx1 = (float)min(qx0 + 7, W - 1), by1 = (float)min(qy0 + 7, H - 1);
     const uint2 rg = ranges[tile];
-    // a list that does not fit the workspace was neither scattered completely nor sorted (speculative launch that
-    // the host redoes): treat it as empty instead of following unsorted ids
-    // (likewise a list longer than what the sort was provisioned for from a stale hint: point_list holds no ids for it)
+    // lists that were not (completely) scattered or sorted by a speculative launch are treated as empty (see above)
     const int n = (rg.y > capacity || rg.y - rg.x > longest_sorted) ? 0 : (int)(rg.y - rg.x);
     const bool inside = px < W && py < H;
 
-    // Pixel state that is only ever tested wave-wide lives in wave-uniform 64-bit lane masks (SGPR pairs): `donem` =
-    // pixels that are finished.  Compares feed the masks directly (v_cmp writes an SGPR pair), the logic between them is
-    // scalar, and __builtin_amdgcn_inverse_ballot_w64 turns a mask back into a lane predicate for v_cndmask -- the
-    // compiler's own lowering of a loop-carried `bool done` + ballot re-materialises it in a VGPR every iteration.
     const unsigned long long full = __builtin_amdgcn_ballot_w64(true);
     unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Uf = 0.f;
     uint32_t last = 0;
-    uint16_t* mylist = sList[wave];
+    const uint32_t* ids = point_list + rg.x;
 
-    for (int base = 0; base < n; base += GSR_BATCH) {
-        if (__syncthreads_and(donem == full)) break;  // also fences the previous batch's LDS reads
-        const int cnt = min(GSR_BATCH, n - base);
-        if (t < cnt) {
-            const float4* r = reinterpret_cast<const float4*>(rec + point_list[rg.x + base + t]);
-            const float4 a = r[0], b = r[1], c = r[2];
-            sA[t] = a; sB[t] = b; sC[t] = c;
-            sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+    if (lane < n) {
+        const float4* r = reinterpret_cast<const float4*>(rec + ids[lane]);
+        a = r[0]; b = r[1]; c = r[2];
+    }
+    for (int base = 0; base < n; base += GSR_FWB) {
+        if (donem == full) break;  // wave-uniform
+        // Issue priority grows with the depth reached: the launch lasts as long as its deepest quadrants, which share
+        // their SIMD fairly with up to seven shallower ones for most of their life; letting the waves that are still
+        // going at depth 128 / 256 / 384 issue first shortens exactly those.
+        if (base == 128) __builtin_amdgcn_s_setprio(1);
+        else if (base == 256) __builtin_amdgcn_s_setprio(2);
+        else if (base == 384) __builtin_amdgcn_s_setprio(3);
+        const int cnt = min(GSR_FWB, n - base);
+        bool hit = false;
+        if (lane < cnt) {
+            const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;
+            hit = !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), bx0, bx1, by0, by1) >
+                    gsr_cull_tau_fast(b.y) * GSR_LOG2E);
         }
-        __syncthreads();
-        const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [](int) { return true; });
-        __builtin_amdgcn_wave_barrier();
-
-        for (int c0 = 0; c0 < nw; c0 += 64) {
-            if (donem == full) break;  // wave-uniform
-            const int m = min(64, nw - c0);
-            // software pipeline, unrolled by two so that the operand registers of instance k+1 become "current" by
-            // renaming instead of by copies: body(cur, next) / body(next, cur)
-            const int jj = mylist[min(c0 + lane, nw - 1)];
-            int j0 = __builtin_amdgcn_readlane(jj, 0), j1;
-            float4 A0 = sA[j0], B0 = sB[j0], A1, B1;
-            auto body = [&](const int k, const int j, const float4& A, const float4& B, int& jn, float4& An, float4& Bn) {
-                jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
-                An = sA[jn]; Bn = sB[jn];
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the Gaussian falloff
-                const float alpha = fminf(0.99f, B.y * GSR_EXP2(power));
-                const unsigned long long okm = __builtin_amdgcn_ballot_w64(power <= 0.0f) &
-                                               __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f)) & ~donem;
-                if (okm != 0ull) {  // wave-uniform
-                    const float test_T = Tr * (1.0f - alpha);
-                    const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
-                    donem |= stopm;
-                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm & ~stopm);
-                    const float w = ok ? alpha * Tr : 0.0f;
-                    const float4 C = sC[j];
-                    C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
-                    Dp += B.z * w; Uf += B.w * w;
-                    Tr = ok ? test_T : Tr;
-                    last = ok ? (uint32_t)(base + j + 1) : last;
-                }
-            };
-            for (int k = 0; k < m; k += 2) {
-                if (donem == full) break;  // wave-uniform
-                body(k, j0, A0, B0, j1, A1, B1);
-                if (k + 1 >= m || donem == full) break;
-                body(k + 1, j1, A1, B1, j0, A0, B0);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        const int nq = __popcll(bal);
+        if (hit) {
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            float* dst = reinterpret_cast<float*>(&sPair[pos >> 1][0]) + (pos & 1);
+            dst[0] = a.x; dst[2] = a.y; dst[4] = a.z; dst[6] = a.w; dst[8] = b.x; dst[10] = b.y;
+            dst[12] = __int_as_float(lane); dst[14] = b.w;
+            sC[lane] = make_float4(c.x, c.y, c.z, b.z);
+        }
+        if ((nq & 1) && lane == 0) {  // odd count: the second half of the last pair is an instance with opacity 0
+            float* dst = reinterpret_cast<float*>(&sPair[nq >> 1][0]) + 1;
+            dst[0] = 0.f; dst[2] = 0.f; dst[4] = 0.f; dst[6] = 0.f; dst[8] = 0.f; dst[10] = 0.f; dst[12] = 0.f; dst[14] = 0.f;
+        }
+        {  // next batch's records: in flight during the blend loop
+            const int i = base + GSR_FWB + lane;
+            if (i < n) {
+                const float4* r = reinterpret_cast<const float4*>(rec + ids[i]);
+                a = r[0]; b = r[1]; c = r[2];
             }
         }
+        __syncthreads();  // single-wave workgroup: orders the LDS writes above against the reads below
+
+        const int np = (nq + 1) >> 1;
+        float4 P0 = sPair[0][0], P1 = sPair[0][1], P2 = sPair[0][2], P3 = sPair[0][3];
+        for (int k = 0; k < np; k++) {
+            if (donem == full) break;  // wave-uniform
+            const int kn = min(k + 1, np - 1);
+            const float4 N0 = sPair[kn][0], N1 = sPair[kn][1], N2 = sPair[kn][2], N3 = sPair[kn][3];
+            const gsr_f2 X = {P0.x, P0.y}, Y = {P0.z, P0.w}, HA = {P1.x, P1.y}, HB = {P1.z, P1.w};
+            const gsr_f2 HC = {P2.x, P2.y}, OP = {P2.z, P2.w};
+            const gsr_f2 dx = X - pxf, dy = Y - pyf;
+            // log2 of the falloff, evaluated as fma(dy, hC dy, dx * fma(hA, dx, hB dy)) like every blend kernel
+            const gsr_f2 inner = gsr_fma2(HA, dx, HB * dy);
+            const gsr_f2 power = gsr_fma2(dy, HC * dy, dx * inner);
+            const gsr_f2 G = {GSR_EXP2(power.x), GSR_EXP2(power.y)};
+            const gsr_f2 al = OP * G;
+            const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
+            const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
+            const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
+            auto blend = [&](const unsigned long long okm, const float al1, const int j, const float feat) {
+                const float test_T = Tr * (1.0f - al1);
+                const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
+                donem |= stopm;
+                const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm & ~stopm);
+                const float w = ok ? al1 * Tr : 0.0f;
+                const float4 C = sC[j];
+                C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
+                Dp += C.w * w; Uf += feat * w;
+                Tr = ok ? test_T : Tr;
+                last = ok ? (uint32_t)(base + j + 1) : last;
+            };
+            const unsigned long long okma = cma & ~donem;
+            if (okma != 0ull) blend(okma, alpha.x, __builtin_amdgcn_readfirstlane(__float_as_int(P3.x)), P3.z);
+            const unsigned long long okmb = cmb & ~donem;  // after a: pixels it finished no longer blend b
+            if (okmb != 0ull) blend(okmb, alpha.y, __builtin_amdgcn_readfirstlane(__float_as_int(P3.y)), P3.w);
+            P0 = N0; P1 = N1; P2 = N2; P3 = N3;
+        }
+        __syncthreads();
     }
 
-    // deepest contributor of the tile: what the backward has to traverse (drives its launch order)
+    // deepest contributor of the quadrant -> of the tile: what the backward has to traverse (drives its launch order)
     uint32_t wl = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
-    __syncthreads();  // every wave has left the batch loop: sQ is free
-    if (t == 0) sQ[0] = 0;
-    __syncthreads();
-    if (lane == 0) atomicMax(&sQ[0], wl);
-    __syncthreads();
-    if (t == 0) tile_work[tile] = sQ[0];
+    if (lane == 0 && wl) atomicMax(&tile_work[tile], wl);  // zeroed by gsr_tile_scan_kernel
 
     if (inside) {
         const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
@@ -278,6 +342,7 @@ __global__ void __launch_bounds__(256) gsr_blend_fwd_kernel(
         out_depth[pid] = Dp;
         out_feature[pid] = Uf;
     }
+    GSR_TRACE_END_AT(1, 4 * 4 * 36864)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -297,12 +362,23 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
     __shared__ uint16_t sList[4][GSR_BATCH];
     __shared__ int sMax;
 
+    GSR_TRACE_BEGIN
     const int tile = (int)tile_order[blockIdx.x];  // XCD band kept, deepest tiles of the band first
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     if (n == 0) return;
+    // Issue priority by launch rank: the launch is ordered deepest tile first and (almost) every workgroup is resident
+    // from the start, so the kernel lasts as long as its deepest tiles do while they share their SIMDs fairly with
+    // shallow ones.  Giving the deep quartiles a higher wave priority lets them finish earlier; the shallow tiles fill
+    // the issue slots they leave (LPT at the instruction-arbiter level).
+    {
+        const int rank4 = (int)((blockIdx.x >> 3) * 4u / (uint32_t)max(1, (T + 7) >> 3));
+        if (rank4 <= 0) __builtin_amdgcn_s_setprio(3);
+        else if (rank4 == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rank4 == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
     const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -475,6 +551,7 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
         }
         __syncthreads();
     }
+    GSR_TRACE_END(4)
 }
 
 // Backward launch order.  Workgroup b runs on XCD b % 8 and, with the forward's map, on the b>>3-th tile of that
@@ -544,7 +621,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
                                     float* out_feature, int capacity, int max_tile_count, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work,
                        (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count);
     return hipGetLastError();
