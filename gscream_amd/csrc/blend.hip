@@ -35,7 +35,7 @@
 //     same 4 MiB L2.  Pure speed: any placement gives the same result.
 //   * Scheduling (measured with the `make trace` build, tools/wave_trace.py): nearly all wavefronts of a launch are
 //     resident from the start, so a launch lasts as long as its most loaded SIMD; the backward is launched deepest
-//     tile first (gsr_tile_order_kernel), which hands every SIMD one tile of each depth stratum.
+//     backward is therefore cut into uniform depth-segment tasks (gsr_task_list_kernel), several per wavefront slot.
 #include <cstdlib>
 #include "gsr_math.h"
 
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    uint32_t* __restrict__ tile_work, uint32_t capacity, uint32_t longest_sorted)
+    uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, uint32_t capacity, uint32_t longest_sorted)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     // lists that were not (completely) scattered or sorted by a speculative launch are treated as empty (see above)
     const int n = (rg.y > capacity || rg.y - rg.x > longest_sorted) ? 0 : (int)(rg.y - rg.x);
     const bool inside = px < W && py < H;
+    const uint32_t HW = (uint32_t)H * (uint32_t)W, pid = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;  // <= 2^24 tiles (api.hip) = at most 2^32 pixels
 
     const unsigned long long full = __builtin_amdgcn_ballot_w64(true);
     unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
@@ -259,6 +260,14 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         if (base == 128) __builtin_amdgcn_s_setprio(1);
         else if (base == 256) __builtin_amdgcn_s_setprio(2);
         else if (base == 384) __builtin_amdgcn_s_setprio(3);
+        // Checkpoint of the blend state in front of list position k * GSR_SEG_LEN, for the pixels that are still
+        // blending: the backward starts its depth segment k - 1 from it instead of walking there from the back.
+        if (base > 0 && base % GSR_SEG_LEN == 0 && base / GSR_SEG_LEN < GSR_SEG_MAX) {
+            if (!__builtin_amdgcn_inverse_ballot_w64(donem)) {
+                float* ck = ckpt + (size_t)(base / GSR_SEG_LEN - 1) * 6 * HW + pid;
+                ck[0] = Tr; ck[HW] = C0; ck[2 * (size_t)HW] = C1; ck[3 * (size_t)HW] = C2; ck[4 * (size_t)HW] = Dp; ck[5 * (size_t)HW] = Uf;
+            }
+        }
         const int cnt = min(GSR_FWB, n - base);
         bool hit = false;
         if (lane < cnt) {
@@ -333,84 +342,131 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     if (lane == 0 && wl) atomicMax(&tile_work[tile], wl);  // zeroed by gsr_tile_scan_kernel
 
     if (inside) {
-        const size_t HW = (size_t)H * W, pid = (size_t)py * W + px;
         final_T[pid] = Tr;
         n_contrib[pid] = last;
         out_color[pid] = C0 + Tr * bg[0];
         out_color[HW + pid] = C1 + Tr * bg[1];
-        out_color[2 * HW + pid] = C2 + Tr * bg[2];
+        out_color[2 * (size_t)HW + pid] = C2 + Tr * bg[2];
         out_depth[pid] = Dp;
         out_feature[pid] = Uf;
+        float* fin = ckpt + (size_t)(GSR_SEG_MAX - 1) * 6 * HW + pid;  // final sums without the background term
+        fin[0] = C0; fin[HW] = C1; fin[2 * (size_t)HW] = C2; fin[3 * (size_t)HW] = Dp; fin[4 * (size_t)HW] = Uf;
     }
     GSR_TRACE_END_AT(1, 4 * 4 * 36864)
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward
+//
+// Work unit = one DEPTH SEGMENT of one tile: GSR_SEG_LEN consecutive list positions (the last segment of a tile takes
+// everything behind (GSR_SEG_MAX-1) * GSR_SEG_LEN).  The reference walks a tile's list back to front carrying
+// T and the colour accumulated behind the current instance (backward.cu:500-566); both are functions of the forward's
+// prefix sums, T_e and (C_final - C_front(e)) / T_e, which the forward stores per pixel at the segment boundaries, so
+// every segment can start on its own.  On the bench scene that turns 2268 tile-sized work units (1.8 per wavefront
+// slot: the launch lasted as long as its most loaded SIMD) into ~5900 uniform ones.
+//
+// One 128-thread workgroup (2 wavefronts) per task; wavefront w owns the 16x8 pixel STRIP w of the tile and lane l the
+// two pixels (l & 7, l >> 3) and (8 + (l & 7), l >> 3) of it.  The per-pixel arithmetic runs on float2 values, i.e.
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two fp32 operations per lane and instruction), the blend recurrences
+// are made branch-free by zeroing alpha and G of the pixels that do not blend (two selects per pixel; everything
+// downstream is then exact: T / (1 - 0) = T, 0 * C + 1 * acc = acc, weights 0), and the wave reduction -- the
+// largest fixed cost per (wave, instance) -- is paid once per 128 pixels instead of once per 64.
 // ---------------------------------------------------------------------------------------------
+template <typename Pred>
+__device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, int cnt, uint32_t qmask, int lane, Pred pred)
+{
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < GSR_SEG_LEN / 64; c++) {
+        const int i = c * 64 + lane;
+        const bool hit = i < cnt && (sQ[i] & qmask) && pred(i);
+        const unsigned long long bal = __ballot(hit);
+        if (hit) list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)i;
+        n += __popcll(bal);
+    }
+    return n;
+}
+
 template <bool AUX>
-__global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
+__global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
-    int H, int gx, int T, const float* __restrict__ bg, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_order,
+    int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
+    const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
+    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t task_cap,
     const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
 {
-    __shared__ float4 sA[GSR_BATCH], sB[GSR_BATCH], sC[GSR_BATCH];
-    __shared__ __attribute__((aligned(16))) float acc[GSR_BATCH * GSR_SLOT_FLOATS];
-    __shared__ uint32_t sSlot[GSR_BATCH], sQ[GSR_BATCH];
-    __shared__ uint16_t sList[4][GSR_BATCH];
-    __shared__ int sMax;
+    __shared__ float4 sA[GSR_SEG_LEN], sB[GSR_SEG_LEN], sC[GSR_SEG_LEN];
+    __shared__ __attribute__((aligned(16))) float acc[GSR_SEG_LEN * GSR_SLOT_FLOATS];
+    __shared__ uint32_t sSlot[GSR_SEG_LEN], sQ[GSR_SEG_LEN];
+    __shared__ uint16_t sList[2][GSR_SEG_LEN];
 
     GSR_TRACE_BEGIN
-    const int tile = (int)tile_order[blockIdx.x];  // XCD band kept, deepest tiles of the band first
+    // workgroup b runs on XCD b % 8 and takes the (b >> 3)-th task of that XCD's band of tile rows
+    const uint32_t band = blockIdx.x & 7u, ti = blockIdx.x >> 3;
+    if (ti >= task_count[band]) return;
+    const uint32_t task = tasks[band * task_cap + ti];
+    const int tile = (int)(task & 0xffffffu), seg = (int)(task >> 24);
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
-    if (n == 0) return;
-    // Issue priority by launch rank: the launch is ordered deepest tile first and (almost) every workgroup is resident
-    // from the start, so the kernel lasts as long as its deepest tiles do while they share their SIMDs fairly with
-    // shallow ones.  Giving the deep quartiles a higher wave priority lets them finish earlier; the shallow tiles fill
-    // the issue slots they leave (LPT at the instruction-arbiter level).
-    {
-        const int rank4 = (int)((blockIdx.x >> 3) * 4u / (uint32_t)max(1, (T + 7) >> 3));
-        if (rank4 <= 0) __builtin_amdgcn_s_setprio(3);
-        else if (rank4 == 1) __builtin_amdgcn_s_setprio(2);
-        else if (rank4 == 2) __builtin_amdgcn_s_setprio(1);
-    }
+    // Instances behind the tile's deepest contributor were blended by no pixel: they are not traversed and their
+    // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots exist.
+    const int nproc = min((int)(rg.y - rg.x), (int)tile_work[tile]);
+    const int seg_lo = seg * GSR_SEG_LEN;
+    const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + GSR_SEG_LEN);
+    if (seg_hi <= seg_lo) return;
 
-    const int px = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const float pxf = (float)px, pyf = (float)py;
+    const int pxa = tx * 16 + (lane & 7), pxb = pxa + 8;
+    const int py = ty * 16 + wave * 8 + (lane >> 3);
+    const gsr_f2 pxf = {(float)pxa, (float)pxb};
+    const float pyf = (float)py;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const size_t HW = (size_t)H * W;
-    const bool inside = px < W && py < H;
-    const size_t pid = inside ? (size_t)py * W + px : 0;
+    const bool ina = pxa < W && py < H, inb = pxb < W && py < H;
+    const size_t pa = ina ? (size_t)py * W + pxa : 0, pb = inb ? (size_t)py * W + pxb : 0;
 
-    const float Tf = inside ? final_T[pid] : 0.f;
-    float Tr = Tf;
-    const int lastc = inside ? (int)n_contrib[pid] : 0;
-    const float g0 = inside ? dL_dcolor[pid] : 0.f, g1 = inside ? dL_dcolor[HW + pid] : 0.f;
-    const float g2 = inside ? dL_dcolor[2 * HW + pid] : 0.f;
-    float gd = 0.f, gu = 0.f;
-    if (AUX && inside) { gd = dL_ddepth[pid]; gu = dL_dfeature[pid]; }
-    const float bgdot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, ard = 0.f, aru = 0.f;
+    const gsr_f2 Tf = {ina ? final_T[pa] : 0.f, inb ? final_T[pb] : 0.f};
+    const int lastca = ina ? (int)n_contrib[pa] : 0, lastcb = inb ? (int)n_contrib[pb] : 0;
+    const gsr_f2 g0 = {ina ? dL_dcolor[pa] : 0.f, inb ? dL_dcolor[pb] : 0.f};
+    const gsr_f2 g1 = {ina ? dL_dcolor[HW + pa] : 0.f, inb ? dL_dcolor[HW + pb] : 0.f};
+    const gsr_f2 g2 = {ina ? dL_dcolor[2 * HW + pa] : 0.f, inb ? dL_dcolor[2 * HW + pb] : 0.f};
+    gsr_f2 gd = {0.f, 0.f}, gu = {0.f, 0.f};
+    if (AUX) {
+        if (ina) { gd.x = dL_ddepth[pa]; gu.x = dL_dfeature[pa]; }
+        if (inb) { gd.y = dL_ddepth[pb]; gu.y = dL_dfeature[pb]; }
+    }
+    const gsr_f2 nTfb = -Tf * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);  // -T_final * (bg . dL/dC)
 
-    // wave-level and block-level maxima of the last contributor: nothing at a position >= them is blended
-    int wmax = lastc;
+    // State behind the segment.  A pixel whose last contributor lies inside or in front of the segment starts from its
+    // final state (T_final, nothing accumulated behind) exactly like the reference; a pixel that blends instances behind
+    // the segment end e starts from the forward's checkpoint: T_e and (final sum - sum in front of e) / T_e.
+    gsr_f2 Tr = Tf, ar0 = {0.f, 0.f}, ar1 = ar0, ar2 = ar0, ard = ar0, aru = ar0;
+    {
+        const float* ck = ckpt + (size_t)seg * 6 * HW;                    // checkpoint seg + 1 (position seg_hi)
+        const float* fin = ckpt + (size_t)(GSR_SEG_MAX - 1) * 6 * HW;
+        if (lastca > seg_hi) {  // only possible for seg < GSR_SEG_MAX - 1
+            const float Te = ck[pa], r = 1.0f / Te;
+            Tr.x = Te;
+            ar0.x = (fin[pa] - ck[HW + pa]) * r; ar1.x = (fin[HW + pa] - ck[2 * HW + pa]) * r; ar2.x = (fin[2 * HW + pa] - ck[3 * HW + pa]) * r;
+            if (AUX) { ard.x = (fin[3 * HW + pa] - ck[4 * HW + pa]) * r; aru.x = (fin[4 * HW + pa] - ck[5 * HW + pa]) * r; }
+        }
+        if (lastcb > seg_hi) {
+            const float Te = ck[pb], r = 1.0f / Te;
+            Tr.y = Te;
+            ar0.y = (fin[pb] - ck[HW + pb]) * r; ar1.y = (fin[HW + pb] - ck[2 * HW + pb]) * r; ar2.y = (fin[2 * HW + pb] - ck[3 * HW + pb]) * r;
+            if (AUX) { ard.y = (fin[3 * HW + pb] - ck[4 * HW + pb]) * r; aru.y = (fin[4 * HW + pb] - ck[5 * HW + pb]) * r; }
+        }
+    }
+
+    // wave-level maximum of the last contributor: nothing at a position >= it is blended by this strip
+    int wmax = max(lastca, lastcb);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
-    if (t == 0) sMax = 0;
-    for (int i = t; i < GSR_BATCH * GSR_SLOT_FLOATS; i += 256) acc[i] = 0.f;
-    __syncthreads();
-    if (lane == 0) atomicMax(&sMax, wmax);
-    __syncthreads();
-    const int nproc = min(n, sMax);
+    for (int i = t; i < GSR_SEG_LEN * GSR_SLOT_FLOATS; i += 128) acc[i] = 0.f;
     uint16_t* mylist = sList[wave];
-    // accumulator field this lane reports after the wave reduction (see gsr_bank_reduce), -1: none
-    int accfield = -1;
+    const uint32_t qmask = 3u << (2 * wave);  // the two 8x8 quadrants of this strip
+    int accfield = -1;  // accumulator field this lane reports after the wave reduction (see gsr_bank_reduce)
     {
         const int row = lane >> 4, bank = (lane >> 2) & 3;
         if ((lane & 3) == 0) {
@@ -418,14 +474,11 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             else accfield = row == 0 ? (bank < 3 ? bank : 5) : row == 2 ? 6 + bank : (row == 1 && bank == 0) ? 10 : -1;
         }
     }
-    // Instances at list positions >= nproc were blended by no pixel of the tile: they are not traversed and their
-    // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots
-    // exist.  On the bench scene lists hold ~1185 instances and pixels saturate after ~276, so three quarters of the
-    // slot traffic and of the batch loads disappear.
 
-    // back to front, in batches of 256 instances; local j = 0 is the backmost instance of the batch
-    for (int hi = nproc; hi > 0; hi -= GSR_BATCH) {
-        const int lo = max(0, hi - GSR_BATCH), cnt = hi - lo;
+    // back to front, in batches of GSR_SEG_LEN instances (one batch, except in a tile's last segment); local j = 0 is
+    // the backmost instance of the batch
+    for (int hi = seg_hi; hi > seg_lo; hi -= GSR_SEG_LEN) {
+        const int lo = max(seg_lo, hi - GSR_SEG_LEN), cnt = hi - lo;
         if (t < cnt) {
             const uint32_t id = point_list[rg.x + (hi - 1 - t)];
             const GsrRec* r = rec + id;
@@ -442,10 +495,9 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
             sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
         }
         __syncthreads();
-
         {
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
-            const int nw = gsr_compact(sQ, mylist, cnt, wave, lane, [=](int i) { return hi - 1 - i < wmax; });
+            const int nw = gsr_compact2(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
             __builtin_amdgcn_wave_barrier();
             for (int c0 = 0; c0 < nw; c0 += 64) {
                 const int m = min(64, nw - c0);
@@ -456,47 +508,57 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
                     const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
                     const float4 An = sA[jn], Bn = sB[jn];
                     const int p = hi - 1 - j;
-                    const float dx = A.x - pxf, dy = A.y - pyf;
-                    const float power = dx * (A.z * dx + A.w * dy) + (B.x * dy) * dy;  // log2 of the falloff
-                    const float G = GSR_EXP2(power);
-                    const float alpha = fminf(0.99f, B.y * G);
+                    const gsr_f2 dx = gsr_splat(A.x) - pxf;
+                    const float dy = A.y - pyf;
+                    // log2 of the falloff, same evaluation order as the forward: fma(dy, hC dy, dx * fma(hA, dx, hB dy))
+                    const gsr_f2 inner = gsr_fma2(gsr_splat(A.z), dx, gsr_splat(A.w * dy));
+                    const gsr_f2 power = gsr_fma2(gsr_splat(dy), gsr_splat(B.x * dy), dx * inner);
+                    const gsr_f2 G = {GSR_EXP2(power.x), GSR_EXP2(power.y)};
+                    const gsr_f2 al = B.y * G;
+                    const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
                     // lane masks straight from the compares, combined on the scalar unit (see the forward)
-                    const unsigned long long okm = __builtin_amdgcn_ballot_w64(p < lastc) & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
-                                                   __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f));
-                    if (okm != 0ull) {  // wave-uniform: some pixel of this quadrant blends the instance
-                        const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
-                        // per-lane partials: s0-2 colour, s3 depth, s4 feature, s5.. moments of g = G * dL/dalpha:
-                        // sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The per-Gaussian factors
-                        // (conic, opacity, -1/2, viewport scale) are applied once per instance at flush time.
-                        // Only the two per-lane weights are zero-initialised for the lanes that do not blend; the
-                        // 9 (11) products below then run unpredicated (a VALU instruction costs the same whatever its
-                        // EXEC mask, and nine v_mov 0 per instance are saved).
-                        float w = 0.f, g = 0.f;
+                    const unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
+                                                    __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
+                    const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
+                                                    __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
+                    if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
+                        const bool oka = __builtin_amdgcn_inverse_ballot_w64(okma), okb = __builtin_amdgcn_inverse_ballot_w64(okmb);
+                        const gsr_f2 ae = {oka ? alpha.x : 0.f, okb ? alpha.y : 0.f};
+                        const gsr_f2 Ge = {oka ? G.x : 0.f, okb ? G.y : 0.f};
                         const float4 C = sC[j];
-                        if (ok) {  // divergent: executed under the EXEC mask of the lanes that blend
-                            const float oma = 1.0f - alpha;
-                            const float rinv = GSR_RCP(oma);
-                            const float Tn = Tr * rinv;  // T / (1 - alpha)
-                            w = alpha * Tn;
-                            // ar* = colour accumulated BEHIND this instance (DGR backward.cu:546,559,566 update it
-                            // lazily from last_alpha / last_color at the top of the next contribution; updating it
-                            // here, right after its use, is the same arithmetic without the four carried registers)
-                            float dL_dalpha = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
-                            ar0 = alpha * C.x + oma * ar0; ar1 = alpha * C.y + oma * ar1; ar2 = alpha * C.z + oma * ar2;
-                            if (AUX) {
-                                dL_dalpha += (B.z - ard) * gd + (B.w - aru) * gu;
-                                ard = alpha * B.z + oma * ard; aru = alpha * B.w + oma * aru;
-                            }
-                            dL_dalpha *= Tn;
-                            dL_dalpha += (-Tf * rinv) * bgdot;
-                            g = G * dL_dalpha;
-                            Tr = Tn;
+                        const gsr_f2 oma = 1.0f - ae;
+                        const gsr_f2 rinv = {GSR_RCP(oma.x), GSR_RCP(oma.y)};
+                        const gsr_f2 Tn = Tr * rinv;  // T / (1 - alpha); unchanged where alpha was zeroed
+                        const gsr_f2 w = ae * Tn;
+                        // ar* = colour accumulated BEHIND this instance (DGR backward.cu:546,559,566 update it lazily
+                        // from last_alpha / last_color at the top of the next contribution; updating it here, right
+                        // after its use, is the same arithmetic without the carried registers)
+                        gsr_f2 dLda = (C.x - ar0) * g0 + (C.y - ar1) * g1 + (C.z - ar2) * g2;
+                        ar0 = ae * C.x + oma * ar0; ar1 = ae * C.y + oma * ar1; ar2 = ae * C.z + oma * ar2;
+                        if (AUX) {
+                            dLda += (B.z - ard) * gd + (B.w - aru) * gu;
+                            ard = ae * B.z + oma * ard; aru = ae * B.w + oma * aru;
                         }
+                        dLda = dLda * Tn + nTfb * rinv;  // ... - T_final / (1 - alpha) * (bg . dL/dC)
+                        const gsr_f2 g = Ge * dLda;
+                        Tr = Tn;
+                        // per-lane partials (both pixels summed): s0-2 colour, s3 depth, s4 feature, s5.. moments of
+                        // g = G * dL/dalpha: sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The
+                        // per-Gaussian factors (conic, opacity, -1/2, viewport scale) are applied once per instance at
+                        // flush time.
                         float s[11];
-                        const float gdx = g * dx, gdy = g * dy;
-                        s[0] = w * g0; s[1] = w * g1; s[2] = w * g2;
-                        s[3] = AUX ? w * gd : 0.f; s[4] = AUX ? w * gu : 0.f;
-                        s[5] = gdx; s[6] = gdy; s[7] = gdx * dx; s[8] = gdx * dy; s[9] = gdy * dy; s[10] = g;
+                        const gsr_f2 w0 = w * g0, w1 = w * g1, w2 = w * g2;
+                        s[0] = w0.x + w0.y; s[1] = w1.x + w1.y; s[2] = w2.x + w2.y;
+                        if (AUX) {
+                            const gsr_f2 w3 = w * gd, w4 = w * gu;
+                            s[3] = w3.x + w3.y; s[4] = w4.x + w4.y;
+                        } else {
+                            s[3] = 0.f; s[4] = 0.f;
+                        }
+                        const gsr_f2 gdx = g * dx, gdy = g * dy;
+                        const gsr_f2 mxx = gdx * dx, mxy = gdx * dy, myy = gdy * dy;
+                        s[5] = gdx.x + gdx.y; s[6] = gdy.x + gdy.y; s[7] = mxx.x + mxx.y; s[8] = mxy.x + mxy.y;
+                        s[9] = myy.x + myy.y; s[10] = g.x + g.y;
                         // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly whose pair steps need no
                         // selects: within a DPP row the two bank-level steps (row_ror:4, row_ror:8) write the two
                         // halves of the destination with complementary bank masks (gsr_bank_reduce), the cross-row
@@ -551,68 +613,40 @@ __global__ void __launch_bounds__(256) gsr_blend_bwd_kernel(
         }
         __syncthreads();
     }
-    GSR_TRACE_END(4)
+    GSR_TRACE_END(2)
 }
 
-// Backward launch order.  Workgroup b runs on XCD b % 8 and, with the forward's map, on the b>>3-th tile of that
-// XCD's band of tile rows.  Here each band is re-ordered by descending work (deepest n_contrib first), so the long
-// tiles start first and the tail of the launch is made of short ones; the band -> XCD assignment (L2 locality)
-// is unchanged.  One workgroup per band; bands hold <= 4608 tiles (T <= 36864), sorted in LDS.
-__global__ void __launch_bounds__(1024) gsr_tile_order_kernel(int T, const uint32_t* __restrict__ tile_work,
-                                                               uint32_t* __restrict__ tile_order)
+// Backward work list.  One workgroup per XCD band of tiles (the forward's tile -> XCD map, so a tile's records are
+// in the L2 that fetched them): tile t contributes min(GSR_SEG_MAX, ceil(tile_work[t] / GSR_SEG_LEN)) tasks; the list
+// holds all first segments, then all second ones, ... (full segments are equally long, the order inside a class is
+// whatever the LDS cursors hand out).
+__global__ void __launch_bounds__(1024) gsr_task_list_kernel(int T, const uint32_t* __restrict__ tile_work,
+                                                              uint32_t* __restrict__ tasks, uint32_t* __restrict__ task_count,
+                                                              uint32_t task_cap)
 {
-    __shared__ unsigned long long k[4608 + 1];
-    __shared__ uint32_t rank[1024];
+    __shared__ uint32_t cnt[GSR_SEG_MAX], cur[GSR_SEG_MAX];
     const int xcd = blockIdx.x, q = T >> 3, r = T & 7;
     const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int cnt = q + (xcd < r ? 1 : 0);
-    const int nt = blockDim.x;
-    if (cnt > 4608) {  // beyond the LDS provision (> 36 864 tiles): keep the band in natural order
-        for (int i = threadIdx.x; i < cnt; i += nt) tile_order[xcd + 8 * i] = (uint32_t)(first + i);
-        return;
-    }
-    for (int i = threadIdx.x; i < cnt; i += nt)
-        k[i] = ((unsigned long long)(0xffffffffu - tile_work[first + i]) << 32) | (uint32_t)(first + i);
-    if (threadIdx.x < 1024) rank[threadIdx.x] = 0u;
+    const int ntiles = q + (xcd < r ? 1 : 0);
+    if (threadIdx.x < GSR_SEG_MAX) cnt[threadIdx.x] = 0u;
     __syncthreads();
-    if (cnt <= 1024) {
-        // rank sort: the keys are unique, so the number of smaller keys IS the output position.  Thread (e, part)
-        // compares element e with one quarter of the keys (LDS broadcast reads); the four partial ranks meet in LDS.
-        const int part = threadIdx.x >> 8, e0 = threadIdx.x & 255;
-        const int j0 = (cnt * part) >> 2, j1 = (cnt * (part + 1)) >> 2;
-        for (int e = e0; e < cnt; e += 256) {
-            const unsigned long long mine = k[e];
-            uint32_t c = 0;
-#pragma unroll 8
-            for (int j = j0; j < j1; j++) c += k[j] < mine ? 1u : 0u;
-            atomicAdd(&rank[e], c);
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += nt) tile_order[xcd + 8 * rank[e]] = (uint32_t)k[e];  // block b = 8 i + xcd
-        return;
+    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+        const uint32_t w = tile_work[first + i];
+        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + GSR_SEG_LEN - 1) / GSR_SEG_LEN);
+        for (uint32_t s = 0; s < nt; s++) atomicAdd(&cnt[s], 1u);
     }
-    // plain bitonic network (ascending) with virtual +inf padding, as in binning.hip
-    uint32_t lm = 0;
-    while ((1u << lm) < (uint32_t)cnt) lm++;
-    const uint32_t npairs = (1u << lm) >> 1;
-    for (uint32_t ls = 1; ls <= lm; ls++) {
-        const uint32_t lh = ls - 1, half = 1u << lh;
-        for (uint32_t t = threadIdx.x; t < npairs; t += nt) {
-            const uint32_t blk = (t >> lh) << ls, l = t & (half - 1);
-            const uint32_t i = blk + l, j = blk + (2u << lh) - 1 - l;
-            if (j < (uint32_t)cnt && k[i] > k[j]) { const unsigned long long a = k[i]; k[i] = k[j]; k[j] = a; }
-        }
-        __syncthreads();
-        for (int lst = (int)lh - 1; lst >= 0; lst--) {
-            const uint32_t stride = 1u << lst;
-            for (uint32_t t = threadIdx.x; t < npairs; t += nt) {
-                const uint32_t i = ((t >> lst) << (lst + 1)) + (t & (stride - 1)), j = i + stride;
-                if (j < (uint32_t)cnt && k[i] > k[j]) { const unsigned long long a = k[i]; k[i] = k[j]; k[j] = a; }
-            }
-            __syncthreads();
-        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int s = 0; s < GSR_SEG_MAX; s++) { cur[s] = run; run += cnt[s]; }
+        task_count[xcd] = run;
     }
-    for (int i = threadIdx.x; i < cnt; i += nt) tile_order[xcd + 8 * i] = (uint32_t)k[i];  // block b = 8 i + xcd
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+        const uint32_t w = tile_work[first + i];
+        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + GSR_SEG_LEN - 1) / GSR_SEG_LEN);
+        for (uint32_t s = 0; s < nt; s++) tasks[(size_t)xcd * task_cap + atomicAdd(&cur[s], 1u)] = (uint32_t)(first + i) | (s << 24);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -622,7 +656,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
 {
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
-                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work,
+                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
                        (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count);
     return hipGetLastError();
 }
@@ -634,14 +668,17 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
-    hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(8), dim3(1024), 0, stream, T, image.tile_work, image.tile_order);
+    hipLaunchKernelGGL(gsr_task_list_kernel, dim3(8), dim3(1024), 0, stream, T, image.tile_work, image.tasks, image.task_count,
+                       image.task_cap);
+    // the grid covers the longest possible list; workgroups beyond their band's task count leave at once
+    const dim3 grid(8u * image.task_cap);
     if (dL_ddepth && dL_dfeature)
-        hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
-                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, dL_ddepth, dL_dfeature,
-                           image.tile_order, geom.offsets, slot_written, s4);
+        hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
+                           gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, dL_ddepth, dL_dfeature,
+                           image.tile_work, image.tasks, image.task_count, image.task_cap, geom.offsets, slot_written, s4);
     else
-        hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, dim3(T), dim3(256), 0, stream, image.ranges, bin.point_list,
-                           geom.rec, W, H, gx, T, bg, image.final_T, image.n_contrib, dL_dcolor, nullptr, nullptr,
-                           image.tile_order, geom.offsets, slot_written, s4);
+        hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
+                           gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, nullptr, nullptr,
+                           image.tile_work, image.tasks, image.task_count, image.task_cap, geom.offsets, slot_written, s4);
     return hipGetLastError();
 }

@@ -17,7 +17,11 @@
 //   image : ranges[T]     8 B  [start,end) of each tile in the sorted list
 //           final_T[N], n_contrib[N]
 //           table[NB*T]   4 B  per-(chunk, tile) instance counts -> scatter offsets
-//           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile), tile_order[T] 4 B (backward launch order)
+//           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile)
+//           tasks[8][cap] 4 B  backward work list per XCD band: tile | depth segment << 24; task_count[8]
+//           ckpt[(GSR_SEG_MAX-1)*6 + 5][N] 4 B  per-pixel blend state at list positions k*GSR_SEG_LEN
+//                              (T, r, g, b, depth, feature accumulated in FRONT of the position) + the final sums:
+//                              lets the backward start in the middle of a list (independent depth segments)
 //           info           16 B {R, max tile count}
 //   binning: point_list[R] 4 B Gaussian ids per tile segment (unsorted after the scatter, sorted in place by the
 //            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
@@ -37,6 +41,9 @@
 #define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
 #define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path
 #define GSR_SLOT_FLOATS 12
+#define GSR_SEG_LEN 128          // instances per backward task (depth segment of a tile list)
+#define GSR_SEG_MAX 4            // segments per tile; the last one takes everything behind (GSR_SEG_MAX-1)*GSR_SEG_LEN
+#define GSR_CKPT_PLANES ((GSR_SEG_MAX - 1) * 6 + 5)
 #define GSR_LOG2E 1.4426950408889634f
 
 struct GsrRec {
@@ -66,7 +73,11 @@ struct GsrImage {
     uint32_t* table;
     uint32_t* tile_count;
     uint32_t* tile_work;   // per tile: deepest n_contrib of its pixels = instances the backward must traverse
-    uint32_t* tile_order;  // backward launch order: per XCD band, tiles by descending tile_work
+    uint32_t* tasks;       // [8][task_cap] backward tasks of each XCD band: tile | segment << 24
+    uint32_t* task_count;  // [8]
+    float* ckpt;           // [GSR_CKPT_PLANES][N], see the header comment
+    uint32_t task_cap;     // ceil(T / 8) * GSR_SEG_MAX
+    size_t N;
     uint32_t* info;  // [0] = R, [1] = max tile count
     size_t bytes;
 };
@@ -122,7 +133,11 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.table = (uint32_t*)(b + off); off += gsr_align((T > GSR_MAX_TILES_LDS ? (size_t)1 : (size_t)gsr_num_chunks(P)) * T * 4);
     im.tile_count = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.tile_work = (uint32_t*)(b + off); off += gsr_align(T * 4);
-    im.tile_order = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.task_cap = (uint32_t)(((T + 7) / 8) * GSR_SEG_MAX);
+    im.N = N;
+    im.tasks = (uint32_t*)(b + off); off += gsr_align((size_t)8 * im.task_cap * 4);
+    im.task_count = (uint32_t*)(b + off); off += gsr_align(8 * 4);
+    im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * N * 4);
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.bytes = off;
     return im;
