@@ -3,8 +3,8 @@ decodes the opaque geom / image / binning byte tensors the forward returns."""
 import torch
 
 
-SEG_LEN, SEG_MAX = 128, 4  # GSR_SEG_LEN, GSR_SEG_MAX
-CKPT_PLANES = (SEG_MAX - 1) * 6 + 5
+SEG_MAX = 8  # GSR_SEG_MAX
+CKPT_PLANES = SEG_MAX * 6
 
 
 def _align(x):
@@ -47,7 +47,8 @@ def image_views(buf, P, W, H):
     cap = ((T + 7) // 8) * SEG_MAX
     out["tasks"] = _take(buf, off, 8 * cap * 4, torch.int32, (8, cap)); off += _align(8 * cap * 4)
     out["task_count"] = _take(buf, off, 32, torch.int32, (8,)); off += _align(32)
-    out["ckpt"] = _take(buf, off, CKPT_PLANES * N * 4, torch.float32, (CKPT_PLANES, N)); off += _align(CKPT_PLANES * N * 4)
+    Np = (N + 3) & ~3
+    out["ckpt"] = _take(buf, off, CKPT_PLANES * Np * 4, torch.float32, (SEG_MAX, 6 * Np)); off += _align(CKPT_PLANES * Np * 4)
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
     return out
 

@@ -216,11 +216,19 @@ typedef float gsr_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gsr_f2 gsr_splat(float v) { gsr_f2 r = {v, v}; return r; }
 __device__ __forceinline__ gsr_f2 gsr_fma2(gsr_f2 a, gsr_f2 b, gsr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Checkpoint planes (gsr_common.h): slot k of a pixel = float4 {T_k (last slot: checkpoints passed), r, g, b} + float2
+// {depth, feature}; slot k < GSR_SEG_MAX-1 belongs to list position (k + 1) * segment length, the last one to the end.
+__device__ __forceinline__ size_t gsr_ckpt_stride(size_t HW) { return (HW + 3) & ~(size_t)3; }  // keeps the float4 slots aligned
+__device__ __forceinline__ float4* gsr_ckpt_a(float* ckpt, int k, size_t HW) { return reinterpret_cast<float4*>(ckpt + (size_t)k * 6 * gsr_ckpt_stride(HW)); }
+__device__ __forceinline__ float2* gsr_ckpt_b(float* ckpt, int k, size_t HW) { return reinterpret_cast<float2*>(ckpt + ((size_t)k * 6 + 4) * gsr_ckpt_stride(HW)); }
+__device__ __forceinline__ const float4* gsr_ckpt_a(const float* ckpt, int k, size_t HW) { return reinterpret_cast<const float4*>(ckpt + (size_t)k * 6 * gsr_ckpt_stride(HW)); }
+__device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, size_t HW) { return reinterpret_cast<const float2*>(ckpt + ((size_t)k * 6 + 4) * gsr_ckpt_stride(HW)); }
+
 __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, uint32_t capacity, uint32_t longest_sorted)
+    uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
@@ -245,6 +253,8 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Uf = 0.f;
     uint32_t last = 0;
+    int npass = 0;  // checkpoints passed (wave-uniform)
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, A4 = 0.f;  // sums of the segments closed so far
     const uint32_t* ids = point_list + rg.x;
 
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
@@ -260,13 +270,19 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         if (base == 128) __builtin_amdgcn_s_setprio(1);
         else if (base == 256) __builtin_amdgcn_s_setprio(2);
         else if (base == 384) __builtin_amdgcn_s_setprio(3);
-        // Checkpoint of the blend state in front of list position k * GSR_SEG_LEN, for the pixels that are still
-        // blending: the backward starts its depth segment k - 1 from it instead of walking there from the back.
-        if (base > 0 && base % GSR_SEG_LEN == 0 && base / GSR_SEG_LEN < GSR_SEG_MAX) {
-            if (!__builtin_amdgcn_inverse_ballot_w64(donem)) {
-                float* ck = ckpt + (size_t)(base / GSR_SEG_LEN - 1) * 6 * HW + pid;
-                ck[0] = Tr; ck[HW] = C0; ck[2 * (size_t)HW] = C1; ck[3 * (size_t)HW] = C2; ck[4 * (size_t)HW] = Dp; ck[5 * (size_t)HW] = Uf;
+        // Checkpoint at list position k * seg_len (k = 1 .. GSR_SEG_MAX-1), from which the backward starts its depth
+        // segment k - 1: the transmittance T_k in front of the position and the sums S_k over the segment that ends
+        // there; C0.. restart from zero and the image sums are the sums of the segment sums.  (The
+        // backward needs the sum BEHIND a position to a relative accuracy that final - prefix cannot give once T is
+        // small: sums of small terms have to stay small.)
+        if (base > 0 && (base & (seg_len - 1)) == 0 && npass < GSR_SEG_MAX - 1) {
+            if (inside) {
+                gsr_ckpt_a(ckpt, npass, HW)[pid] = make_float4(Tr, C0, C1, C2);
+                gsr_ckpt_b(ckpt, npass, HW)[pid] = make_float2(Dp, Uf);
             }
+            npass++;
+            A0 += C0; A1 += C1; A2 += C2; A3 += Dp; A4 += Uf;
+            C0 = 0.f; C1 = 0.f; C2 = 0.f; Dp = 0.f; Uf = 0.f;
         }
         const int cnt = min(GSR_FWB, n - base);
         bool hit = false;
@@ -342,6 +358,10 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     if (lane == 0 && wl) atomicMax(&tile_work[tile], wl);  // zeroed by gsr_tile_scan_kernel
 
     if (inside) {
+        // sums behind the last checkpoint + how many checkpoints were passed
+        gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float4(__int_as_float(npass), C0, C1, C2);
+        gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float2(Dp, Uf);
+        C0 += A0; C1 += A1; C2 += A2; Dp += A3; Uf += A4;  // image sums = sum of the segment sums
         final_T[pid] = Tr;
         n_contrib[pid] = last;
         out_color[pid] = C0 + Tr * bg[0];
@@ -349,8 +369,6 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         out_color[2 * (size_t)HW + pid] = C2 + Tr * bg[2];
         out_depth[pid] = Dp;
         out_feature[pid] = Uf;
-        float* fin = ckpt + (size_t)(GSR_SEG_MAX - 1) * 6 * HW + pid;  // final sums without the background term
-        fin[0] = C0; fin[HW] = C1; fin[2 * (size_t)HW] = C2; fin[3 * (size_t)HW] = Dp; fin[4 * (size_t)HW] = Uf;
     }
     GSR_TRACE_END_AT(1, 4 * 4 * 36864)
 }
@@ -393,7 +411,7 @@ __global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
-    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t task_cap,
+    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t task_cap, int seg_len,
     const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
 {
     __shared__ float4 sA[GSR_SEG_LEN], sB[GSR_SEG_LEN], sC[GSR_SEG_LEN];
@@ -413,8 +431,8 @@ __global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
     // Instances behind the tile's deepest contributor were blended by no pixel: they are not traversed and their
     // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots exist.
     const int nproc = min((int)(rg.y - rg.x), (int)tile_work[tile]);
-    const int seg_lo = seg * GSR_SEG_LEN;
-    const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + GSR_SEG_LEN);
+    const int seg_lo = seg * seg_len;
+    const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + seg_len);
     if (seg_hi <= seg_lo) return;
 
     const int pxa = tx * 16 + (lane & 7), pxb = pxa + 8;
@@ -440,22 +458,32 @@ __global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
 
     // State behind the segment.  A pixel whose last contributor lies inside or in front of the segment starts from its
     // final state (T_final, nothing accumulated behind) exactly like the reference; a pixel that blends instances behind
-    // the segment end e starts from the forward's checkpoint: T_e and (final sum - sum in front of e) / T_e.
+    // the segment end e starts from the forward's checkpoints: T_e, and the sums of the segments behind e (added back
+    // to front, smallest first) divided by T_e.
     gsr_f2 Tr = Tf, ar0 = {0.f, 0.f}, ar1 = ar0, ar2 = ar0, ard = ar0, aru = ar0;
     {
-        const float* ck = ckpt + (size_t)seg * 6 * HW;                    // checkpoint seg + 1 (position seg_hi)
-        const float* fin = ckpt + (size_t)(GSR_SEG_MAX - 1) * 6 * HW;
+        auto behind = [&](const size_t p, float& T_, float& a0, float& a1, float& a2, float& ad, float& au) {
+            const float4 fa = gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[p];
+            const int np = __float_as_int(fa.x);  // checkpoints this pixel passed (>= seg + 1 here)
+            float t0 = fa.y, t1 = fa.z, t2 = fa.w, td = 0.f, tu = 0.f;
+            if (AUX) { const float2 fb = gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[p]; td = fb.x; tu = fb.y; }
+            for (int k = np - 1; k >= seg + 1; k--) {  // the segments behind this one, back to front
+                const float4 sa = gsr_ckpt_a(ckpt, k, HW)[p];
+                t0 += sa.y; t1 += sa.z; t2 += sa.w;
+                if (AUX) { const float2 sb = gsr_ckpt_b(ckpt, k, HW)[p]; td += sb.x; tu += sb.y; }
+            }
+            const float Te = gsr_ckpt_a(ckpt, seg, HW)[p].x, r = 1.0f / Te;
+            T_ = Te; a0 = t0 * r; a1 = t1 * r; a2 = t2 * r; ad = td * r; au = tu * r;
+        };
         if (lastca > seg_hi) {  // only possible for seg < GSR_SEG_MAX - 1
-            const float Te = ck[pa], r = 1.0f / Te;
-            Tr.x = Te;
-            ar0.x = (fin[pa] - ck[HW + pa]) * r; ar1.x = (fin[HW + pa] - ck[2 * HW + pa]) * r; ar2.x = (fin[2 * HW + pa] - ck[3 * HW + pa]) * r;
-            if (AUX) { ard.x = (fin[3 * HW + pa] - ck[4 * HW + pa]) * r; aru.x = (fin[4 * HW + pa] - ck[5 * HW + pa]) * r; }
+            float T_, a0, a1, a2, ad, au;
+            behind(pa, T_, a0, a1, a2, ad, au);
+            Tr.x = T_; ar0.x = a0; ar1.x = a1; ar2.x = a2; ard.x = ad; aru.x = au;
         }
         if (lastcb > seg_hi) {
-            const float Te = ck[pb], r = 1.0f / Te;
-            Tr.y = Te;
-            ar0.y = (fin[pb] - ck[HW + pb]) * r; ar1.y = (fin[HW + pb] - ck[2 * HW + pb]) * r; ar2.y = (fin[2 * HW + pb] - ck[3 * HW + pb]) * r;
-            if (AUX) { ard.y = (fin[3 * HW + pb] - ck[4 * HW + pb]) * r; aru.y = (fin[4 * HW + pb] - ck[5 * HW + pb]) * r; }
+            float T_, a0, a1, a2, ad, au;
+            behind(pb, T_, a0, a1, a2, ad, au);
+            Tr.y = T_; ar0.y = a0; ar1.y = a1; ar2.y = a2; ard.y = ad; aru.y = au;
         }
     }
 
@@ -477,8 +505,8 @@ __global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
 
     // back to front, in batches of GSR_SEG_LEN instances (one batch, except in a tile's last segment); local j = 0 is
     // the backmost instance of the batch
-    for (int hi = seg_hi; hi > seg_lo; hi -= GSR_SEG_LEN) {
-        const int lo = max(seg_lo, hi - GSR_SEG_LEN), cnt = hi - lo;
+    for (int hi = seg_hi; hi > seg_lo; hi -= seg_len) {
+        const int lo = max(seg_lo, hi - seg_len), cnt = hi - lo;
         if (t < cnt) {
             const uint32_t id = point_list[rg.x + (hi - 1 - t)];
             const GsrRec* r = rec + id;
@@ -622,7 +650,7 @@ __global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
 // whatever the LDS cursors hand out).
 __global__ void __launch_bounds__(1024) gsr_task_list_kernel(int T, const uint32_t* __restrict__ tile_work,
                                                               uint32_t* __restrict__ tasks, uint32_t* __restrict__ task_count,
-                                                              uint32_t task_cap)
+                                                              uint32_t task_cap, int seg_len)
 {
     __shared__ uint32_t cnt[GSR_SEG_MAX], cur[GSR_SEG_MAX];
     const int xcd = blockIdx.x, q = T >> 3, r = T & 7;
@@ -632,7 +660,7 @@ __global__ void __launch_bounds__(1024) gsr_task_list_kernel(int T, const uint32
     __syncthreads();
     for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
         const uint32_t w = tile_work[first + i];
-        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + GSR_SEG_LEN - 1) / GSR_SEG_LEN);
+        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + (uint32_t)seg_len - 1) / (uint32_t)seg_len);
         for (uint32_t s = 0; s < nt; s++) atomicAdd(&cnt[s], 1u);
     }
     __syncthreads();
@@ -644,7 +672,7 @@ __global__ void __launch_bounds__(1024) gsr_task_list_kernel(int T, const uint32
     __syncthreads();
     for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
         const uint32_t w = tile_work[first + i];
-        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + GSR_SEG_LEN - 1) / GSR_SEG_LEN);
+        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + (uint32_t)seg_len - 1) / (uint32_t)seg_len);
         for (uint32_t s = 0; s < nt; s++) tasks[(size_t)xcd * task_cap + atomicAdd(&cur[s], 1u)] = (uint32_t)(first + i) | (s << 24);
     }
 }
@@ -657,7 +685,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
-                       (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count);
+                       gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count);
     return hipGetLastError();
 }
 
@@ -669,16 +697,16 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
     hipLaunchKernelGGL(gsr_task_list_kernel, dim3(8), dim3(1024), 0, stream, T, image.tile_work, image.tasks, image.task_count,
-                       image.task_cap);
+                       image.task_cap, gsr_seg_len(T));
     // the grid covers the longest possible list; workgroups beyond their band's task count leave at once
     const dim3 grid(8u * image.task_cap);
     if (dL_ddepth && dL_dfeature)
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                            gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, dL_ddepth, dL_dfeature,
-                           image.tile_work, image.tasks, image.task_count, image.task_cap, geom.offsets, slot_written, s4);
+                           image.tile_work, image.tasks, image.task_count, image.task_cap, gsr_seg_len(T), geom.offsets, slot_written, s4);
     else
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                            gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, nullptr, nullptr,
-                           image.tile_work, image.tasks, image.task_count, image.task_cap, geom.offsets, slot_written, s4);
+                           image.tile_work, image.tasks, image.task_count, image.task_cap, gsr_seg_len(T), geom.offsets, slot_written, s4);
     return hipGetLastError();
 }

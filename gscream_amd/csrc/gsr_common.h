@@ -19,9 +19,10 @@
 //           table[NB*T]   4 B  per-(chunk, tile) instance counts -> scatter offsets
 //           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile)
 //           tasks[8][cap] 4 B  backward work list per XCD band: tile | depth segment << 24; task_count[8]
-//           ckpt[(GSR_SEG_MAX-1)*6 + 5][N] 4 B  per-pixel blend state at list positions k*GSR_SEG_LEN
-//                              (T, r, g, b, depth, feature accumulated in FRONT of the position) + the final sums:
-//                              lets the backward start in the middle of a list (independent depth segments)
+//           ckpt[GSR_SEG_MAX] slots of {float4[N'], float2[N']} (N' = N rounded up to 4): slot k-1 = list position
+//                              k * segment length (k = 1..GSR_SEG_MAX-1): {T in front of it, r, g, b}, {depth, feature}
+//                              sums over the segment that ends there; last slot: {checkpoints passed, sums behind the
+//                              last one}.  Lets the backward start in the middle of a list (independent depth segments)
 //           info           16 B {R, max tile count}
 //   binning: point_list[R] 4 B Gaussian ids per tile segment (unsorted after the scatter, sorted in place by the
 //            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
@@ -41,9 +42,12 @@
 #define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
 #define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path
 #define GSR_SLOT_FLOATS 12
-#define GSR_SEG_LEN 128          // instances per backward task (depth segment of a tile list)
-#define GSR_SEG_MAX 4            // segments per tile; the last one takes everything behind (GSR_SEG_MAX-1)*GSR_SEG_LEN
-#define GSR_CKPT_PLANES ((GSR_SEG_MAX - 1) * 6 + 5)
+#define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
+#define GSR_SEG_MAX 8            // segments per tile; the last one takes everything behind (GSR_SEG_MAX-1) * segment length
+#define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
+// Segment length of a launch: small images have few tiles, so their lists are cut finer to get enough tasks for the
+// 5120 wavefront slots; large ones already have them and shorter tasks would only add fixed costs (measured both ways).
+static inline int gsr_seg_len(int T) { return T <= 4096 ? 64 : 128; }
 #define GSR_LOG2E 1.4426950408889634f
 
 struct GsrRec {
@@ -137,7 +141,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.N = N;
     im.tasks = (uint32_t*)(b + off); off += gsr_align((size_t)8 * im.task_cap * 4);
     im.task_count = (uint32_t*)(b + off); off += gsr_align(8 * 4);
-    im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * N * 4);
+    im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * ((N + 3) & ~(size_t)3) * 4);
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.bytes = off;
     return im;

@@ -149,14 +149,16 @@ def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", m
     (exp() and FMA contraction differ by ulps); that moves one pixel's worth of gradient for that Gaussian.
     Measured on the GPU box: 0-9 such elements out of 240k (tools/grad_diag.py).  One flipped pair moves ALL components
     of that Gaussian's gradient (4 for the quaternion), hence at least 4 elements are tolerated per family.  The 99.9th
-    percentile must be inside `tol` regardless."""
+    percentile must be inside `tol` regardless (families of >= 1000 x the handful)."""
     rep = {}
     for k in keys:
         if k not in ref or k not in got:
             continue
         rep[k] = grad_report(got[k], ref[k], tol)
     bad = {k: v for k, v in rep.items()
-           if v["n_bad"] > max(min_bad_allowed, max_bad_frac * v["n"]) or not v["p999"] <= tol or not v["max"] <= 0.5}
+           if v["n_bad"] > max(min_bad_allowed, max_bad_frac * v["n"]) or not v["max"] <= 0.5
+           # the 99.9th percentile says something only where 0.1 % of the elements is more than the tolerated handful
+           or (v["n"] >= 1000 * min_bad_allowed and not v["p999"] <= tol)}
     assert not bad, f"{context} gradient mismatch (rel tol {tol}): {bad}; all: {rep}"
     return {k: v["max"] for k, v in rep.items()}
 

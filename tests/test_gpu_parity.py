@@ -100,8 +100,12 @@ def test_tile_culling_only_drops_dead_instances(name):
     assert dropped > 0.2 * st["num_rendered"], "the 3-sigma rectangles of these scenes are mostly empty corners"
     set_tuning(tile_cull=False)
     full = Hh.hip_run(s, keep_state=True)
+    P, W, H = s["means3D"].shape[0], s["W"], s["H"]
+    fT = [_layout.image_views(x["img"], P, W, H)["final_T"].cpu().numpy() for x in (full, got)]
+    assert np.array_equal(fT[0], fT[1]), "culling must not change a single bit of the transmittance"
     for k in ("out_color", "out_depth", "out_unc"):
-        assert np.array_equal(full[k], got[k]), f"{k}: culling must not change a single bit of the image"
+        # same terms, other association (segment boundaries are list positions): rounding of a float sum, nothing more
+        assert np.abs(full[k] - got[k]).max() <= 2e-6 * max(1.0, np.abs(full[k]).max()), f"{k}: culling changed the image"
     ga, gb = Hh.hip_run(s, grads), None
     set_tuning(tile_cull=True)
     gb = Hh.hip_run(s, grads)
