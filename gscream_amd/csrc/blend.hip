@@ -406,7 +406,7 @@ __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, 
 }
 
 template <bool AUX>
-__global__ void __launch_bounds__(128) gsr_blend_bwd_kernel(
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,

@@ -22,9 +22,9 @@ STAGE_OF = {
     "gsr_tile_scan_kernel": "count_scan", "gsr_scatter_kernel": "scatter", "gsr_scatter_kernel<false>": "scatter",
     "gsr_scatter_kernel<true>": "scatter", "gsr_tile_hist_kernel<false>": "count_scan", "gsr_tile_hist_kernel<true>": "count_scan",
     "gsr_cursor_init_kernel": "scatter", "gsr_tile_sort_lds_kernel": "tile_sort",
-    "gsr_tile_sort_global_kernel": "tile_sort", "gsr_blend_fwd_kernel": "blend_forward", "gsr_blend_fwd2_kernel": "blend_forward",
+    "gsr_tile_sort_global_kernel": "tile_sort", "gsr_blend_fwd_kernel": "blend_forward",
     "gsr_blend_bwd_kernel<false>": "blend_backward", "gsr_blend_bwd_kernel<true>": "blend_backward",
-    "gsr_blend_bwd2_kernel<false>": "blend_backward", "gsr_blend_bwd2_kernel<true>": "blend_backward",
+    "gsr_task_list_kernel": "blend_backward",
     "gsr_gauss_bwd_kernel": "gauss_backward",
 }
 
