@@ -10,36 +10,35 @@
 //     per loop iteration with packed fp32 instructions.  No workgroup barriers, no waiting for sibling quadrants.
 //     The reference tests every instance of the tile against all 256 pixels (forward.cu:513-553) and re-reads colour
 //     and depth from GLOBAL memory per contribution (forward.cu:545-546).
-//   * Backward: one 256-thread workgroup (4 wavefronts) per tile, because the four quadrants add into the same
-//     per-(instance, tile) gradient slot.  Lists are consumed in batches of 256 instances: thread i gathers the record of
-//     instance i into LDS as float4 SoA arrays and computes the 4-bit quadrant mask once per instance; each wave
-//     compacts, with ballot + mbcnt, the indices of the instances that can reach ITS quadrant into a private LDS
-//     list and walks only those.  Operands come back with same-address (broadcast) ds_read_b128, software-pipelined
-//     one instance ahead; the list index comes from a per-lane copy via v_readlane (no dependent LDS read).
+//   * Backward: one 128-thread workgroup per DEPTH SEGMENT of a tile (see gsr_blend_bwd_kernel): the forward stores,
+//     per pixel and every 64 / 128 list positions, the transmittance and the sums of the segment that ends there, so a
+//     segment can be walked back to front without the ones behind it.  Wavefront w owns the 16x8 strip w of the tile,
+//     lane l two pixels of it; the per-pixel arithmetic runs on float2 (v_pk_*).  Thread i gathers the record of
+//     instance i into LDS and computes the 4-bit quadrant mask once per instance; each wave compacts, with ballot +
+//     mbcnt, the indices of the instances that can reach ITS strip into a private LDS list and walks only those.
+//     Operands come back with same-address (broadcast) ds_read_b128, software-pipelined one instance ahead; the list
+//     index comes from a per-lane copy via v_readlane (no dependent LDS read).
 //   * Early-out: a forward wave stops when all its pixels are saturated; a backward wave skips gradient math +
 //     reduction when none of its pixels blends the instance, and instances behind the tile's deepest contributor are
 //     not even loaded.
 //   * Backward gradient scatter: the reference issues 11 global atomicAdd per (pixel, Gaussian) contribution
 //     (backward.cu:554-601).  Here each lane forms 9 (11) partials (colour, depth, feature and six moments of
 //     G dL/dalpha), the wave reduces them with a select-free transposing butterfly (gsr_bank_reduce + permlane swaps,
-//     23-26 VALU operations) and 9 (11) lanes add into an LDS accumulator [256][12] with ONE ds_add_f32 (built with
+//     23-26 VALU operations) and 9 (11) lanes add into an LDS accumulator [128][12] with ONE ds_add_f32 (built with
 //     -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch, thread i stores the
 //     12 floats of instance i with three plain 16-byte stores into that instance's private gradient slot (slot =
 //     Gaussian's scan offset + rank of the tile among the surviving tiles of its rectangle); gauss_bwd.hip sums each
-//     Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a tile's 4 wavefronts are unordered,
+//     Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a task's 2 wavefronts are unordered,
 //     so two runs agree to rounding, not bit for bit.)
 //   * AUX = false specialises the backward for "no gradient flows into the depth and feature maps" (GScream's
 //     RGB-only iterations): 9 instead of 11 reductions and no depth/feature recurrences.
-//   * XCD awareness: workgroup b runs on XCD b % 8 (observed dispatch rule); the block->tile map hands each
+//   * XCD awareness: workgroup b runs on XCD b % 8 (observed dispatch rule); the block->tile maps hand each
 //     XCD a contiguous band of tile rows so neighbouring tiles, which share most of their Gaussians, hit the
 //     same 4 MiB L2.  Pure speed: any placement gives the same result.
 //   * Scheduling (measured with the `make trace` build, tools/wave_trace.py): nearly all wavefronts of a launch are
-//     resident from the start, so a launch lasts as long as its most loaded SIMD; the backward is launched deepest
-//     backward is therefore cut into uniform depth-segment tasks (gsr_task_list_kernel), several per wavefront slot.
-#include <cstdlib>
+//     resident from the start, so a launch lasts as long as its most loaded SIMD.  Hence independent quadrant waves in
+//     the forward and uniform depth-segment tasks, several per wavefront slot, in the backward.
 #include "gsr_math.h"
-
-#define GSR_BATCH 256
 
 // Fast-math knobs of the blend inner loops.  Default: exp via v_exp_f32 (the records hold the quadratic form
 // pre-multiplied by log2 e, so the exponent goes straight into the instruction; ~1 ulp) and
@@ -52,9 +51,6 @@
 #define GSR_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define GSR_RCP(x) __builtin_amdgcn_rcpf(x)
 #endif
-// wave votes on lane masks the compiler already holds (HIP's __all/__any materialise a 0/1 VGPR first)
-#define GSR_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
-#define GSR_ALL(p) (__builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true))
 
 // -DGSR_TRACE (diagnostic build `make trace`, not shipped): every wavefront of the backward blend records its start and
 // end time (100 MHz wall clock) and the hardware slot it ran on (HW_ID, XCC_ID); tools/wave_trace.py reads them back.
@@ -86,35 +82,10 @@ __device__ __forceinline__ int gsr_tile_of_block(int b, int T)
 }
 
 template <int CTRL>
-__device__ __forceinline__ float gsr_dpp_add(float v)
-{
-    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-    return v + __int_as_float(o);
-}
-// Sum over the 16 lanes of a DPP row; every lane of the row ends up with the row total.
-__device__ __forceinline__ float gsr_row_sum16(float v)
-{
-    v = gsr_dpp_add<0xB1>(v);   // quad_perm:[1,0,3,2]
-    v = gsr_dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
-    v = gsr_dpp_add<0x141>(v);  // row_half_mirror
-    v = gsr_dpp_add<0x140>(v);  // row_mirror
-    return v;
-}
-
-template <int CTRL>
 __device__ __forceinline__ float gsr_dpp(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-// One step of the transposing butterfly: lanes with `hi` clear keep value a, lanes with it set keep value b, and
-// each adds its partner's copy of the value it keeps.  Two registers become one: 3 VALU ops instead of 2 DPP adds.
-template <int CTRL>
-__device__ __forceinline__ float gsr_pair_step(float a, float b, bool hi)
-{
-    const float keep = hi ? b : a, send = hi ? a : b;
-    return keep + gsr_dpp<CTRL>(send);
-}
-
 // Row-level part of the transposing wave reduction of the backward blend.  A pair step merges two registers (a, b)
 // into one whose even banks (4-lane groups of a DPP row) hold a + rot(a) and whose odd banks hold b + rot(b): two
 // v_add_f32_dpp with complementary bank masks, no select.  The second step (row_ror:8) does the same with the bank
@@ -179,22 +150,6 @@ __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const floa
         m |= hit ? (1u << q) : 0u;
     }
     return m;
-}
-
-// Wave-private compaction: indices i < cnt with bit `wave` set in sQ[i] and pred(i), in ascending order.
-template <typename Pred>
-__device__ __forceinline__ int gsr_compact(const uint32_t* sQ, uint16_t* list, int cnt, int wave, int lane, Pred pred)
-{
-    int n = 0;
-#pragma unroll
-    for (int c = 0; c < GSR_BATCH / 64; c++) {
-        const int i = c * 64 + lane;
-        const bool hit = i < cnt && ((sQ[i] >> wave) & 1u) && pred(i);
-        const unsigned long long bal = __ballot(hit);
-        if (hit) list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)i;
-        n += __popcll(bal);
-    }
-    return n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -390,6 +345,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 // downstream is then exact: T / (1 - 0) = T, 0 * C + 1 * acc = acc, weights 0), and the wave reduction -- the
 // largest fixed cost per (wave, instance) -- is paid once per 128 pixels instead of once per 64.
 // ---------------------------------------------------------------------------------------------
+// Wave-private compaction: indices i < cnt whose quadrant mask sQ[i] meets `qmask` and pred(i), in ascending order.
 template <typename Pred>
 __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, int cnt, uint32_t qmask, int lane, Pred pred)
 {
