@@ -80,7 +80,8 @@ int gsr_device_count(void);
 
 /* ---- workspace sizes (replace the obtain()/required<T>() carving of rasterizer_impl.h:21-74) ---- */
 size_t gsr_geom_bytes(int P);                 /* per-Gaussian state kept from forward to backward   */
-size_t gsr_image_bytes(int P, int W, int H);  /* per-pixel / per-tile state kept forward -> backward */
+size_t gsr_image_bytes(int P, int W, int H);  /* per-pixel / per-tile state kept forward -> backward (16 B + 192 B of
+                                                 depth checkpoints per pixel, of which only the reached ones are touched) */
 size_t gsr_binning_bytes(int R);              /* per-instance state: sorted point list (+ sort keys)  */
 size_t gsr_backward_scratch_bytes(int P, int num_slots); /* per-instance gradient slots used inside backward */
 
@@ -143,7 +144,7 @@ int gsr_forward(int P, int D, int M, int W, int H,
  *   dL_dmeans3D[P,3]  dL_dscales[P,3]  dL_drotations[P,4]
  * dL_dout_depth and dL_dout_feature may both be NULL (= no gradient flows into those maps; a cheaper
  * kernel variant runs).  No floating-point atomics on global memory are used.
- * The image workspace (tile launch order) and the binning workspace (one "slot written" byte per instance: set by
+ * The image workspace (backward task list) and the binning workspace (one "slot written" byte per instance: set by
  * the blend, cleared again by the per-Gaussian pass) are used as scratch during the call and left as the forward
  * produced them, so the backward may run again on the same forward state; two backward calls on ONE forward state
  * must not overlap on different streams.
