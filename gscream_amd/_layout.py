@@ -44,6 +44,8 @@ def image_views(buf, P, W, H):
     out["table"] = _take(buf, off, nb * T * 4, torch.int32, (nb, T)); off += _align(nb * T * 4)
     out["tile_count"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["tile_work"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
+    out["sorted_len"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
+    out["need_full"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     cap = ((T + 7) // 8) * SEG_MAX
     out["tasks"] = _take(buf, off, 8 * cap * 4, torch.int32, (8, cap)); off += _align(8 * cap * 4)
     out["task_count"] = _take(buf, off, 32, torch.int32, (8,)); off += _align(32)

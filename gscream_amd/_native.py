@@ -29,7 +29,7 @@ class Stage1Result(ctypes.Structure):
 
 class Tuning(ctypes.Structure):
     _fields_ = [("disable_tile_cull", ctypes.c_int32), ("disable_speculation", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 6)]
+                ("disable_partial_sort", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
 
 
 class Profile(ctypes.Structure):

@@ -211,7 +211,28 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     return gsr_publish_stage1(got, result_host);
 }
 
-static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, const float* background,
+// After a forward over partially sorted lists (binning.hip): tiles whose pixels were still blending at the end of their
+// sorted prefix get a full sort and are blended again.  Nothing happens on the GPU beyond a few empty launches when no
+// tile asked for it; not enqueued at all when no list was long enough to be partially sorted.
+static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_count, const float* background, void* geom_ws,
+                             void* image_ws, void* binning_ws, float* out_color, float* out_depth, float* out_feature,
+                             int debug, hipStream_t stream)
+{
+    if (max_tile_count <= GSR_NEAR_CAP) return GSR_OK;
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
+    const GsrGeom geom = gsr_carve_geom(geom_ws, P);
+    const GsrImage image = gsr_carve_image(image_ws, P, W, H);
+    const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_sort_fixup(T, capacity, max_tile_count, image, bin, stream), "tile sort (fix-up)");
+    GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
+                                                            out_feature, capacity, max_tile_count, true, stream),
+              "forward blend (fix-up)");
+    return GSR_OK;
+}
+
+static bool gsr_partial_sort(const gsr_tuning* tuning) { return !(tuning && tuning->disable_partial_sort); }
+
+static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, const float* background,
                               void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                               float* out_feature, int debug, hipStream_t stream)
 {
@@ -220,10 +241,14 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, stream), "scatter");
-    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, geom, image, bin, stream), "tile sort");
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, stream),
+                                                            out_feature, capacity, max_tile_count, false, stream),
               "forward blend");
+    // longest list known (two-stage form): the fix-up can follow at once; the one-call form enqueues it after the read-back
+    if (partial && max_tile_count >= 0)
+        return gsr_enqueue_fixup(P, W, H, capacity, max_tile_count, background, geom_ws, image_ws, binning_ws, out_color,
+                                 out_depth, out_feature, debug, stream);
     return GSR_OK;
 }
 
@@ -261,8 +286,23 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                             image_ws, radii, info, tuning, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipEventRecord(ev, stream), "record");
-    rc = gsr_enqueue_stage2(P, W, H, binning_capacity, max_tile_count_hint > 0 ? max_tile_count_hint : -1, background,
-                            geom_ws, image_ws, binning_ws, out_color, out_depth, out_feature, debug, stream);
+    const bool partial = gsr_partial_sort(tuning);
+    // (speculative: the sort variants are chosen from the hint; with partial sorting the hint only sizes the LDS of the
+    // lists up to GSR_NEAR_CAP)
+    {
+        const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
+        const GsrGeom geom = gsr_carve_geom(geom_ws, P);
+        const GsrImage image = gsr_carve_image(image_ws, P, W, H);
+        const GsrBinning bin = gsr_carve_binning(binning_ws, binning_capacity);
+        const int hint = max_tile_count_hint > 0 ? max_tile_count_hint : -1;
+        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, stream), "scatter");
+        // partial: lists beyond GSR_NEAR_CAP take the fixed-LDS prefix sort whatever the hint says
+        GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, geom, image, bin, stream),
+                  "tile sort");
+        GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
+                                                                out_feature, binning_capacity, hint, false, stream),
+                  "forward blend");
+    }
     if (rc) return rc;
     GSR_HIP(hipEventSynchronize(ev), "read num_rendered");
     uint32_t got[2] = { info[0], info[1] };
@@ -270,15 +310,19 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     if (rc) return rc;
     // the guesses hold iff every list fitted the workspace AND the sort variants that were launched cover the longest list
     const bool ok = result_host->num_rendered <= binning_capacity &&
-                    (max_tile_count_hint <= 0 || result_host->max_tile_count <= max_tile_count_hint);
-    return ok ? GSR_OK : GSR_NEED_CAPACITY;
+                    (max_tile_count_hint <= 0 || result_host->max_tile_count <= max_tile_count_hint ||
+                     (partial && max_tile_count_hint >= GSR_NEAR_CAP));  // lists beyond the cap do not depend on the hint
+    if (!ok) return GSR_NEED_CAPACITY;
+    if (partial)
+        return gsr_enqueue_fixup(P, W, H, binning_capacity, result_host->max_tile_count, background, geom_ws, image_ws,
+                                 binning_ws, out_color, out_depth, out_feature, debug, stream);
+    return GSR_OK;
 }
 
 extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const float* background,
                                   void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                                   float* out_feature, const gsr_tuning* tuning, int debug, void* stream_)
 {
-    (void)tuning;
     hipStream_t stream = (hipStream_t)stream_;
     int rc = gsr_check_dims(P, W, H);
     if (rc) return rc;
@@ -286,8 +330,8 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     if (!background || !geom_ws || !image_ws || !binning_ws || !out_color || !out_depth || !out_feature)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
-    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, background, geom_ws, image_ws, binning_ws, out_color,
-                              out_depth, out_feature, debug, stream);
+    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), background, geom_ws, image_ws, binning_ws,
+                              out_color, out_depth, out_feature, debug, stream);
 }
 
 extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity, const float* background,

@@ -124,7 +124,8 @@ __global__ void __launch_bounds__(64 * GSR_COLSCAN_GROUPS) gsr_table_colscan_ker
 // Thread i owns ceil(T/1024) consecutive tiles; one DPP wave scan + 16 wave totals in LDS.
 __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                              uint2* __restrict__ ranges, uint32_t* __restrict__ info,
-                                                             uint32_t* __restrict__ tile_work)
+                                                             uint32_t* __restrict__ tile_work, uint32_t* __restrict__ sorted_len,
+                                                             uint32_t* __restrict__ need_full)
 {
     __shared__ uint32_t wsum[16], wmax[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,6 +153,8 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
         const uint32_t v = tile_count[t0 + i];
         ranges[t0 + i] = make_uint2(run, run + v);
         tile_work[t0 + i] = 0u;  // the forward blend's quadrant wavefronts atomicMax their traversal depth into it
+        sorted_len[t0 + i] = v;  // fully sorted unless the partial sort of long lists says otherwise
+        need_full[t0 + i] = 0u;
         run += v;
     }
     if (threadIdx.x == 0) { info[0] = total; info[1] = gmax; }
@@ -386,9 +389,12 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
                                                                 const u64* __restrict__ seg_keys,
                                                                 uint32_t* __restrict__ point_list,
                                                                 uint8_t* __restrict__ slot_written, uint32_t lo,
-                                                                uint32_t hi, uint32_t fits, uint32_t capacity)
+                                                                uint32_t hi, uint32_t fits, uint32_t capacity,
+                                                                const uint32_t* __restrict__ only_flagged,
+                                                                uint32_t* __restrict__ sorted_len)
 {
     extern __shared__ __attribute__((aligned(16))) u64 keys[];
+    if (only_flagged && !only_flagged[blockIdx.x]) return;  // fix-up pass: only the tiles whose sorted prefix ran out
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     // n > fits: the LDS was provisioned from a stale hint of the longest list (speculative launch); the host sees the
@@ -401,6 +407,88 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     __syncthreads();
     gsr_sort_lds_fused(keys, n, 256);
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
+    if (sorted_len && threadIdx.x == 0) sorted_len[blockIdx.x] = n;
+}
+
+// Partial sort of a long list (n > GSR_NEAR_CAP).  The blend stops at the depth where the tile's pixels saturate --
+// typically a small fraction of a long list -- so only the nearest instances need to be in order: three coalesced
+// passes over the tile's keys find their range, histogram them into 1024 equal-width key buckets and split the list
+// at the last bucket boundary that keeps <= GSR_NEAR_CAP keys in front: those are sorted in LDS and written first
+// (sorted_len[tile] = their count), the others follow unsorted.  If the forward runs off the sorted prefix with pixels
+// still blending it says so (need_full[tile]) and the tile is redone after a full sort (gsr_launch_sort_fixup).
+// Fixed LDS (21 KiB) whatever the list length; a full bitonic sort of a 14 000-entry list needs 123 KiB and ~9x the
+// compare-exchanges.
+__global__ void __launch_bounds__(256) gsr_tile_sort_near_kernel(const uint2* __restrict__ ranges,
+                                                                 const u64* __restrict__ seg_keys,
+                                                                 uint32_t* __restrict__ point_list,
+                                                                 uint8_t* __restrict__ slot_written,
+                                                                 uint32_t* __restrict__ sorted_len, uint32_t capacity)
+{
+    __shared__ __attribute__((aligned(16))) u64 keys[GSR_PAD(GSR_NEAR_CAP) + 1];
+    __shared__ uint32_t hist[1024];
+    __shared__ u64 red[8];
+    __shared__ uint32_t s_pick, s_near, s_far;
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= GSR_NEAR_CAP || rg.y > capacity) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const u64* src = seg_keys + rg.x;
+    for (uint32_t i = t; i < n; i += 256) slot_written[rg.x + i] = 0;
+    // pass A: key range
+    u64 mn = ~0ull, mx = 0ull;
+    for (uint32_t i = t; i < n; i += 256) { const u64 k = src[i]; mn = min(mn, k); mx = max(mx, k); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = min(mn, (u64)__shfl_xor((unsigned long long)mn, d, 64));
+        mx = max(mx, (u64)__shfl_xor((unsigned long long)mx, d, 64));
+    }
+    if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+    for (int i = t; i < 1024; i += 256) hist[i] = 0u;
+    if (t == 0) { s_pick = 0u; s_near = 0u; s_far = 0u; }
+    __syncthreads();
+    const u64 kmin = min(min(red[0], red[1]), min(red[2], red[3])), kmax = max(max(red[4], red[5]), max(red[6], red[7]));
+    const u64 span = kmax - kmin;
+    const int shift = span < 1024ull ? 0 : (64 - __builtin_clzll(span)) - 10;  // (k - kmin) >> shift < 1024
+    // pass B: histogram of the key buckets
+    for (uint32_t i = t; i < n; i += 256) atomicAdd(&hist[(uint32_t)((src[i] - kmin) >> shift)], 1u);
+    __syncthreads();
+    // the last bucket boundary with <= GSR_NEAR_CAP keys in front of it: thread t owns buckets 4t .. 4t+3
+    {
+        const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+        const uint32_t mine = h0 + h1 + h2 + h3;
+        const uint32_t incl = gsr_wave_scan_add(mine);
+        __shared__ uint32_t wtot[4];
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (int w = 0; w < wave; w++) run += wtot[w];
+        const uint32_t hh[4] = { h0, h1, h2, h3 };
+        uint32_t best = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            run += hh[j];
+            if (run <= GSR_NEAR_CAP) best = ((uint32_t)(4 * t + j + 1) << 12) | run;  // (bucket + 1, keys up to it)
+        }
+        if (best) atomicMax(&s_pick, best);
+    }
+    __syncthreads();
+    const uint32_t nb = s_pick >> 12, m = s_pick & 0xfffu;  // buckets < nb form the near set of m keys (0: none fits)
+    // pass C: near keys into LDS, the others behind the sorted prefix (any order); one LDS atomic per wave and side
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + t;
+        const u64 k = i < n ? src[i] : 0ull;
+        const bool near = i < n && (uint32_t)((k - kmin) >> shift) < nb, far = i < n && !near;
+        const unsigned long long bn = __ballot(near), bf = __ballot(far);
+        uint32_t basen = 0u, basef = 0u;
+        if (lane == 0) { basen = atomicAdd(&s_near, (uint32_t)__popcll(bn)); basef = atomicAdd(&s_far, (uint32_t)__popcll(bf)); }
+        basen = (uint32_t)__shfl((int)basen, 0, 64); basef = (uint32_t)__shfl((int)basef, 0, 64);
+        if (near) keys[GSR_PAD(basen + __builtin_amdgcn_mbcnt_hi((uint32_t)(bn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bn, 0u)))] = k;
+        if (far) point_list[rg.x + m + basef + __builtin_amdgcn_mbcnt_hi((uint32_t)(bf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bf, 0u))] = (uint32_t)k;
+    }
+    __syncthreads();
+    if (m > 1) gsr_sort_lds_fused(keys, m, 256);  // m is block-uniform
+    for (uint32_t i = t; i < m; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
+    if (t == 0) sorted_len[blockIdx.x] = m;
 }
 
 // Global-memory variant for lists longer than the LDS capacity (degenerate inputs: e.g. a tiny
@@ -409,8 +497,10 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
                                                                     u64* __restrict__ seg_keys,
                                                                     uint32_t* __restrict__ point_list,
                                                                     uint8_t* __restrict__ slot_written, uint32_t lo,
-                                                                    uint32_t capacity)
+                                                                    uint32_t capacity, const uint32_t* __restrict__ only_flagged,
+                                                                    uint32_t* __restrict__ sorted_len)
 {
+    if (only_flagged && !only_flagged[blockIdx.x]) return;
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || rg.y > capacity) return;
@@ -419,6 +509,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
     __syncthreads();
     gsr_bitonic(k, n, 1024);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[rg.x + i] = (uint32_t)k[i];
+    if (sorted_len && threadIdx.x == 0) sorted_len[blockIdx.x] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,7 +554,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
     }
     // (3) tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
-                       image.info, image.tile_work);
+                       image.info, image.tile_work, image.sorted_len, image.need_full);
     return hipGetLastError();
 }
 
@@ -486,34 +577,63 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrGeom& geom, const GsrImage& image,
-                                const GsrBinning& bin, hipStream_t stream)
+// Full sort of the lists in (lo0, ...] by size class: (.., SMALL] and (SMALL, LARGE] in LDS, longer in global memory.
+// The network is a chain of ~30 LDS round trips + barriers per workgroup and runs at the speed occupancy allows, and
+// virtual padding is never stored: the dynamic LDS is sized for the longest list that exists (8.5 B per key), not for
+// the class limit -- 11 KiB instead of 34 KiB on the bench scene, twice the resident workgroups.
+static hipError_t gsr_launch_full_sorts(int T, int capacity, uint32_t lo0, uint32_t max_tile_count, const GsrImage& image,
+                                        const GsrBinning& bin, const uint32_t* only_flagged, uint32_t* sorted_len,
+                                        hipStream_t stream)
 {
-    // max_tile_count < 0: not known yet (speculative launch) -> run every size class, blocks exit on mismatch
-    if (capacity <= 0) return hipSuccess;
-    if (max_tile_count < 0) max_tile_count = 0x7fffffff;
-    hipError_t e;
-    // size classes by list length: (0, SMALL] and (SMALL, LARGE] in LDS, longer in global memory.  The network is a
-    // chain of ~30 LDS round trips + barriers per workgroup and runs at the speed occupancy allows, and virtual
-    // padding is never stored: the dynamic LDS is sized for the longest list that exists (8.5 B per key), not for
-    // the class limit -- 11 KiB instead of 34 KiB on the bench scene, twice the resident workgroups.
     const uint32_t caps[] = { (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)GSR_SORT_CAP_LARGE };
-    uint32_t lo = 0;
+    uint32_t lo = lo0;
     for (uint32_t cap : caps) {
-        if ((uint32_t)max_tile_count > lo) {
+        if (cap > lo && max_tile_count > lo) {
             if (cap > GSR_SORT_CAP_SMALL) {
-                e = gsr_allow_big_lds();
+                const hipError_t e = gsr_allow_big_lds();
                 if (e != hipSuccess) return e;
             }
-            const uint32_t longest = min(cap, (uint32_t)max_tile_count);
+            const uint32_t longest = min(cap, max_tile_count);
             const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
             hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys,
-                               bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity);
+                               bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity, only_flagged, sorted_len);
         }
-        lo = cap;
+        lo = max(lo, cap);
     }
     if (max_tile_count > GSR_SORT_CAP_LARGE)
         hipLaunchKernelGGL(gsr_tile_sort_global_kernel, dim3(T), dim3(1024), 0, stream, image.ranges, bin.seg_keys,
-                           bin.point_list, bin.slot_written, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity);
+                           bin.point_list, bin.slot_written, (uint32_t)GSR_SORT_CAP_LARGE, (uint32_t)capacity, only_flagged,
+                           sorted_len);
     return hipGetLastError();
+}
+
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, const GsrGeom& geom,
+                                const GsrImage& image, const GsrBinning& bin, hipStream_t stream)
+{
+    (void)geom;
+    // max_tile_count < 0: not known -> run every variant, blocks exit on mismatch.  speculative: max_tile_count is the
+    // caller's guess (it sizes the LDS; the host checks it against the truth afterwards)
+    if (capacity <= 0) return hipSuccess;
+    const uint32_t mx = max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count;
+    if (!partial) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, stream);
+    // lists up to GSR_NEAR_CAP: full sort in LDS; longer ones: sorted prefix only (gsr_tile_sort_near_kernel)
+    const uint32_t longest = min((uint32_t)GSR_NEAR_CAP, mx);
+    const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
+    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys, bin.point_list,
+                       bin.slot_written, 0u, (uint32_t)GSR_NEAR_CAP, longest, (uint32_t)capacity, (const uint32_t*)nullptr,
+                       (uint32_t*)nullptr);
+    // (a guess below the cap that turns out too small fails the host's check anyway and stage 2 is redone)
+    if (mx > GSR_NEAR_CAP)
+        hipLaunchKernelGGL(gsr_tile_sort_near_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.seg_keys, bin.point_list,
+                           bin.slot_written, image.sorted_len, (uint32_t)capacity);
+    return hipGetLastError();
+}
+
+// After a forward over partially sorted lists: full sort of the tiles that ran off their sorted prefix (need_full).
+hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
+                                 hipStream_t stream)
+{
+    if (capacity <= 0 || max_tile_count <= GSR_NEAR_CAP) return hipSuccess;
+    return gsr_launch_full_sorts(T, capacity, (uint32_t)GSR_NEAR_CAP, (uint32_t)max_tile_count, image, bin, image.need_full,
+                                 image.sorted_len, stream);
 }

@@ -183,7 +183,8 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted)
+    uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted,
+    const uint32_t* __restrict__ sorted_len, uint32_t* __restrict__ need_full, const uint32_t* __restrict__ only_flagged)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
@@ -198,9 +199,14 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
     const float bx0 = (float)qx0, by0 = (float)qy0, bx1 = (float)min(qx0 + 7, W - 1), by1 = (float)min(qy0 + 7, H - 1);
+    if (only_flagged && !only_flagged[tile]) return;  // fix-up pass after a full sort: only the tiles that asked for it
     const uint2 rg = ranges[tile];
-    // lists that were not (completely) scattered or sorted by a speculative launch are treated as empty (see above)
-    const int n = (rg.y > capacity || rg.y - rg.x > longest_sorted) ? 0 : (int)(rg.y - rg.x);
+    // Lists that were not (completely) scattered by a speculative launch, or that were longer than the LDS the sort was
+    // provisioned with from a stale hint, are treated as empty: the host redoes stage 2.  Lists beyond GSR_NEAR_CAP
+    // are in depth order only up to sorted_len[tile] (binning.hip): the walk ends there, and if a pixel is still
+    // blending the tile is flagged and redone after a full sort.
+    const int nlist = (int)(rg.y - rg.x), nsort = (int)sorted_len[tile];
+    const int n = (rg.y > capacity || (nsort == nlist && (uint32_t)nlist > longest_sorted)) ? 0 : min(nlist, nsort);
     const bool inside = px < W && py < H;
     const uint32_t HW = (uint32_t)H * (uint32_t)W, pid = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;  // <= 2^24 tiles (api.hip) = at most 2^32 pixels
 
@@ -305,6 +311,8 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         }
         __syncthreads();
     }
+
+    if (nsort < nlist && rg.y <= capacity && donem != full && lane == 0) need_full[tile] = 1u;  // ran off the sorted prefix
 
     // deepest contributor of the quadrant -> of the tile: what the backward has to traverse (drives its launch order)
     uint32_t wl = last;
@@ -636,12 +644,13 @@ __global__ void __launch_bounds__(1024) gsr_task_list_kernel(int T, const uint32
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, int max_tile_count, hipStream_t stream)
+                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
-                       gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count);
+                       gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,
+                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 

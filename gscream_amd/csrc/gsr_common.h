@@ -18,6 +18,8 @@
 //           final_T[N], n_contrib[N]
 //           table[NB*T]   4 B  per-(chunk, tile) instance counts -> scatter offsets
 //           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile)
+//           sorted_len[T] 4 B  length of the depth-sorted prefix of the tile's list (partial sort of long lists),
+//           need_full[T] 4 B   1 = a pixel of the tile was still blending at the end of that prefix
 //           tasks[8][cap] 4 B  backward work list per XCD band: tile | depth segment << 24; task_count[8]
 //           ckpt[GSR_SEG_MAX] slots of {float4[N'], float2[N']} (N' = N rounded up to 4): slot k-1 = list position
 //                              k * segment length (k = 1..GSR_SEG_MAX-1): {T in front of it, r, g, b}, {depth, feature}
@@ -41,6 +43,7 @@
 #define GSR_MAX_TILES_LDS 36864  // tiles whose histogram fits one LDS allocation (144 KiB)
 #define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
 #define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path
+#define GSR_NEAR_CAP 2048        // longer lists are sorted only up to (at most) this many nearest instances first
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
 #define GSR_SEG_MAX 8            // segments per tile; the last one takes everything behind (GSR_SEG_MAX-1) * segment length
@@ -77,6 +80,8 @@ struct GsrImage {
     uint32_t* table;
     uint32_t* tile_count;
     uint32_t* tile_work;   // per tile: deepest n_contrib of its pixels = instances the backward must traverse
+    uint32_t* sorted_len;  // per tile: its list is depth-sorted up to here (= list length unless partially sorted)
+    uint32_t* need_full;   // per tile: 1 = the forward ran off the sorted prefix with pixels still blending
     uint32_t* tasks;       // [8][task_cap] backward tasks of each XCD band: tile | segment << 24
     uint32_t* task_count;  // [8]
     float* ckpt;           // [GSR_CKPT_PLANES][N], see the header comment
@@ -137,6 +142,8 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.table = (uint32_t*)(b + off); off += gsr_align((T > GSR_MAX_TILES_LDS ? (size_t)1 : (size_t)gsr_num_chunks(P)) * T * 4);
     im.tile_count = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.tile_work = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.sorted_len = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.need_full = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.task_cap = (uint32_t)(((T + 7) / 8) * GSR_SEG_MAX);
     im.N = N;
     im.tasks = (uint32_t*)(b + off); off += gsr_align((size_t)8 * im.task_cap * 4);
@@ -181,11 +188,13 @@ hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream);
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
                               int capacity, hipStream_t stream);
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, const GsrGeom& geom, const GsrImage& image,
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, const GsrGeom& geom, const GsrImage& image,
                                 const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, int max_tile_count, hipStream_t stream);
+                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, hipStream_t stream);
+hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
+                                 hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots,

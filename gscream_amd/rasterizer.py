@@ -29,13 +29,16 @@ _pinned = {}  # per-device pinned int32[4] that receives gsr_stage1_result (trul
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
-def set_tuning(tile_cull=True, speculative=True):
+def set_tuning(tile_cull=True, speculative=True, partial_sort=True):
     """Performance knobs.  Images, radii and gradients do not depend on them.
+    partial_sort=False sorts every per-tile list completely (the reference's lists); by default lists longer than 2048
+    entries are depth-sorted only as far as the blend is expected to walk, with a complete sort as fall-back.
     tile_cull=False bins every tile of every rectangle: the internal per-tile lists and num_rendered become
     bit-identical to the reference's.  speculative=False always uses the two-stage forward (host reads
     num_rendered, then sizes the binning workspace exactly), like the reference's blocking read-back."""
     _tuning.disable_tile_cull = 0 if tile_cull else 1
     _tuning.disable_speculation = 0 if speculative else 1
+    _tuning.disable_partial_sort = 0 if partial_sort else 1
     _capacity_hint.clear()
     _recent.clear()
 

@@ -61,7 +61,11 @@ typedef struct gsr_tuning {
                                   Default 0: skip tiles the Gaussian cannot change (gsr_math.h) */
     int32_t disable_speculation; /* host-side hint (the library ignores it): 1 = the binding should always use the
                                   two-stage forward instead of gsr_forward */
-    int32_t reserved[6];
+    int32_t disable_partial_sort; /* 1 = sort every per-tile list completely, like the reference.  Default 0: lists longer
+                                  than 2048 entries are put in depth order only for their nearest <= 2048 instances first
+                                  (the blend stops where the tile's pixels saturate); a tile whose pixels are still
+                                  blending at the end of that prefix is sorted completely and blended again */
+    int32_t reserved[5];
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */

@@ -172,12 +172,51 @@ def test_long_tile_lists_use_the_big_sort_paths(P, W, H, expect_class):
     st = Hh.oracle_forward(s)
     mx = int((st["ranges"][:, 1] - st["ranges"][:, 0]).max())
     assert (4096 < mx <= 16384) if expect_class == "large" else (mx > 16384), mx
-    set_tuning(tile_cull=False)
+    set_tuning(tile_cull=False, partial_sort=False)
     got = Hh.hip_run(s, keep_state=True)
     assert got["num_rendered"] == st["num_rendered"]
     _check_binning(s, got, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
     for k in ("out_color", "out_depth", "out_unc"):
         Hh.assert_images_close(got[k], st[k], k, max_outlier_frac=2e-3)
+
+
+@pytest.mark.parametrize("scale_mul,expect_fixup", [(6.0, False), (0.15, True)])
+def test_partial_sort_of_long_lists(scale_mul, expect_fixup):
+    """Lists beyond 2048 entries are depth-sorted only for their nearest <= 2048 instances (binning.hip).  With big
+    splats every pixel saturates inside that prefix; with small ones most pixels never saturate, the tiles are flagged,
+    sorted completely and blended again.  Either way images and gradients must match the oracle, the sorted prefix must
+    be the oracle's list prefix, and the rest of each list must hold the remaining ids (in any order)."""
+    s = S.scene_config1(seed=33, P=14_000, W=32, H=32, lateral=0.3)
+    s["scales"] *= np.float32(scale_mul)
+    if not expect_fixup:
+        s["opacities"] = np.maximum(s["opacities"], np.float32(0.6))
+    grads = S.upstream_grads(9, s["W"], s["H"])
+    st = Hh.oracle_forward(s)
+    ref = Hh.oracle_backward(s, st, grads)
+    counts = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert counts.max() > 4096
+    set_tuning(tile_cull=False)  # the oracle's lists; partial sort stays on
+    got = Hh.hip_run(s, grads, keep_state=True)
+    assert got["num_rendered"] == st["num_rendered"]
+    P, R = s["means3D"].shape[0], got["num_rendered"]
+    img = _layout.image_views(got["img"], P, s["W"], s["H"])
+    slen = img["sorted_len"].cpu().numpy().astype(np.int64)
+    flagged = img["need_full"].cpu().numpy().astype(bool)
+    assert flagged.any() == expect_fixup, (flagged.sum(), expect_fixup)
+    pl = _layout.binning_views(got["binning"], R, got["binning_capacity"])["point_list"].cpu().numpy().astype(np.int64)
+    partial = 0
+    for tile, (a, b) in enumerate(st["ranges"]):
+        a, b, m = int(a), int(b), int(slen[tile])
+        if b - a <= 2048 or flagged[tile]:
+            assert m == b - a and (pl[a:b] == st["point_list"][a:b]).all(), "short and redone lists are sorted completely"
+        else:
+            partial += 1
+            assert 0 < m <= 2048 and (pl[a:a + m] == st["point_list"][a:a + m]).all(), "sorted prefix = the oracle's nearest instances"
+            assert (np.sort(pl[a + m:b]) == np.sort(st["point_list"][a + m:b].astype(np.int64))).all(), "the rest: same ids, any order"
+    assert (partial > 0) or expect_fixup
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k, max_outlier_frac=2e-3)
+    Hh.assert_grads_close(got, ref, context=f"partial sort, scales x{scale_mul}", max_bad_frac=2e-3)
 
 
 def test_filters_match_oracle_and_known_answers():
