@@ -384,6 +384,84 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
     }
 }
 
+// Bucket sort of one tile list held in registers (n <= 8 * 256 keys, thread t owns keys t, t + 256, ...): the
+// 64-bit keys (depth bits, id) are spread over GSR_SORT_BUCKETS equal-width buckets of their own range; a counting
+// pass (LDS atomics) places every key in its bucket's slice of k[], and each bucket -- one or two keys on average --
+// is finished with an insertion sort by the thread that owns it.  O(n) instead of the bitonic network's
+// n log^2 n / 2 compare-exchanges of 5 VALU operations each (2048 keys: 66 stages).  Exact for any input; only its
+// speed depends on the keys being spread out: a bucket with more than GSR_BUCKET_MAX keys (depth clusters finer than
+// 1/1024 of the tile's depth range) makes the tile fall back to the network.  Returns false in that case, with the
+// keys stored at k[GSR_PAD(i)] for it; true with the sorted keys at k[i].
+#define GSR_SORT_BUCKETS 1024
+#define GSR_BUCKET_MAX 16
+__device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32_t n, u64* k, uint32_t* offs /*[1024]*/,
+                                                 u64* red /*[8]*/, uint32_t* wtot /*[6]*/)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    u64 mn = ~0ull, mx = 0ull;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if ((uint32_t)(t + 256 * j) < n) { mn = min(mn, v[j]); mx = max(mx, v[j]); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = min(mn, (u64)__shfl_xor((unsigned long long)mn, d, 64));
+        mx = max(mx, (u64)__shfl_xor((unsigned long long)mx, d, 64));
+    }
+    if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+    for (int i = t; i < GSR_SORT_BUCKETS; i += 256) offs[i] = 0u;
+    __syncthreads();
+    const u64 kmin = min(min(red[0], red[1]), min(red[2], red[3])), kmax = max(max(red[4], red[5]), max(red[6], red[7]));
+    const u64 span = kmax - kmin;
+    const int shift = span < (u64)GSR_SORT_BUCKETS ? 0 : (64 - __builtin_clzll(span)) - 10;  // (key - kmin) >> shift < 1024
+    uint32_t b[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        b[j] = (uint32_t)((v[j] - kmin) >> shift);
+        if ((uint32_t)(t + 256 * j) < n) atomicAdd(&offs[b[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts (thread t owns buckets 4t .. 4t+3) and the largest bucket
+    const uint32_t h0 = offs[4 * t], h1 = offs[4 * t + 1], h2 = offs[4 * t + 2], h3 = offs[4 * t + 3];
+    const uint32_t mine = h0 + h1 + h2 + h3;
+    const uint32_t incl = gsr_wave_scan_add(mine);
+    uint32_t big = gsr_wave_scan_max(max(max(h0, h1), max(h2, h3)));
+    if (lane == 63) { wtot[wave] = incl; wtot[4] = 0u; }
+    __syncthreads();
+    if (lane == 63) atomicMax(&wtot[4], big);
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wave; w++) run += wtot[w];
+    __syncthreads();
+    if (wtot[4] > GSR_BUCKET_MAX) {  // block-uniform: clustered keys, the network does this tile
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)(t + 256 * j) < n) k[GSR_PAD(t + 256 * j)] = v[j];
+        __syncthreads();
+        return false;
+    }
+    offs[4 * t] = run; offs[4 * t + 1] = run + h0; offs[4 * t + 2] = run + h0 + h1; offs[4 * t + 3] = run + h0 + h1 + h2;
+    __syncthreads();
+    // placement: offs[bucket] is the next free position of the bucket's slice (and its end once every key is placed)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if ((uint32_t)(t + 256 * j) < n) k[atomicAdd(&offs[b[j]], 1u)] = v[j];
+    __syncthreads();
+    // every bucket finished by its owner (insertion sort; slices hold <= GSR_BUCKET_MAX keys, mostly 0 - 2)
+    uint32_t lo = run;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t hi = offs[4 * t + q];
+        for (uint32_t i = lo + 1; i < hi; i++) {
+            const u64 x = k[i];
+            uint32_t j = i;
+            while (j > lo && k[j - 1] > x) { k[j] = k[j - 1]; j--; }
+            k[j] = x;
+        }
+        lo = hi;
+    }
+    __syncthreads();
+    return true;
+}
+
 // LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).
 __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
                                                                 const u64* __restrict__ seg_keys,
@@ -394,6 +472,9 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
                                                                 uint32_t* __restrict__ sorted_len)
 {
     extern __shared__ __attribute__((aligned(16))) u64 keys[];
+    __shared__ uint32_t offs[GSR_SORT_BUCKETS];
+    __shared__ u64 red[8];
+    __shared__ uint32_t wtot[6];
     if (only_flagged && !only_flagged[blockIdx.x]) return;  // fix-up pass: only the tiles whose sorted prefix ran out
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
@@ -403,8 +484,22 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     // the tile ranges partition [0, R): each block clears its share of the written-slot flags for the backward
     for (uint32_t i = threadIdx.x; i < n; i += 256) slot_written[rg.x + i] = 0;
     // the scatter left the tile's 64-bit keys (depth bits, Gaussian id) in its segment of seg_keys
-    for (uint32_t i = threadIdx.x; i < n; i += 256) keys[GSR_PAD(i)] = seg_keys[rg.x + i];
-    __syncthreads();
+    if (n <= 2048u) {
+        u64 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t i = threadIdx.x + 256u * j;
+            v[j] = i < n ? seg_keys[rg.x + i] : 0ull;
+        }
+        if (gsr_sort_buckets(v, n, keys, offs, red, wtot)) {
+            for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
+            if (sorted_len && threadIdx.x == 0) sorted_len[blockIdx.x] = n;
+            return;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) keys[GSR_PAD(i)] = seg_keys[rg.x + i];
+        __syncthreads();
+    }
     gsr_sort_lds_fused(keys, n, 256);
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
     if (sorted_len && threadIdx.x == 0) sorted_len[blockIdx.x] = n;
@@ -524,7 +619,7 @@ static hipError_t gsr_allow_big_lds()
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (done_for_device == dev) return hipSuccess;
-    const int big = 160 * 1024 - 4096;  // the hist / scatter kernels also hold 2 KiB of static LDS
+    const int big = 160 * 1024 - 8192;  // static LDS: hist / scatter 2 KiB, tile sort 4.2 KiB (bucket offsets)
     e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
