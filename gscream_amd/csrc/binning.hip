@@ -581,8 +581,20 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_near_kernel(const uint2* __
         if (far) point_list[rg.x + m + basef + __builtin_amdgcn_mbcnt_hi((uint32_t)(bf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bf, 0u))] = (uint32_t)k;
     }
     __syncthreads();
-    if (m > 1) gsr_sort_lds_fused(keys, m, 256);  // m is block-uniform
-    for (uint32_t i = t; i < m; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
+    // the near set, sorted: bucket sort from registers like the short lists, the network if its keys are clustered
+    {
+        u64 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (uint32_t)(t + 256 * j) < m ? keys[GSR_PAD(t + 256 * j)] : 0ull;
+        __syncthreads();
+        __shared__ uint32_t wtot2[6];
+        if (gsr_sort_buckets(v, m, keys, hist, red, wtot2)) {  // m is block-uniform
+            for (uint32_t i = t; i < m; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
+        } else {
+            if (m > 1) gsr_sort_lds_fused(keys, m, 256);
+            for (uint32_t i = t; i < m; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
+        }
+    }
     if (t == 0) sorted_len[blockIdx.x] = m;
 }
 
