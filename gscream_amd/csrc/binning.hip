@@ -390,13 +390,17 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
 // is finished with an insertion sort by the thread that owns it.  O(n) instead of the bitonic network's
 // n log^2 n / 2 compare-exchanges of 5 VALU operations each (2048 keys: 66 stages).  Exact for any input; only its
 // speed depends on the keys being spread out: a bucket with more than GSR_BUCKET_MAX keys (depth clusters finer than
-// 1/1024 of the tile's depth range) makes the tile fall back to the network.  Returns false in that case, with the
-// keys stored at k[GSR_PAD(i)] for it; true with the sorted keys at k[i].
+// 1/1024 of the tile's depth range) is sorted by the whole workgroup with the plain network on its slice; if more than
+// half of the list sits in such buckets, or in more than GSR_HEAVY_MAX of them, the tile falls back to the fused network
+// altogether.  Returns false in that case, with the keys stored at k[GSR_PAD(i)] for it; true with the sorted keys at k[i].
 #define GSR_SORT_BUCKETS 1024
 #define GSR_BUCKET_MAX 16
+#define GSR_HEAVY_MAX 16
 __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32_t n, u64* k, uint32_t* offs /*[1024]*/,
                                                  u64* red /*[8]*/, uint32_t* wtot /*[6]*/)
 {
+    __shared__ uint2 heavy[GSR_HEAVY_MAX];
+    __shared__ uint32_t heavy_n[1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     u64 mn = ~0ull, mx = 0ull;
 #pragma unroll
@@ -420,18 +424,28 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32
         if ((uint32_t)(t + 256 * j) < n) atomicAdd(&offs[b[j]], 1u);
     }
     __syncthreads();
-    // exclusive scan of the bucket counts (thread t owns buckets 4t .. 4t+3) and the largest bucket
+    // exclusive scan of the bucket counts (thread t owns buckets 4t .. 4t+3)
     const uint32_t h0 = offs[4 * t], h1 = offs[4 * t + 1], h2 = offs[4 * t + 2], h3 = offs[4 * t + 3];
     const uint32_t mine = h0 + h1 + h2 + h3;
     const uint32_t incl = gsr_wave_scan_add(mine);
-    uint32_t big = gsr_wave_scan_max(max(max(h0, h1), max(h2, h3)));
-    if (lane == 63) { wtot[wave] = incl; wtot[4] = 0u; }
+    // keys in buckets that are too long for an insertion sort (depth clusters), and how many such buckets
+    const uint32_t hh[4] = { h0, h1, h2, h3 };
+    uint32_t hk = 0u, hn = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (hh[q] > GSR_BUCKET_MAX) { hk += hh[q]; hn++; }
+    hk = gsr_wave_scan_add(hk);
+    hn = gsr_wave_scan_add(hn);
+    if (lane == 63) { wtot[wave] = incl; wtot[4] = 0u; wtot[5] = 0u; }
+    if (t == 0) heavy_n[0] = 0u;
     __syncthreads();
-    if (lane == 63) atomicMax(&wtot[4], big);
+    if (lane == 63) { atomicAdd(&wtot[4], hk); atomicAdd(&wtot[5], hn); }
     uint32_t run = incl - mine;
     for (int w = 0; w < wave; w++) run += wtot[w];
     __syncthreads();
-    if (wtot[4] > GSR_BUCKET_MAX) {  // block-uniform: clustered keys, the network does this tile
+    // A few clusters are sorted separately after the placement (network on their slices); if most of the list sits in
+    // clusters, or in many of them, the whole tile goes to the fused network (block-uniform decision).
+    if (2u * wtot[4] > n || wtot[5] > GSR_HEAVY_MAX) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
             if ((uint32_t)(t + 256 * j) < n) k[GSR_PAD(t + 256 * j)] = v[j];
@@ -445,20 +459,27 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32
     for (int j = 0; j < 8; j++)
         if ((uint32_t)(t + 256 * j) < n) k[atomicAdd(&offs[b[j]], 1u)] = v[j];
     __syncthreads();
-    // every bucket finished by its owner (insertion sort; slices hold <= GSR_BUCKET_MAX keys, mostly 0 - 2)
+    // every bucket finished by its owner (insertion sort; slices hold <= GSR_BUCKET_MAX keys, mostly 0 - 2); the
+    // slices of the few heavy buckets are listed and sorted by the whole workgroup afterwards
     uint32_t lo = run;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t hi = offs[4 * t + q];
-        for (uint32_t i = lo + 1; i < hi; i++) {
-            const u64 x = k[i];
-            uint32_t j = i;
-            while (j > lo && k[j - 1] > x) { k[j] = k[j - 1]; j--; }
-            k[j] = x;
+        if (hi - lo > GSR_BUCKET_MAX) {
+            heavy[atomicAdd(&heavy_n[0], 1u)] = make_uint2(lo, hi - lo);
+        } else {
+            for (uint32_t i = lo + 1; i < hi; i++) {
+                const u64 x = k[i];
+                uint32_t j = i;
+                while (j > lo && k[j - 1] > x) { k[j] = k[j - 1]; j--; }
+                k[j] = x;
+            }
         }
         lo = hi;
     }
     __syncthreads();
+    const uint32_t nh = heavy_n[0];
+    for (uint32_t c = 0; c < nh; c++) gsr_bitonic(k + heavy[c].x, heavy[c].y, 256);  // ends with a barrier
     return true;
 }
 

@@ -219,6 +219,31 @@ def test_partial_sort_of_long_lists(scale_mul, expect_fixup):
     Hh.assert_grads_close(got, ref, context=f"partial sort, scales x{scale_mul}", max_bad_frac=2e-3)
 
 
+@pytest.mark.parametrize("clustered_frac", [0.3, 1.0])
+def test_tile_sort_with_depth_clusters(clustered_frac):
+    """The O(n) bucket sort of the tile lists spreads the keys over 1024 equal-width buckets of the tile's depth range;
+    Gaussians sitting on a few exact depth planes put hundreds of keys into one bucket.  30 % of the cloud on two planes:
+    those buckets are sorted on their own; the whole cloud on eight planes: the tile falls back to the sorting network.
+    The lists must equal the oracle's either way (ties on a plane -> ascending id)."""
+    s = S.scene_config1(seed=35, P=4500, W=64, H=64, lateral=0.3)
+    s["scales"] *= 0.5
+    rng = np.random.default_rng(35)
+    z = s["means3D"][:, 2]
+    planes = np.array([2.5, 4.0], np.float32) if clustered_frac < 1.0 else np.linspace(2.2, 5.8, 8).astype(np.float32)
+    pick = rng.random(z.shape[0]) < clustered_frac
+    scale = np.where(pick, planes[rng.integers(0, len(planes), z.shape[0])] / z, 1.0).astype(np.float32)
+    s["means3D"] = (s["means3D"] * scale[:, None]).astype(np.float32)  # same pixel, depth snapped to a plane
+    st = Hh.oracle_forward(s)
+    counts = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert 300 < counts.max() <= 2048
+    set_tuning(tile_cull=False)
+    got = Hh.hip_run(s, keep_state=True)
+    assert got["num_rendered"] == st["num_rendered"]
+    _check_binning(s, got, st["point_list"], counts)
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k, max_outlier_frac=2e-3)
+
+
 def test_filters_match_oracle_and_known_answers():
     from oracle import oracle as O
     from gscream_amd import GaussianRasterizer
