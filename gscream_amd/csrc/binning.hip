@@ -393,35 +393,40 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
 // 1/1024 of the tile's depth range) is sorted by the whole workgroup with the plain network on its slice; if more than
 // half of the list sits in such buckets, or in more than GSR_HEAVY_MAX of them, the tile falls back to the fused network
 // altogether.  Returns false in that case, with the keys stored at k[GSR_PAD(i)] for it; true with the sorted keys at k[i].
-#define GSR_SORT_BUCKETS 1024
 #define GSR_BUCKET_MAX 16
 #define GSR_HEAVY_MAX 16
-__device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32_t n, u64* k, uint32_t* offs /*[1024]*/,
-                                                 u64* red /*[8]*/, uint32_t* wtot /*[6]*/)
+// NT threads, KPT keys per thread in registers (n <= NT * KPT), 4 * NT buckets (thread t owns buckets 4t .. 4t+3).
+template <int NT, int KPT>
+__device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[KPT], const uint32_t n, u64* k, uint32_t* offs /*[4 NT]*/,
+                                                 u64* red /*[2 NT / 64]*/, uint32_t* wtot /*[NT / 64 + 2]*/)
 {
+    constexpr int NW = NT / 64, NB = 4 * NT, LOGNB = NT == 256 ? 10 : 12;
+    static_assert(NT == 256 || NT == 1024, "bucket count = 4 NT must match LOGNB");
     __shared__ uint2 heavy[GSR_HEAVY_MAX];
     __shared__ uint32_t heavy_n[1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     u64 mn = ~0ull, mx = 0ull;
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        if ((uint32_t)(t + 256 * j) < n) { mn = min(mn, v[j]); mx = max(mx, v[j]); }
+    for (int j = 0; j < KPT; j++)
+        if ((uint32_t)(t + NT * j) < n) { mn = min(mn, v[j]); mx = max(mx, v[j]); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         mn = min(mn, (u64)__shfl_xor((unsigned long long)mn, d, 64));
         mx = max(mx, (u64)__shfl_xor((unsigned long long)mx, d, 64));
     }
-    if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
-    for (int i = t; i < GSR_SORT_BUCKETS; i += 256) offs[i] = 0u;
+    if (lane == 0) { red[wave] = mn; red[NW + wave] = mx; }
+    for (int i = t; i < NB; i += NT) offs[i] = 0u;
     __syncthreads();
-    const u64 kmin = min(min(red[0], red[1]), min(red[2], red[3])), kmax = max(max(red[4], red[5]), max(red[6], red[7]));
-    const u64 span = kmax - kmin;
-    const int shift = span < (u64)GSR_SORT_BUCKETS ? 0 : (64 - __builtin_clzll(span)) - 10;  // (key - kmin) >> shift < 1024
-    uint32_t b[8];
+    u64 kmin = red[0], kmax = red[NW];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int w = 1; w < NW; w++) { kmin = min(kmin, red[w]); kmax = max(kmax, red[NW + w]); }
+    const u64 span = kmax - kmin;
+    const int shift = span < (u64)NB ? 0 : (64 - __builtin_clzll(span)) - LOGNB;  // (key - kmin) >> shift < NB
+    uint32_t b[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
         b[j] = (uint32_t)((v[j] - kmin) >> shift);
-        if ((uint32_t)(t + 256 * j) < n) atomicAdd(&offs[b[j]], 1u);
+        if ((uint32_t)(t + NT * j) < n) atomicAdd(&offs[b[j]], 1u);
     }
     __syncthreads();
     // exclusive scan of the bucket counts (thread t owns buckets 4t .. 4t+3)
@@ -436,19 +441,19 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32
         if (hh[q] > GSR_BUCKET_MAX) { hk += hh[q]; hn++; }
     hk = gsr_wave_scan_add(hk);
     hn = gsr_wave_scan_add(hn);
-    if (lane == 63) { wtot[wave] = incl; wtot[4] = 0u; wtot[5] = 0u; }
+    if (lane == 63) { wtot[wave] = incl; wtot[NW] = 0u; wtot[NW + 1] = 0u; }
     if (t == 0) heavy_n[0] = 0u;
     __syncthreads();
-    if (lane == 63) { atomicAdd(&wtot[4], hk); atomicAdd(&wtot[5], hn); }
+    if (lane == 63) { atomicAdd(&wtot[NW], hk); atomicAdd(&wtot[NW + 1], hn); }
     uint32_t run = incl - mine;
     for (int w = 0; w < wave; w++) run += wtot[w];
     __syncthreads();
     // A few clusters are sorted separately after the placement (network on their slices); if most of the list sits in
     // clusters, or in many of them, the whole tile goes to the fused network (block-uniform decision).
-    if (2u * wtot[4] > n || wtot[5] > GSR_HEAVY_MAX) {
+    if (2u * wtot[NW] > n || wtot[NW + 1] > GSR_HEAVY_MAX) {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if ((uint32_t)(t + 256 * j) < n) k[GSR_PAD(t + 256 * j)] = v[j];
+        for (int j = 0; j < KPT; j++)
+            if ((uint32_t)(t + NT * j) < n) k[GSR_PAD(t + NT * j)] = v[j];
         __syncthreads();
         return false;
     }
@@ -456,8 +461,8 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32
     __syncthreads();
     // placement: offs[bucket] is the next free position of the bucket's slice (and its end once every key is placed)
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        if ((uint32_t)(t + 256 * j) < n) k[atomicAdd(&offs[b[j]], 1u)] = v[j];
+    for (int j = 0; j < KPT; j++)
+        if ((uint32_t)(t + NT * j) < n) k[atomicAdd(&offs[b[j]], 1u)] = v[j];
     __syncthreads();
     // every bucket finished by its owner (insertion sort; slices hold <= GSR_BUCKET_MAX keys, mostly 0 - 2); the
     // slices of the few heavy buckets are listed and sorted by the whole workgroup afterwards
@@ -479,23 +484,26 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[8], const uint32
     }
     __syncthreads();
     const uint32_t nh = heavy_n[0];
-    for (uint32_t c = 0; c < nh; c++) gsr_bitonic(k + heavy[c].x, heavy[c].y, 256);  // ends with a barrier
+    for (uint32_t c = 0; c < nh; c++) gsr_bitonic(k + heavy[c].x, heavy[c].y, NT);  // ends with a barrier
     return true;
 }
 
-// LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).
-__global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
-                                                                const u64* __restrict__ seg_keys,
-                                                                uint32_t* __restrict__ point_list,
-                                                                uint8_t* __restrict__ slot_written, uint32_t lo,
-                                                                uint32_t hi, uint32_t fits, uint32_t capacity,
-                                                                const uint32_t* __restrict__ only_flagged,
-                                                                uint32_t* __restrict__ sorted_len)
+// LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).  NT = 256 threads (8 keys each) for the lists up
+// to 2048, 1024 threads (16 keys each) for the class up to 16384.
+template <int NT>
+__global__ void __launch_bounds__(NT) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
+                                                               const u64* __restrict__ seg_keys,
+                                                               uint32_t* __restrict__ point_list,
+                                                               uint8_t* __restrict__ slot_written, uint32_t lo,
+                                                               uint32_t hi, uint32_t fits, uint32_t capacity,
+                                                               const uint32_t* __restrict__ only_flagged,
+                                                               uint32_t* __restrict__ sorted_len)
 {
+    constexpr int KPT = NT == 256 ? 8 : 16;
     extern __shared__ __attribute__((aligned(16))) u64 keys[];
-    __shared__ uint32_t offs[GSR_SORT_BUCKETS];
-    __shared__ u64 red[8];
-    __shared__ uint32_t wtot[6];
+    __shared__ uint32_t offs[4 * NT];
+    __shared__ u64 red[2 * NT / 64];
+    __shared__ uint32_t wtot[NT / 64 + 2];
     if (only_flagged && !only_flagged[blockIdx.x]) return;  // fix-up pass: only the tiles whose sorted prefix ran out
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
@@ -503,26 +511,26 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_lds_kernel(const uint2* __r
     // true maximum after the fact and redoes stage 2
     if (n <= lo || n > hi || n > fits || rg.y > capacity) return;
     // the tile ranges partition [0, R): each block clears its share of the written-slot flags for the backward
-    for (uint32_t i = threadIdx.x; i < n; i += 256) slot_written[rg.x + i] = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += NT) slot_written[rg.x + i] = 0;
     // the scatter left the tile's 64-bit keys (depth bits, Gaussian id) in its segment of seg_keys
-    if (n <= 2048u) {
-        u64 v[8];
+    if (n <= (uint32_t)(NT * KPT)) {
+        u64 v[KPT];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t i = threadIdx.x + 256u * j;
+        for (int j = 0; j < KPT; j++) {
+            const uint32_t i = threadIdx.x + (uint32_t)NT * j;
             v[j] = i < n ? seg_keys[rg.x + i] : 0ull;
         }
-        if (gsr_sort_buckets(v, n, keys, offs, red, wtot)) {
-            for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
+        if (gsr_sort_buckets<NT, KPT>(v, n, keys, offs, red, wtot)) {
+            for (uint32_t i = threadIdx.x; i < n; i += NT) point_list[rg.x + i] = (uint32_t)keys[i];
             if (sorted_len && threadIdx.x == 0) sorted_len[blockIdx.x] = n;
             return;
         }
     } else {
-        for (uint32_t i = threadIdx.x; i < n; i += 256) keys[GSR_PAD(i)] = seg_keys[rg.x + i];
+        for (uint32_t i = threadIdx.x; i < n; i += NT) keys[GSR_PAD(i)] = seg_keys[rg.x + i];
         __syncthreads();
     }
-    gsr_sort_lds_fused(keys, n, 256);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
+    gsr_sort_lds_fused(keys, n, NT);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
     if (sorted_len && threadIdx.x == 0) sorted_len[blockIdx.x] = n;
 }
 
@@ -609,7 +617,7 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_near_kernel(const uint2* __
         for (int j = 0; j < 8; j++) v[j] = (uint32_t)(t + 256 * j) < m ? keys[GSR_PAD(t + 256 * j)] : 0ull;
         __syncthreads();
         __shared__ uint32_t wtot2[6];
-        if (gsr_sort_buckets(v, m, keys, hist, red, wtot2)) {  // m is block-uniform
+        if (gsr_sort_buckets<256, 8>(v, m, keys, hist, red, wtot2)) {  // m is block-uniform
             for (uint32_t i = t; i < m; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
         } else {
             if (m > 1) gsr_sort_lds_fused(keys, m, 256);
@@ -655,7 +663,7 @@ static hipError_t gsr_allow_big_lds()
     const int big = 160 * 1024 - 8192;  // static LDS: hist / scatter 2 KiB, tile sort 4.2 KiB (bucket offsets)
     e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 17408);  // 16.9 KiB static: 4096 bucket offsets + scan scratch
     if (e == hipSuccess) done_for_device = dev;
     return e;
 }
@@ -723,8 +731,12 @@ static hipError_t gsr_launch_full_sorts(int T, int capacity, uint32_t lo0, uint3
             }
             const uint32_t longest = min(cap, max_tile_count);
             const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
-            hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys,
-                               bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity, only_flagged, sorted_len);
+            if (longest <= 2048u)
+                hipLaunchKernelGGL(gsr_tile_sort_lds_kernel<256>, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys,
+                                   bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity, only_flagged, sorted_len);
+            else
+                hipLaunchKernelGGL(gsr_tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), lds, stream, image.ranges, bin.seg_keys,
+                                   bin.point_list, bin.slot_written, lo, cap, longest, (uint32_t)capacity, only_flagged, sorted_len);
         }
         lo = max(lo, cap);
     }
@@ -747,7 +759,7 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
     // lists up to GSR_NEAR_CAP: full sort in LDS; longer ones: sorted prefix only (gsr_tile_sort_near_kernel)
     const uint32_t longest = min((uint32_t)GSR_NEAR_CAP, mx);
     const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
-    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys, bin.point_list,
+    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel<256>, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys, bin.point_list,
                        bin.slot_written, 0u, (uint32_t)GSR_NEAR_CAP, longest, (uint32_t)capacity, (const uint32_t*)nullptr,
                        (uint32_t*)nullptr);
     // (a guess below the cap that turns out too small fails the host's check anyway and stage 2 is redone)
