@@ -21,7 +21,8 @@ STAGE_OF = {
     "gsr_scan_apply_kernel": "count_scan", "gsr_tile_hist_kernel": "count_scan", "gsr_table_colscan_kernel": "count_scan",
     "gsr_tile_scan_kernel": "count_scan", "gsr_scatter_kernel": "scatter", "gsr_scatter_kernel<false>": "scatter",
     "gsr_scatter_kernel<true>": "scatter", "gsr_tile_hist_kernel<false>": "count_scan", "gsr_tile_hist_kernel<true>": "count_scan",
-    "gsr_cursor_init_kernel": "scatter", "gsr_tile_sort_lds_kernel": "tile_sort",
+    "gsr_cursor_init_kernel": "scatter", "gsr_tile_sort_lds_kernel": "tile_sort", "gsr_tile_sort_lds_kernel<256>": "tile_sort",
+    "gsr_tile_sort_lds_kernel<1024>": "tile_sort", "gsr_tile_sort_near_kernel": "tile_sort",
     "gsr_tile_sort_global_kernel": "tile_sort", "gsr_blend_fwd_kernel": "blend_forward",
     "gsr_blend_bwd_kernel<false>": "blend_backward", "gsr_blend_bwd_kernel<true>": "blend_backward",
     "gsr_task_list_kernel": "blend_backward",
@@ -42,21 +43,31 @@ def load(db):
 def main():
     d, workload = sys.argv[1], sys.argv[2]
     res = collections.defaultdict(dict)
+    tot = collections.defaultdict(dict)   # per kernel and counter: sum over its dispatches, dispatch count
     for f in sorted(os.listdir(d)):
         if f.endswith("_results.db"):
             for k, v in load(os.path.join(d, f)).items():
                 for c, vals in v.items():
                     res[k][c] = sum(vals) / len(vals)
+                    tot[k][c] = (sum(vals), len(vals))
     counters = sorted({c for v in res.values() for c in v})
     print("| kernel | " + " | ".join(counters) + " |")
     print("|---|" + "---:|" * len(counters))
     for k in sorted(res):
         print(f"| `{k}` | " + " | ".join(f"{res[k].get(c, float('nan')):.4g}" for c in counters) + " |")
+    # per-iteration traffic of a stage: sums over ALL dispatches of its kernels divided by the dispatch count of the
+    # stage's most-launched kernel, so that a kernel launched once (a first, non-speculative call) counts once
     traffic = collections.defaultdict(float)
-    for k, v in res.items():
+    launches = collections.defaultdict(lambda: {"FETCH_SIZE": 0, "WRITE_SIZE": 0})
+    for k, v in tot.items():
+        st = STAGE_OF.get(k)
+        if st:
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                launches[st][c] = max(launches[st][c], v.get(c, (0, 0))[1])
+    for k, v in tot.items():
         st = STAGE_OF.get(k)
         if st and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            traffic[st] += 2.0 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
+            traffic[st] += 2.0 * v["FETCH_SIZE"][0] / launches[st]["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"][0] / launches[st]["WRITE_SIZE"] * 1024
     print("\nHBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B):")
     for st, b in traffic.items():
         print(f"  {st:16s} {b / 1e6:9.1f} MB")
