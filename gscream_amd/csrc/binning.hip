@@ -384,13 +384,13 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
     }
 }
 
-// Bucket sort of one tile list held in registers (n <= 8 * 256 keys, thread t owns keys t, t + 256, ...): the
-// 64-bit keys (depth bits, id) are spread over GSR_SORT_BUCKETS equal-width buckets of their own range; a counting
+// Bucket sort of one tile list held in registers (n <= NT * KPT keys, thread t owns keys t, t + NT, ...): the
+// 64-bit keys (depth bits, id) are spread over 4 * NT equal-width buckets of their own range; a counting
 // pass (LDS atomics) places every key in its bucket's slice of k[], and each bucket -- one or two keys on average --
 // is finished with an insertion sort by the thread that owns it.  O(n) instead of the bitonic network's
 // n log^2 n / 2 compare-exchanges of 5 VALU operations each (2048 keys: 66 stages).  Exact for any input; only its
 // speed depends on the keys being spread out: a bucket with more than GSR_BUCKET_MAX keys (depth clusters finer than
-// 1/1024 of the tile's depth range) is sorted by the whole workgroup with the plain network on its slice; if more than
+// 1/1024 .. 1/4096 of the tile's depth range) is sorted by the whole workgroup with the plain network on its slice; if more than
 // half of the list sits in such buckets, or in more than GSR_HEAVY_MAX of them, the tile falls back to the fused network
 // altogether.  Returns false in that case, with the keys stored at k[GSR_PAD(i)] for it; true with the sorted keys at k[i].
 #define GSR_BUCKET_MAX 16
