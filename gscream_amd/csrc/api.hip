@@ -147,13 +147,33 @@ static int gsr_check_dims(int P, int W, int H)
     return GSR_OK;
 }
 
+// Pinned host words the tile-scan kernel writes {R, longest list} into; valid to read after the stream / event the
+// caller waits on.  One buffer per host thread and device.
+static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
+{
+    static thread_local uint32_t* buf = nullptr;
+    static thread_local uint32_t* buf_dev = nullptr;
+    static thread_local int buf_device = -1;
+    int d = 0;
+    GSR_HIP(hipGetDevice(&d), "hipGetDevice");
+    if (!buf || buf_device != d) {
+        void* p = nullptr;
+        GSR_HIP(hipHostMalloc(&p, 64, hipHostMallocMapped), "hipHostMalloc(info)");
+        void* pd = nullptr;
+        GSR_HIP(hipHostGetDevicePointer(&pd, p, 0), "hipHostGetDevicePointer(info)");
+        buf = (uint32_t*)p; buf_dev = (uint32_t*)pd; buf_device = d;
+    }
+    *host = buf; *dev = buf_dev;
+    return GSR_OK;
+}
+
 // Validates the stage-1 arguments and enqueues preprocess + counting + the 16-byte D2H copy of {R, max tile count}.
 static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* means3D, const float* scales,
                               float scale_modifier, const float* rotations, const float* opacities,
                               const float* features, const float* shs, const float* cov3D_precomp,
                               const float* colors_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, float tan_fovx, float tan_fovy, void* geom_ws, void* image_ws,
-                              int32_t* radii, uint32_t* info_host, const gsr_tuning* tuning, int debug, hipStream_t stream)
+                              int32_t* radii, volatile uint32_t** info_pinned, const gsr_tuning* tuning, int debug, hipStream_t stream)
 {
     if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
@@ -172,8 +192,12 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
                                     cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr,
                                     !(tuning && tuning->disable_tile_cull), stream),
               "preprocess");
-    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, stream), "tile count / scans");
-    GSR_HIP(hipMemcpyAsync(info_host, image.info, 8, hipMemcpyDeviceToHost, stream), "read num_rendered");
+    // {R, longest list} reach the host through a pinned, device-mapped word pair the scan kernel stores into (one per
+    // host thread and device, 8 bytes, kept for the life of the thread): no copy kernel between the scan and the scatter.
+    uint32_t* mapped_dev = nullptr;
+    rc = gsr_info_buffer(info_pinned, &mapped_dev);
+    if (rc) return rc;
+    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, stream), "tile count / scans");
     return GSR_OK;
 }
 
@@ -201,10 +225,10 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
     memset(result_host, 0, sizeof(*result_host));
     if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:85
-    uint32_t* info = reinterpret_cast<uint32_t*>(result_host);  // {R, max} land in the first two fields
+    volatile uint32_t* info = nullptr;  // pinned words the scan kernel writes {R, max} into
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, info, tuning, debug, stream);
+                            image_ws, radii, &info, tuning, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
     uint32_t got[2] = { info[0], info[1] };
@@ -280,10 +304,10 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
         ev_dev = dev;
     }
-    uint32_t* info = reinterpret_cast<uint32_t*>(result_host);
+    volatile uint32_t* info = nullptr;
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, info, tuning, debug, stream);
+                            image_ws, radii, &info, tuning, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipEventRecord(ev, stream), "record");
     const bool partial = gsr_partial_sort(tuning);

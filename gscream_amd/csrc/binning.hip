@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64 * GSR_COLSCAN_GROUPS) gsr_table_colscan_ker
 __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                              uint2* __restrict__ ranges, uint32_t* __restrict__ info,
                                                              uint32_t* __restrict__ tile_work, uint32_t* __restrict__ sorted_len,
-                                                             uint32_t* __restrict__ need_full)
+                                                             uint32_t* __restrict__ need_full, uint32_t* __restrict__ info_host)
 {
     __shared__ uint32_t wsum[16], wmax[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,7 +157,11 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
         need_full[t0 + i] = 0u;
         run += v;
     }
-    if (threadIdx.x == 0) { info[0] = total; info[1] = gmax; }
+    if (threadIdx.x == 0) {
+        info[0] = total; info[1] = gmax;
+        // the host's copy, written straight into its pinned (device-mapped) buffer: no copy kernel in the stream
+        if (info_host) { info_host[0] = total; info_host[1] = gmax; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -668,7 +672,8 @@ static hipError_t gsr_allow_big_lds()
     return e;
 }
 
-hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream)
+hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
+                            hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
     hipError_t e;
@@ -690,7 +695,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
     }
     // (3) tile scan -> ranges, info
     hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
-                       image.info, image.tile_work, image.sorted_len, image.need_full);
+                       image.info, image.tile_work, image.sorted_len, image.need_full, info_host_mapped);
     return hipGetLastError();
 }
 

@@ -185,7 +185,8 @@ hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& ca
                                  int tile_cull, hipStream_t stream);
 hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                    hipStream_t stream);
-hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, hipStream_t stream);
+hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
+                            hipStream_t stream);
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
                               int capacity, hipStream_t stream);
 hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, const GsrGeom& geom, const GsrImage& image,
