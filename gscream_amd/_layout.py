@@ -46,9 +46,6 @@ def image_views(buf, P, W, H):
     out["tile_work"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["sorted_len"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["need_full"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
-    cap = ((T + 7) // 8) * SEG_MAX
-    out["tasks"] = _take(buf, off, 8 * cap * 4, torch.int32, (8, cap)); off += _align(8 * cap * 4)
-    out["task_count"] = _take(buf, off, 32, torch.int32, (8,)); off += _align(32)
     Np = (N + 3) & ~3
     out["ckpt"] = _take(buf, off, CKPT_PLANES * Np * 4, torch.float32, (SEG_MAX, 6 * Np)); off += _align(CKPT_PLANES * Np * 4)
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 // T and the colour accumulated behind the current instance (backward.cu:500-566); both are functions of the forward's
 // prefix sums, T_e and (C_final - C_front(e)) / T_e, which the forward stores per pixel at the segment boundaries, so
 // every segment can start on its own.  On the bench scene that turns 2268 tile-sized work units (1.8 per wavefront
-// slot: the launch lasted as long as its most loaded SIMD) into ~5900 uniform ones.
+// slot: the launch lasted as long as its most loaded SIMD) into ~8000 uniform ones.
 //
 // One 128-thread workgroup (2 wavefronts) per task; wavefront w owns the 16x8 pixel STRIP w of the tile and lane l the
 // two pixels (l & 7, l >> 3) and (8 + (l & 7), l >> 3) of it.  The per-pixel arithmetic runs on float2 values, i.e.
@@ -375,8 +375,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
-    const uint32_t* __restrict__ tasks, const uint32_t* __restrict__ task_count, uint32_t task_cap, int seg_len,
-    const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
+    int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
 {
     __shared__ float4 sA[GSR_SEG_LEN], sB[GSR_SEG_LEN], sC[GSR_SEG_LEN];
     __shared__ __attribute__((aligned(16))) float acc[GSR_SEG_LEN * GSR_SLOT_FLOATS];
@@ -384,11 +383,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
     __shared__ uint16_t sList[2][GSR_SEG_LEN];
 
     GSR_TRACE_BEGIN
-    // workgroup b runs on XCD b % 8 and takes the (b >> 3)-th task of that XCD's band of tile rows
-    const uint32_t band = blockIdx.x & 7u, ti = blockIdx.x >> 3;
-    if (ti >= task_count[band]) return;
-    const uint32_t task = tasks[band * task_cap + ti];
-    const int tile = (int)(task & 0xffffffu), seg = (int)(task >> 24);
+    // Workgroup b runs on XCD b % 8 and takes the (b >> 3)-th slot of that XCD's band of tiles (the forward's tile -> XCD
+    // map, so a tile's records are in the L2 that fetched them).  Slot i = (depth segment i / band size, tile i % band
+    // size): all first segments come first, then all second ones, ...; a tile has min(GSR_SEG_MAX, ceil(tile_work /
+    // segment length)) segments and the workgroups of the ones it does not have leave at once.
+    const int band = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+    const int bq = T >> 3, br = T & 7;
+    const int band_first = band < br ? band * (bq + 1) : br * (bq + 1) + (band - br) * bq, band_size = bq + (band < br ? 1 : 0);
+    if (band_size == 0) return;
+    const int seg = slot / band_size, tile = band_first + (slot - seg * band_size);
+    if (seg >= GSR_SEG_MAX) return;
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
@@ -608,39 +612,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
     GSR_TRACE_END(2)
 }
 
-// Backward work list.  One workgroup per XCD band of tiles (the forward's tile -> XCD map, so a tile's records are
-// in the L2 that fetched them): tile t contributes min(GSR_SEG_MAX, ceil(tile_work[t] / GSR_SEG_LEN)) tasks; the list
-// holds all first segments, then all second ones, ... (full segments are equally long, the order inside a class is
-// whatever the LDS cursors hand out).
-__global__ void __launch_bounds__(1024) gsr_task_list_kernel(int T, const uint32_t* __restrict__ tile_work,
-                                                              uint32_t* __restrict__ tasks, uint32_t* __restrict__ task_count,
-                                                              uint32_t task_cap, int seg_len)
-{
-    __shared__ uint32_t cnt[GSR_SEG_MAX], cur[GSR_SEG_MAX];
-    const int xcd = blockIdx.x, q = T >> 3, r = T & 7;
-    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int ntiles = q + (xcd < r ? 1 : 0);
-    if (threadIdx.x < GSR_SEG_MAX) cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
-        const uint32_t w = tile_work[first + i];
-        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + (uint32_t)seg_len - 1) / (uint32_t)seg_len);
-        for (uint32_t s = 0; s < nt; s++) atomicAdd(&cnt[s], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int s = 0; s < GSR_SEG_MAX; s++) { cur[s] = run; run += cnt[s]; }
-        task_count[xcd] = run;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
-        const uint32_t w = tile_work[first + i];
-        const uint32_t nt = min((uint32_t)GSR_SEG_MAX, (w + (uint32_t)seg_len - 1) / (uint32_t)seg_len);
-        for (uint32_t s = 0; s < nt; s++) tasks[(size_t)xcd * task_cap + atomicAdd(&cur[s], 1u)] = (uint32_t)(first + i) | (s << 24);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
@@ -661,17 +632,15 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
-    hipLaunchKernelGGL(gsr_task_list_kernel, dim3(8), dim3(1024), 0, stream, T, image.tile_work, image.tasks, image.task_count,
-                       image.task_cap, gsr_seg_len(T));
-    // the grid covers the longest possible list; workgroups beyond their band's task count leave at once
-    const dim3 grid(8u * image.task_cap);
+    // the grid covers GSR_SEG_MAX segments of every tile; workgroups of segments a tile does not have leave at once
+    const dim3 grid(8u * (uint32_t)((T + 7) / 8) * GSR_SEG_MAX);
     if (dL_ddepth && dL_dfeature)
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                            gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, dL_ddepth, dL_dfeature,
-                           image.tile_work, image.tasks, image.task_count, image.task_cap, gsr_seg_len(T), geom.offsets, slot_written, s4);
+                           image.tile_work, T, gsr_seg_len(T), geom.offsets, slot_written, s4);
     else
         hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
                            gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, nullptr, nullptr,
-                           image.tile_work, image.tasks, image.task_count, image.task_cap, gsr_seg_len(T), geom.offsets, slot_written, s4);
+                           image.tile_work, T, gsr_seg_len(T), geom.offsets, slot_written, s4);
     return hipGetLastError();
 }

@@ -20,7 +20,6 @@
 //           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile)
 //           sorted_len[T] 4 B  length of the depth-sorted prefix of the tile's list (partial sort of long lists),
 //           need_full[T] 4 B   1 = a pixel of the tile was still blending at the end of that prefix
-//           tasks[8][cap] 4 B  backward work list per XCD band: tile | depth segment << 24; task_count[8]
 //           ckpt[GSR_SEG_MAX] slots of {float4[N'], float2[N']} (N' = N rounded up to 4): slot k-1 = list position
 //                              k * segment length (k = 1..GSR_SEG_MAX-1): {T in front of it, r, g, b}, {depth, feature}
 //                              sums over the segment that ends there; last slot: {checkpoints passed, sums behind the
@@ -82,10 +81,7 @@ struct GsrImage {
     uint32_t* tile_work;   // per tile: deepest n_contrib of its pixels = instances the backward must traverse
     uint32_t* sorted_len;  // per tile: its list is depth-sorted up to here (= list length unless partially sorted)
     uint32_t* need_full;   // per tile: 1 = the forward ran off the sorted prefix with pixels still blending
-    uint32_t* tasks;       // [8][task_cap] backward tasks of each XCD band: tile | segment << 24
-    uint32_t* task_count;  // [8]
     float* ckpt;           // [GSR_CKPT_PLANES][N], see the header comment
-    uint32_t task_cap;     // ceil(T / 8) * GSR_SEG_MAX
     size_t N;
     uint32_t* info;  // [0] = R, [1] = max tile count
     size_t bytes;
@@ -144,10 +140,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.tile_work = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.sorted_len = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.need_full = (uint32_t*)(b + off); off += gsr_align(T * 4);
-    im.task_cap = (uint32_t)(((T + 7) / 8) * GSR_SEG_MAX);
     im.N = N;
-    im.tasks = (uint32_t*)(b + off); off += gsr_align((size_t)8 * im.task_cap * 4);
-    im.task_count = (uint32_t*)(b + off); off += gsr_align(8 * 4);
     im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * ((N + 3) & ~(size_t)3) * 4);
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.bytes = off;

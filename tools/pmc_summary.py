@@ -25,7 +25,6 @@ STAGE_OF = {
     "gsr_tile_sort_lds_kernel<1024>": "tile_sort", "gsr_tile_sort_near_kernel": "tile_sort",
     "gsr_tile_sort_global_kernel": "tile_sort", "gsr_blend_fwd_kernel": "blend_forward",
     "gsr_blend_bwd_kernel<false>": "blend_backward", "gsr_blend_bwd_kernel<true>": "blend_backward",
-    "gsr_task_list_kernel": "blend_backward",
     "gsr_gauss_bwd_kernel": "gauss_backward",
 }
 
