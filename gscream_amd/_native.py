@@ -108,7 +108,7 @@ def load():
     lib.gsr_depth_loss_backward.restype = _c_int
     lib.gsr_depth_loss_backward.argtypes = [_c_int, _c_int] + [_vp] * 7
     lib.gsr_training_stats.restype = _c_int
-    lib.gsr_training_stats.argtypes = [_c_int, _c_int] + [_vp] * 11
+    lib.gsr_training_stats.argtypes = [_c_int, _c_int, _c_int] + [_vp] * 11
     _lib = lib
     return lib
 

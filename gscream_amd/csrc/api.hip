@@ -147,23 +147,55 @@ static int gsr_check_dims(int P, int W, int H)
     return GSR_OK;
 }
 
-// Pinned host words the tile-scan kernel writes {R, longest list} into; valid to read after the stream / event the
-// caller waits on.  One buffer per host thread and device.
+// Per host thread and device: the pinned, device-mapped words the tile-scan kernel writes {R, longest list} into (valid
+// to read after the stream / event the caller waits on) and the event that marks "R is on the host".  A thread that
+// alternates between devices finds each device's pair again (nothing is re-allocated on a switch); the pairs live as
+// long as the thread and are released when it exits.
+#define GSR_MAX_DEVICES 64
+struct GsrThreadDeviceState {
+    uint32_t* host[GSR_MAX_DEVICES] = {};
+    uint32_t* dev[GSR_MAX_DEVICES] = {};
+    hipEvent_t ev[GSR_MAX_DEVICES] = {};
+    ~GsrThreadDeviceState()
+    {
+        for (int d = 0; d < GSR_MAX_DEVICES; d++) {
+            if (host[d]) (void)hipHostFree(host[d]);
+            if (ev[d]) (void)hipEventDestroy(ev[d]);
+        }
+    }
+};
+static thread_local GsrThreadDeviceState g_tds;
+
+static int gsr_current_device(int* d)
+{
+    GSR_HIP(hipGetDevice(d), "hipGetDevice");
+    if (*d < 0 || *d >= GSR_MAX_DEVICES) return gsr_fail(GSR_ERR_UNSUPPORTED, "device index %d out of range", *d);
+    return GSR_OK;
+}
+
 static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
 {
-    static thread_local uint32_t* buf = nullptr;
-    static thread_local uint32_t* buf_dev = nullptr;
-    static thread_local int buf_device = -1;
     int d = 0;
-    GSR_HIP(hipGetDevice(&d), "hipGetDevice");
-    if (!buf || buf_device != d) {
+    int rc = gsr_current_device(&d);
+    if (rc) return rc;
+    if (!g_tds.host[d]) {
         void* p = nullptr;
         GSR_HIP(hipHostMalloc(&p, 64, hipHostMallocMapped), "hipHostMalloc(info)");
         void* pd = nullptr;
         GSR_HIP(hipHostGetDevicePointer(&pd, p, 0), "hipHostGetDevicePointer(info)");
-        buf = (uint32_t*)p; buf_dev = (uint32_t*)pd; buf_device = d;
+        g_tds.host[d] = (uint32_t*)p; g_tds.dev[d] = (uint32_t*)pd;
     }
-    *host = buf; *dev = buf_dev;
+    *host = g_tds.host[d]; *dev = g_tds.dev[d];
+    return GSR_OK;
+}
+
+static int gsr_info_event(hipEvent_t* ev)
+{
+    int d = 0;
+    int rc = gsr_current_device(&d);
+    if (rc) return rc;
+    if (!g_tds.ev[d]) GSR_HIP(hipEventCreateWithFlags(&g_tds.ev[d], hipEventDisableTiming), "hipEventCreate");
+    *ev = g_tds.ev[d];
     return GSR_OK;
 }
 
@@ -294,16 +326,11 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     if (P == 0) return GSR_OK;
     if (!background || !binning_ws || !out_color || !out_depth || !out_feature || binning_capacity <= 0)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL or the binning capacity is not positive");
-    // One event per thread marks "R is on the host"; stage 2 is enqueued BEFORE we wait for it, so the GPU never
-    // idles on the host round trip the reference pays at rasterizer_impl.cu:287.
-    static thread_local hipEvent_t ev = nullptr;
-    static thread_local int ev_dev = -1;
-    int dev = 0;
-    GSR_HIP(hipGetDevice(&dev), "hipGetDevice");
-    if (!ev || ev_dev != dev) {
-        GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
-        ev_dev = dev;
-    }
+    // One event per thread and device marks "R is on the host"; stage 2 is enqueued BEFORE we wait for it, so the GPU
+    // never idles on the host round trip the reference pays at rasterizer_impl.cu:287.
+    hipEvent_t ev = nullptr;
+    rc = gsr_info_event(&ev);
+    if (rc) return rc;
     volatile uint32_t* info = nullptr;
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
@@ -335,7 +362,8 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     // the guesses hold iff every list fitted the workspace AND the sort variants that were launched cover the longest list
     const bool ok = result_host->num_rendered <= binning_capacity &&
                     (max_tile_count_hint <= 0 || result_host->max_tile_count <= max_tile_count_hint ||
-                     (partial && max_tile_count_hint >= GSR_NEAR_CAP));  // lists beyond the cap do not depend on the hint
+                     (partial && max_tile_count_hint > GSR_NEAR_CAP));  // lists beyond the cap do not depend on the hint
+    // (strictly greater: gsr_launch_tile_sort starts the prefix-sort kernel only for a provision > GSR_NEAR_CAP)
     if (!ok) return GSR_NEED_CAPACITY;
     if (partial)
         return gsr_enqueue_fixup(P, W, H, binning_capacity, result_host->max_tile_count, background, geom_ws, image_ws,
@@ -576,17 +604,18 @@ extern "C" int gsr_depth_loss_backward(int H, int W, const float* depth, const f
 }
 
 // ---- densification statistics (stats.hip) ----
-extern "C" int gsr_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity, const uint8_t* selection,
+extern "C" int gsr_training_stats(int Nv, int K, int M, const int32_t* visible, const float* neural_opacity, const uint8_t* selection,
                                   const uint32_t* first, const uint8_t* update_filter, const float* viewspace_grad,
                                   float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
                                   float* offset_denom, void* stream)
 {
-    if (Nv < 0 || K < 1) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "training stats: bad sizes Nv=%d K=%d", Nv, K);
+    if (Nv < 0 || K < 1 || M < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "training stats: bad sizes Nv=%d K=%d M=%d", Nv, K, M);
     if (Nv == 0) return GSR_OK;
     if (!neural_opacity || !selection || !first || !opacity_accum || !anchor_demon || !offset_gradient_accum || !offset_denom)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "training stats: a required pointer is NULL");
     // update_filter / viewspace_grad may be NULL only if no offset was selected (M = 0); the kernel then never reads them
-    GSR_HIP(gst_launch_training_stats(Nv, K, visible, neural_opacity, selection, first, update_filter, viewspace_grad,
+    if (M > 0 && (!update_filter || !viewspace_grad)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "training stats: update_filter / viewspace_grad is NULL with M = %d", M);
+    GSR_HIP(gst_launch_training_stats(Nv, K, M, visible, neural_opacity, selection, first, update_filter, viewspace_grad,
                                       opacity_accum, anchor_demon, offset_gradient_accum, offset_denom, (hipStream_t)stream),
             "training stats");
     return GSR_OK;

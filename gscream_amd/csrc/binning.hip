@@ -659,16 +659,16 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
 // hipFuncSetAttribute between the stage-1 read-back and the stage-2 launches is exposed GPU idle time).
 static hipError_t gsr_allow_big_lds()
 {
-    static thread_local int done_for_device = -1;
+    static thread_local uint64_t done_mask = 0;  // one bit per device: switching devices re-issues nothing
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (done_for_device == dev) return hipSuccess;
+    if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1)) return hipSuccess;
     const int big = 160 * 1024 - 8192;  // static LDS: hist / scatter 2 KiB, tile sort 4.2 KiB (bucket offsets)
     e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 17408);  // 16.9 KiB static: 4096 bucket offsets + scan scratch
-    if (e == hipSuccess) done_for_device = dev;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done_mask |= 1ull << dev;
     return e;
 }
 

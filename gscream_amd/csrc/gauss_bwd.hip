@@ -80,6 +80,9 @@ __device__ __forceinline__ float3 gsr_sh_backward(int idx, int deg, int M, float
     }
 #undef SH
 #undef DSH
+    // coefficients beyond the active degree get no gradient: exact zeros, as in the reference's zero-filled dL_dsh
+    // (rasterize_points.cu:168; the usual 3DGS degree ramp runs with M = 16 and sh_degree 0..2)
+    for (int i = (deg + 1) * (deg + 1) * 3; i < M * 3; i++) dsh[i] = 0.f;
     const float gx_ = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
     const float gy_ = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
     const float gz_ = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];

@@ -236,7 +236,7 @@ hipError_t gdl_launch_backward(int H, int W, const float* depth, const float* ta
                                const void* workspace, const float* upstream, float* dL_ddepth, hipStream_t stream);
 
 // ---- stats.hip (densification statistics) ----
-hipError_t gst_launch_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity,
+hipError_t gst_launch_training_stats(int Nv, int K, int M, const int32_t* visible, const float* neural_opacity,
                                      const uint8_t* selection, const uint32_t* first, const uint8_t* update_filter,
                                      const float* viewspace_grad, float* opacity_accum, float* anchor_demon,
                                      float* offset_gradient_accum, float* offset_denom, hipStream_t stream);

@@ -14,7 +14,7 @@
 #include "gsr_common.h"
 
 __global__ void __launch_bounds__(256) gst_training_stats_kernel(
-    int Nv, int K, const int32_t* __restrict__ visible, const float* __restrict__ neural_opacity,
+    int Nv, int K, int M, const int32_t* __restrict__ visible, const float* __restrict__ neural_opacity,
     const uint8_t* __restrict__ selection, const uint32_t* __restrict__ first, const uint8_t* __restrict__ update_filter,
     const float* __restrict__ viewspace_grad /*[M,3]*/, float* __restrict__ opacity_accum, float* __restrict__ anchor_demon,
     float* __restrict__ offset_gradient_accum, float* __restrict__ offset_denom)
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) gst_training_stats_kernel(
         const float op = neural_opacity[(size_t)n * K + k];
         osum += op < 0.f ? 0.f : op;
         if (!selection[(size_t)n * K + k]) continue;
-        if (update_filter[row]) {
+        if (row < (uint32_t)M && update_filter[row]) {  // row >= M: a selection mask of another render; never read out of bounds
             const float gx = viewspace_grad[3 * (size_t)row], gy = viewspace_grad[3 * (size_t)row + 1];
             offset_gradient_accum[(size_t)a * K + k] += sqrtf(gx * gx + gy * gy);
             offset_denom[(size_t)a * K + k] += 1.0f;
@@ -39,13 +39,13 @@ __global__ void __launch_bounds__(256) gst_training_stats_kernel(
     anchor_demon[a] += 1.0f;
 }
 
-hipError_t gst_launch_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity,
+hipError_t gst_launch_training_stats(int Nv, int K, int M, const int32_t* visible, const float* neural_opacity,
                                      const uint8_t* selection, const uint32_t* first, const uint8_t* update_filter,
                                      const float* viewspace_grad, float* opacity_accum, float* anchor_demon,
                                      float* offset_gradient_accum, float* offset_denom, hipStream_t stream)
 {
     if (Nv <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gst_training_stats_kernel, dim3((Nv + 255) / 256), dim3(256), 0, stream, Nv, K, visible, neural_opacity,
+    hipLaunchKernelGGL(gst_training_stats_kernel, dim3((Nv + 255) / 256), dim3(256), 0, stream, Nv, K, M, visible, neural_opacity,
                        selection, first, update_filter, viewspace_grad, opacity_accum, anchor_demon, offset_gradient_accum,
                        offset_denom);
     return hipGetLastError();

@@ -36,10 +36,16 @@ def training_statis(model, viewspace_point_tensor, opacity, update_filter, offse
     first = (torch.cumsum(counts, 0, dtype=torch.int32) - counts).contiguous()
     uf = update_filter.detach().reshape(-1).to(torch.uint8).contiguous()
     grad = viewspace_point_tensor.grad.detach().contiguous().float()
-    if int(uf.shape[0]) != int(grad.shape[0]):
+    M = int(uf.shape[0])
+    if M != int(grad.shape[0]):
         raise ValueError("update_filter and viewspace_point_tensor.grad disagree on the number of Gaussians")
+    # the reference's `combined_mask[temp_mask] = update_filter` raises a shape error when the selection mask comes from
+    # another render than update_filter; same here (the kernel additionally never reads beyond row M)
+    kept = int(counts.sum()) if Nv else 0
+    if kept != M:
+        raise ValueError(f"offset_selection_mask keeps {kept} offsets but update_filter has {M} entries (masks of different renders?)")
     with torch.cuda.device(dev):
-        _native.check(lib.gsr_training_stats(Nv, K, _native.ptr(vis), _native.ptr(nop), _native.ptr(sel), _native.ptr(first),
+        _native.check(lib.gsr_training_stats(Nv, K, M, _native.ptr(vis), _native.ptr(nop), _native.ptr(sel), _native.ptr(first),
                                              _native.ptr(uf), _native.ptr(grad), _native.ptr(model.opacity_accum),
                                              _native.ptr(model.anchor_demon), _native.ptr(model.offset_gradient_accum),
                                              _native.ptr(model.offset_denom),

@@ -153,13 +153,25 @@ class _DepthLoss(torch.autograd.Function):
 
 
 def depth_loss(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0,
-               return_parts=False):
+               return_parts=False, fg_mask=None, lambda_fg=0.0):
     """The depth terms of train.py:548-573 in one forward and one backward:
         scale, shift = compute_scale_and_shift(depth, target, lsq_mask); aligned = |scale| * depth + shift
         lambda_l1 * l1_loss[_masked](aligned, target[, l1_weight])
+          + lambda_fg * l1_loss_masked(aligned, target, fg_mask)                                  (train.py:555-557)
           + sum_{k<4} 0.5 * lambda_smooth * gradient_loss(aligned[:, ::2^k, ::2^k], target[...], grad_mask[...])
-    (reference view: l1_weight = grad_mask = None; other views: both = valid_mask).  Gradients flow to `depth`, through
-    the alignment as well.  return_parts -> (loss, (loss, l1 mean, smooth part, scale, shift))."""
+    Reference view (train.py:548-561): lsq_mask = 1 - gt_mask, l1_weight = grad_mask = None, lambda_l1 =
+    opt.refer_depth_lr, lambda_smooth = opt.refer_depth_lr_smooth and -- in the shipped run config (scripts/run.py:
+    refer_depth_lr_fg = 100 > refer_depth_lr = 1) -- the foreground term `fg_mask = get_random_mask(...)`, `lambda_fg =
+    opt.refer_depth_lr_fg - opt.refer_depth_lr`, the DOMINANT depth term there: do not drop it.  Other views (:563-573):
+    l1_weight = grad_mask = lsq_mask = valid_mask, lambda_l1 = opt.other_depth_lr, lambda_smooth =
+    opt.other_depth_lr_smooth.  Both L1 terms are means over all pixels of |aligned - target| times a weight
+    (utils/loss_utils.py:26-30), so they are folded into ONE per-pixel weight map `lambda_l1 * l1_weight + lambda_fg *
+    fg_mask` for the kernel.  Gradients flow to `depth`, through the alignment as well.
+    return_parts -> (loss, (loss, weighted L1 mean, smooth part, scale, shift))."""
+    if fg_mask is not None and float(lambda_fg) != 0.0:
+        base = float(lambda_l1) if l1_weight is None else float(lambda_l1) * l1_weight.detach().float()
+        l1_weight = base + float(lambda_fg) * fg_mask.detach().float().reshape(
+            fg_mask.shape[-2:] if l1_weight is None else l1_weight.shape)
+        lambda_l1 = 1.0
     loss, parts = _DepthLoss.apply(depth, target, lsq_mask, l1_weight, grad_mask, lambda_l1, lambda_smooth)
     return (loss, parts) if return_parts else loss
-

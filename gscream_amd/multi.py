@@ -31,6 +31,76 @@ def init(backend, device=None):
     return dist
 
 
+def launch_ranks(script, argv, n_gpus, python=None):
+    """`bench.py --gpus N` started WITHOUT torchrun: re-execute the script as N ranks of one node
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), one process per
+    GPU, and return the launcher's exit code.  Rank 0 prints the JSON line; stdout/stderr pass straight through."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def pick_device(local_rank, oversubscribe=False):
+    """The GPU of this rank: one rank per GPU.  More ranks than GPUs is an error unless `oversubscribe` (a test mode
+    for boxes with a single GPU: ranks share devices round-robin; never a measurement)."""
+    n = torch.cuda.device_count()
+    if local_rank < n:
+        return local_rank
+    if not oversubscribe:
+        raise RuntimeError(f"rank with LOCAL_RANK={local_rank} has no GPU of its own: only {n} visible "
+                           "(one process per GPU; pass --oversubscribe only to test the launch path)")
+    return local_rank % max(n, 1)
+
+
+class SceneQueue:
+    """Shared work queue for more scenes than GPUs (BASELINE.json config 5: ten SPIn-NeRF scenes on eight GPUs; the
+    reference trains them one after the other, scripts/run.py:14-80).  A rank that finishes a scene pulls the next
+    index, so the two left-over scenes go to whichever GPUs are free first.  The queue head is one atomic counter in
+    the process group's TCPStore (host side, rank 0 serves it): no collective, nothing on xGMI.  Single process: a
+    local counter."""
+
+    def __init__(self, dist, num_scenes, name="gsr_scene_queue"):
+        self.num_scenes, self.name, self._local = int(num_scenes), name, 0
+        self.store = None
+        if dist is not None:
+            self.store = dist.distributed_c10d._get_default_store()
+
+    def pull(self):
+        """-> next scene index, or None when the list is exhausted.  Every index is handed out exactly once."""
+        if self.store is None:
+            i, self._local = self._local, self._local + 1
+        else:
+            i = int(self.store.add(self.name, 1)) - 1
+        return i if i < self.num_scenes else None
+
+
+def config5_scene(index):
+    """(seed, P) of scene `index` of config 5: seeds 10..19 of the config-2 generator,
+    P in [0.6, 1.4] x 10^6, fixed per seed."""
+    import numpy as np
+    seed = 10 + int(index)
+    frac = np.random.default_rng(1000 + seed).uniform(0.6, 1.4)
+    return seed, int(round(frac * 1_000_000 / 1000.0)) * 1000
+
+
+def gather_objects(dist, obj):
+    """Every rank's small report object on every rank (host side; gloo or RCCL's object path)."""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def assign_scenes(num_scenes, world_size):
     """Static round-robin share of the scene list per rank: BASELINE.json config 5 (10 scenes on 8 GPUs) gives
     ranks 0 and 1 two scenes each.  Every scene appears exactly once."""
@@ -52,6 +122,8 @@ def barrier(dist, device=None):
 def aggregate_throughput(dist, units_done, elapsed_s, device=None):
     """Whole-job throughput = units processed by ALL ranks / the SLOWEST rank's time (bench.py contract).
     Returns (total_units, max_elapsed, units_per_second) on every rank."""
+    if dist is not None and dist.get_backend() == "gloo":
+        device = None  # gloo reduces host tensors
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units_done)], dtype=torch.float64, device=device)
     if dist is not None:

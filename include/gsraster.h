@@ -17,9 +17,12 @@
  *     (DGR forward.cu:209,245; backward.cu:400,404);
  *   - every function returns 0 on success and a negative gsr_status on failure;
  *     gsr_last_error() returns a thread-local message for the last failure on this thread;
- *   - the library owns no memory and keeps no global state: workspaces are sized by the
- *     gsr_*_bytes queries, allocated by the caller (PyTorch's caching allocator) and passed in.
- *     All workspace pointers must be 256-byte aligned.
+ *   - the library owns no device memory: workspaces are sized by the gsr_*_bytes queries, allocated by the
+ *     caller (PyTorch's caching allocator) and passed in.  All workspace pointers must be 256-byte aligned.
+ *     State it does keep, none of it observable through results: per host thread and device one 64-byte pinned,
+ *     device-mapped word block (the read-back of num_rendered) and one event, created on first use and released
+ *     when the thread exits; the last-error string (thread-local); the optional profiler's event list
+ *     (process-wide, mutex-guarded, only between gsr_profile_begin / _end).  Entry points are re-entrant.
  *   - `stream` is a hipStream_t (NULL = the legacy default stream, which is what the reference
  *     launches on).  debug != 0 synchronises and checks for errors after every stage, the
  *     semantics of the reference's CHECK_CUDA (auxiliary.h:166-173).
@@ -220,7 +223,7 @@ int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t
  * decoded Gaussians), viewspace_grad[M,3] (gradient of the screen-space means).  Accumulates IN PLACE into the
  * model-sized opacity_accum[N], anchor_demon[N], offset_gradient_accum[N*K], offset_denom[N*K] (fp32).
  */
-int gsr_training_stats(int Nv, int K, const int32_t* visible, const float* neural_opacity, const uint8_t* selection,
+int gsr_training_stats(int Nv, int K, int M, const int32_t* visible, const float* neural_opacity, const uint8_t* selection,
                        const uint32_t* first, const uint8_t* update_filter, const float* viewspace_grad,
                        float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                        void* stream);

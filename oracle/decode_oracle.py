@@ -7,42 +7,13 @@ the parts of scene/gaussian_model.py the function touches (MLPs as :118-144, act
 PARITY UNPINNED: the reference module cannot be imported here (it imports einops' `repeat` -- present -- but also
 scene.gaussian_model, which needs simple_knn / plyfile / torch_scatter builds that are absent), and the reference
 ships no vectors for it; the restatement follows the cited lines one to one."""
+import os
+import sys
+
 import torch
-from torch import nn
 
-
-class Camera:
-    def __init__(self, center):
-        self.camera_center = center
-
-
-class Model(nn.Module):
-    """What generate_neural_gaussians reads from GaussianModel."""
-
-    def __init__(self, N, K=10, feat_dim=32, seed=0, dtype=torch.float64, spread=3.0):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
-        self.n_offsets, self.use_feat_bank = K, False
-        self._anchor = nn.Parameter((r(N, 3) * spread).to(dtype))
-        self._anchor_feat = nn.Parameter((r(N, feat_dim) * 0.5).to(dtype))
-        self._offset = nn.Parameter((r(N, K, 3) * 0.3).to(dtype))
-        self._scaling = nn.Parameter((r(N, 6) * 0.3 - 2.0).to(dtype))
-        mk = lambda out, act: nn.Sequential(nn.Linear(feat_dim + 3 + 1, feat_dim), nn.ReLU(True), nn.Linear(feat_dim, out),
-                                            *([act] if act is not None else [])).to(dtype)
-        torch.manual_seed(seed + 1)
-        self.mlp_opacity = mk(K, nn.Tanh())             # scene/gaussian_model.py:118-123
-        self.mlp_uncertainty = mk(K, nn.Sigmoid())       # :125-131
-        self.mlp_cov = mk(7 * K, None)                   # :133-137
-        self.mlp_color = mk(3 * K, nn.Sigmoid())         # :139-144
-        self.rotation_activation = torch.nn.functional.normalize  # :54
-
-    get_anchor = property(lambda self: self._anchor)
-    get_scaling = property(lambda self: 1.0 * torch.exp(self._scaling))  # :241-242
-    get_opacity_mlp = property(lambda self: self.mlp_opacity)
-    get_uncertainty_mlp = property(lambda self: self.mlp_uncertainty)
-    get_cov_mlp = property(lambda self: self.mlp_cov)
-    get_color_mlp = property(lambda self: self.mlp_color)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gscream_amd.standin_model import Camera, Model  # noqa: E402,F401  (seeded parameter container, shared with bench.py)
 
 
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):

@@ -107,14 +107,18 @@ def gradient_loss(prediction, target, mask):  # :58-74
     return reduction_batch_based(torch.sum(grad_x, (1, 2)) + torch.sum(grad_y, (1, 2)), M)
 
 
-def depth_loss(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0):
-    """train.py:548-561 (reference view: weights None) / :563-573 (other views: l1_weight = grad_mask = valid_mask)."""
+def depth_loss(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0,
+               fg_mask=None, lambda_fg=0.0):
+    """train.py:548-561 (reference view: weights None; fg_mask / lambda_fg = the foreground term :555-557) / :563-573
+    (other views: l1_weight = grad_mask = valid_mask)."""
     ones = torch.ones_like(depth)
     m = ones if lsq_mask is None else lsq_mask
     scale, shift = compute_scale_and_shift(depth, target, m)          # train.py:551
     scale = torch.abs(scale)                                          # :552
     aligned = scale.view(-1, 1, 1) * depth + shift.view(-1, 1, 1)     # :553
     loss = lambda_l1 * (l1_loss(aligned, target) if l1_weight is None else l1_loss_masked(aligned, target, l1_weight))
+    if fg_mask is not None:
+        loss = loss + lambda_fg * l1_loss_masked(aligned, target, fg_mask)   # train.py:555-557
     g = ones if grad_mask is None else grad_mask
     for k in range(4):                                                # :558-561
         step = pow(2, k)
@@ -123,10 +127,10 @@ def depth_loss(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lam
 
 
 def depth_value_and_grad(depth, target, lsq_mask=None, l1_weight=None, grad_mask=None, lambda_l1=1.0, lambda_smooth=1.0,
-                         dtype=torch.float64):
+                         dtype=torch.float64, fg_mask=None, lambda_fg=0.0):
     t = lambda a: None if a is None else torch.as_tensor(a).to(dtype).reshape(1, *torch.as_tensor(a).shape[-2:])
     d = t(depth).clone().requires_grad_(True)
-    loss, scale, shift = depth_loss(d, t(target), t(lsq_mask), t(l1_weight), t(grad_mask), lambda_l1, lambda_smooth)
+    loss, scale, shift = depth_loss(d, t(target), t(lsq_mask), t(l1_weight), t(grad_mask), lambda_l1, lambda_smooth, t(fg_mask), lambda_fg)
     loss.backward()
     return float(loss.detach()), float(scale.detach()), float(shift.detach()), d.grad[0].numpy()
 

@@ -126,6 +126,26 @@ def test_depth_loss_against_oracle(H, W, masked, seed):
     assert bad.mean() <= 2e-3, float(bad.mean())
 
 
+def test_depth_loss_reference_view_with_foreground_term():
+    """The shipped run config (scripts/run.py: refer_depth_lr_fg = 100 > refer_depth_lr = 1) adds
+    (fg - lr) * l1_loss_masked(aligned, midas, fg_mask) at train.py:555-557 -- the dominant depth term."""
+    from gscream_amd import loss_utils as L
+    H, W = 96, 160
+    d, y, m, _ = _depth_case(11, H, W, False)
+    fg = np.zeros((H, W), np.float32)
+    fg[20:70, 40:120] = 1.0
+    ref_loss, ref_s, ref_t, ref_g = LO.depth_value_and_grad(d, y, m, None, None, 1.0, 1.0, fg_mask=fg, lambda_fg=99.0)
+    plain, *_ = LO.depth_value_and_grad(d, y, m, None, None, 1.0, 1.0)
+    assert ref_loss > 3 * plain, "the foreground term dominates in the shipped configuration"
+    t = lambda a: torch.from_numpy(a).cuda().reshape(1, H, W)
+    x = t(d).requires_grad_(True)
+    loss = L.depth_loss(x, t(y), t(m), None, None, 1.0, 1.0, fg_mask=t(fg), lambda_fg=99.0)
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) < 5e-6 * max(1.0, abs(ref_loss))
+    bad = np.abs(x.grad.cpu().numpy().reshape(H, W) - ref_g) > 1e-4 * np.abs(ref_g).max()
+    assert bad.mean() <= 2e-3, float(bad.mean())
+
+
 def test_depth_loss_properties_full_size():
     from gscream_amd import loss_utils as L
     g = torch.Generator(device="cuda").manual_seed(3)

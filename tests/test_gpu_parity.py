@@ -219,6 +219,28 @@ def test_partial_sort_of_long_lists(scale_mul, expect_fixup):
     Hh.assert_grads_close(got, ref, context=f"partial sort, scales x{scale_mul}", max_bad_frac=2e-3)
 
 
+def test_speculative_hint_exactly_at_the_partial_sort_cap():
+    """A caller of the C ABI may pass max_tile_count_hint == GSR_NEAR_CAP (2048) while a real list is longer: the prefix-sort
+    kernel is only launched for provisions > 2048, so the call must come back as NEED_CAPACITY and be redone, never
+    return tiles rendered as background."""
+    from gscream_amd import rasterizer as RZ
+    s = S.scene_config1(seed=33, P=14_000, W=32, H=32, lateral=0.3)
+    s["scales"] *= np.float32(6.0)
+    s["opacities"] = np.maximum(s["opacities"], np.float32(0.6))
+    st = Hh.oracle_forward(s)
+    assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 2048
+    set_tuning()
+    ref = Hh.hip_run(s)
+    for hint in (2048, 2049, 1024):
+        RZ._capacity_hint[0] = (1 << 22, hint)
+        got = Hh.hip_run(s)
+        assert RZ._last_stage1["speculative"] is (hint > 2048), (hint, RZ._last_stage1)
+        for k in ("out_color", "out_depth", "out_unc", "radii"):
+            assert np.array_equal(got[k], ref[k]), (hint, k)
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(ref[k], st[k], k, max_outlier_frac=2e-3)
+
+
 @pytest.mark.parametrize("clustered_frac", [0.3, 1.0])
 def test_tile_sort_with_depth_clusters(clustered_frac):
     """The O(n) bucket sort of the tile lists spreads the keys over 1024 equal-width buckets of the tile's depth range;
@@ -492,6 +514,26 @@ def test_more_cases_against_live_oracle(variant):
         full = Hh.hip_run(s, keep_state=True)
         assert full["num_rendered"] == st["num_rendered"]
         _check_binning(s, full, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_sh_degree_ramp_leaves_unused_coefficients_with_zero_gradient(deg):
+    """The usual 3DGS ramp: M = 16 coefficients allocated, only (deg+1)^2 active.  The gradient rows of the inactive
+    coefficients must be exact zeros (the reference zero-fills dL_dsh, rasterize_points.cu:168) although the gradient
+    tensors are torch.empty -- the allocator is poisoned first so stale memory would show."""
+    rng = np.random.default_rng(300 + deg)
+    s = S.scene_config1(seed=310 + deg, P=1500, W=112, H=80)
+    s["shs"] = rng.normal(0, 0.35, size=(1500, 16, 3)).astype(np.float32)
+    s["sh_degree"] = deg
+    del s["colors"]
+    grads = S.upstream_grads(91, s["W"], s["H"])
+    poison = [torch.full((1500 * 16 * 3,), float("nan"), device="cuda") for _ in range(8)]
+    del poison
+    st, got = _vs_oracle(s, grads, f"sh_ramp_deg{deg}")
+    n = (deg + 1) ** 2
+    assert got["dL_dsh"].shape == (1500, 16, 3)
+    assert (got["dL_dsh"][:, n:, :] == 0).all(), "inactive SH coefficients must get exact zeros"
+    assert np.abs(got["dL_dsh"][:, :n, :]).max() > 0
 
 
 def test_non_finite_inputs_do_not_fault():

@@ -35,7 +35,9 @@ def _worker(rank, world, port, out):
     units, elapsed = 10 * len(my_scenes), 1.0 + 0.5 * rank
     total, tmax, rate = multi.aggregate_throughput(dist, units, elapsed)
     multi.barrier(dist)
-    out[rank] = (my_scenes, total, tmax, rate, multi.scene_seed(7, rank, world))
+    pulled = [i for i in iter(multi.SceneQueue(dist, 10).pull, None)]  # config 5: shared work queue
+    multi.barrier(dist)
+    out[rank] = (my_scenes, total, tmax, rate, multi.scene_seed(7, rank, world), pulled, multi.gather_objects(dist, pulled))
     dist.destroy_process_group()
 
 
@@ -49,9 +51,12 @@ def test_two_rank_gloo_throughput_reduction():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert out[0][0] == [0, 2, 4] and out[1][0] == [1, 3]
     for r in range(world):
-        _, total, tmax, rate, seed = out[r]
+        _, total, tmax, rate, seed = out[r][:5]
         assert total == 50.0 and tmax == 1.5 and abs(rate - 50.0 / 1.5) < 1e-9  # all units / slowest rank
     assert out[0][4] != out[1][4]
+    # the work queue hands every one of the ten scenes to exactly one rank, and the report gather sees both shares
+    assert sorted(out[0][5] + out[1][5]) == list(range(10))
+    assert out[0][6] == out[1][6] == [out[0][5], out[1][5]]
 
 
 def test_single_process_needs_no_process_group():
@@ -59,3 +64,35 @@ def test_single_process_needs_no_process_group():
     assert multi.init("gloo") is None
     total, tmax, rate = multi.aggregate_throughput(None, 20, 0.5)
     assert (total, tmax, rate) == (20.0, 0.5, 40.0)
+
+
+def test_scene_queue_single_process_and_config5_scene_list():
+    q = multi.SceneQueue(None, 3)
+    assert [q.pull(), q.pull(), q.pull(), q.pull(), q.pull()] == [0, 1, 2, None, None]
+    scenes = [multi.config5_scene(i) for i in range(10)]
+    assert [s for s, _ in scenes] == list(range(10, 20))          # seeds 10..19
+    assert all(600_000 <= p <= 1_400_000 for _, p in scenes) and len({p for _, p in scenes}) > 5
+    assert scenes == [multi.config5_scene(i) for i in range(10)]  # fixed per seed
+
+
+def test_pick_device_refuses_more_ranks_than_gpus(monkeypatch):
+    import pytest
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert multi.pick_device(1) == 1 and multi.pick_device(3, oversubscribe=True) == 1
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        multi.pick_device(2)
+
+
+def test_bench_refuses_gpus_without_devices():
+    """`bench.py --gpus 8` on a box without 8 GPUs must fail loudly instead of measuring fewer GPUs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "one process per GPU" in (p.stderr + p.stdout)
+    # and a launcher/flag mismatch is an error too
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
