@@ -44,12 +44,19 @@
 // pre-multiplied by log2 e, so the exponent goes straight into the instruction; ~1 ulp) and
 // T/(1-alpha) via v_rcp_f32 (1 ulp).  -DGSR_PRECISE_MATH selects libm-accurate expf and IEEE division
 // (diagnostic build, used to attribute parity differences; not shipped).
+// PARITY build (-DGSR_PRECISE_MATH, libgsraster_precise.so, compiled with -ffp-contract=off): the records keep the raw
+// conic (preprocess.hip) and the falloff is the reference's own expression, power = -0.5 (A dx^2 + C dy^2) - B dx dy,
+// alpha = min(0.99, o * expf(power)) (DGR forward.cu:528-533, backward.cu:516-524), with libm-accurate expf and IEEE
+// division -- no pre-scaling, no v_exp_f32, no v_rcp_f32, no FMA contraction.  Used by tests/test_gpu_precise.py to show
+// that the outliers of the shipped build against the oracle are alpha = 1/255 / T = 1e-4 threshold flips.
 #ifdef GSR_PRECISE_MATH
-#define GSR_EXP2(x) exp2f(x)
 #define GSR_RCP(x) (1.0f / (x))
+#define GSR_QSCALE(v) ((v) * GSR_LOG2E)     // raw conic entry -> entry of the base-2 quadratic form used by the box tests
+__device__ __forceinline__ float gsr_power1(float cA, float cB, float cC, float dx, float dy) { return -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy; }
+__device__ __forceinline__ float gsr_gauss1(float power) { return expf(power); }
 #else
-#define GSR_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define GSR_RCP(x) __builtin_amdgcn_rcpf(x)
+__device__ __forceinline__ float gsr_gauss1(float power) { return __builtin_amdgcn_exp2f(power); }
 #endif
 
 // -DGSR_TRACE (diagnostic build `make trace`, not shipped): every wavefront of the backward blend records its start and
@@ -138,7 +145,11 @@ __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const floa
 {
     // records hold (hA, hB, hC) = -log2(e) (conA/2, conB, conC/2): q2 = log2(e) q = 0.5 (a dx^2 + c dy^2) + b dx dy with
     // a = -2 hA, b = -hB, c = -2 hC; the threshold scales the same way
+#ifdef GSR_PRECISE_MATH
+    const float ca = GSR_QSCALE(A.z), cb = GSR_QSCALE(A.w), cc = GSR_QSCALE(B.x);
+#else
     const float ca = -2.0f * A.z, cb = -A.w, cc = -2.0f * B.x;
+#endif
     const float rA = GSR_RCP(ca), rC = GSR_RCP(cc);
     uint32_t m = 0;
 #pragma unroll
@@ -248,7 +259,11 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         const int cnt = min(GSR_FWB, n - base);
         bool hit = false;
         if (lane < cnt) {
+#ifdef GSR_PRECISE_MATH
+            const float ca = GSR_QSCALE(a.z), cb = GSR_QSCALE(a.w), cc = GSR_QSCALE(b.x);
+#else
             const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;
+#endif
             hit = !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), bx0, bx1, by0, by1) >
                     gsr_cull_tau_fast(b.y) * GSR_LOG2E);
         }
@@ -284,9 +299,13 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             const gsr_f2 HC = {P2.x, P2.y}, OP = {P2.z, P2.w};
             const gsr_f2 dx = X - pxf, dy = Y - pyf;
             // log2 of the falloff, evaluated as fma(dy, hC dy, dx * fma(hA, dx, hB dy)) like every blend kernel
+#ifdef GSR_PRECISE_MATH
+            const gsr_f2 power = {gsr_power1(HA.x, HB.x, HC.x, dx.x, dy.x), gsr_power1(HA.y, HB.y, HC.y, dx.y, dy.y)};
+#else
             const gsr_f2 inner = gsr_fma2(HA, dx, HB * dy);
             const gsr_f2 power = gsr_fma2(dy, HC * dy, dx * inner);
-            const gsr_f2 G = {GSR_EXP2(power.x), GSR_EXP2(power.y)};
+#endif
+            const gsr_f2 G = {gsr_gauss1(power.x), gsr_gauss1(power.y)};
             const gsr_f2 al = OP * G;
             const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
             const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
@@ -507,9 +526,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
                     const gsr_f2 dx = gsr_splat(A.x) - pxf;
                     const float dy = A.y - pyf;
                     // log2 of the falloff, same evaluation order as the forward: fma(dy, hC dy, dx * fma(hA, dx, hB dy))
+#ifdef GSR_PRECISE_MATH
+                    const gsr_f2 power = {gsr_power1(A.z, A.w, B.x, dx.x, dy), gsr_power1(A.z, A.w, B.x, dx.y, dy)};
+#else
                     const gsr_f2 inner = gsr_fma2(gsr_splat(A.z), dx, gsr_splat(A.w * dy));
                     const gsr_f2 power = gsr_fma2(gsr_splat(dy), gsr_splat(B.x * dy), dx * inner);
-                    const gsr_f2 G = {GSR_EXP2(power.x), GSR_EXP2(power.y)};
+#endif
+                    const gsr_f2 G = {gsr_gauss1(power.x), gsr_gauss1(power.y)};
                     const gsr_f2 al = B.y * G;
                     const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
                     // lane masks straight from the compares, combined on the scalar unit (see the forward)
@@ -597,8 +620,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
                 //   dL/dopacity = M0            with M* = sum over pixels of G dL/dalpha {dx, dy, dx^2, dx dy, dy^2, 1}
                 const float4 A = sA[t], B = sB[t];
                 const float op = B.y, Mx = o1.y, My = o1.z, Mxx = o1.w, Mxy = o2.x, Myy = o2.y;
+#ifdef GSR_PRECISE_MATH
+                const float cA = A.z, cB = A.w, cC = B.x;
+#else
                 const float k = -1.0f / GSR_LOG2E;  // back from the pre-scaled form to the conic (A, B, C)
                 const float cA = 2.0f * k * A.z, cB = k * A.w, cC = 2.0f * k * B.x;
+#endif
                 o1.y = -op * (cA * Mx + cB * My) * ddelx_dx;
                 o1.z = -op * (cC * My + cB * Mx) * ddely_dy;
                 o1.w = -0.5f * op * Mxx; o2.x = -0.5f * op * Mxy; o2.y = -0.5f * op * Myy;

@@ -189,8 +189,13 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         else col = gsr_sh_to_rgb(idx, D, M, p, cam, shs, clamped);
         GsrRec* r = rec + idx;
         // quadratic form pre-scaled for the blend loops: log2(alpha/opacity) = dx (hA dx + hB dy) + hC dy^2
+#ifdef GSR_PRECISE_MATH  // parity build: the records keep the raw conic, the blend evaluates the reference's expression
+        r->a = make_float4(pix, piy, conx, cony);
+        r->b = make_float4(conz, opacities[idx], viewz, features[idx]);
+#else
         r->a = make_float4(pix, piy, conx * (-0.5f * GSR_LOG2E), cony * (-GSR_LOG2E));
         r->b = make_float4(conz * (-0.5f * GSR_LOG2E), opacities[idx], viewz, features[idx]);
+#endif
         r->c = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));  // .w = rectangle width
         r->d = make_uint4(0u, (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
     }

@@ -9,7 +9,7 @@ the reference's GaussianModel does: `_anchor_feat`, `get_anchor`, `_offset`, `ge
 The visible-anchor gather (:25-28) is folded into the kernels (the mask becomes a row list once); view vector, four
 MLPs, opacity mask, boolean-mask compaction, post-processing run in `gsr_decode_count` / `gsr_decode_emit`
 (include/gsraster.h), and the backward in `gsr_decode_backward` + eight plain GEMMs for the weight gradients.
-`use_feat_bank=True` (off in every GScream config, arguments/__init__.py:57) raises NotImplementedError.
+`use_feat_bank=True` (off in every GScream config, arguments/__init__.py:57) runs the bank MLP + blend as a torch pre-step.
 No CPU fallback."""
 import ctypes
 
@@ -145,9 +145,30 @@ def decode(feat, anchor, offsets, grid_scaling, campos, opacity_mlp, uncertainty
     return _Decode.apply(feat, anchor, offsets, grid_scaling, campos, visible_idx, *weights)
 
 
+def _generate_with_feature_bank(viewpoint_camera, pc, visible_mask, is_training):
+    """gaussian_renderer/__init__.py:39-49: the view-adaptive feature bank (use_feat_bank=True; off in every shipped
+    config, arguments/__init__.py:57).  The bank MLP (4 -> 32 -> 3, softmax) and the three-resolution blend of the anchor
+    feature are a per-anchor pre-step in front of the fused decode: done with torch ops on the gathered rows (autograd
+    carries their backward), then the same kernels run on the blended feature."""
+    if visible_mask is None:
+        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
+    feat, anchor = pc._anchor_feat[visible_mask], pc.get_anchor[visible_mask]
+    grid_offsets, grid_scaling = pc._offset[visible_mask], pc.get_scaling[visible_mask]
+    ob_view = anchor - viewpoint_camera.camera_center
+    ob_dist = ob_view.norm(dim=1, keepdim=True)
+    ob_view = ob_view / ob_dist
+    bank_weight = pc.get_featurebank_mlp(torch.cat([ob_view, ob_dist], dim=1)).unsqueeze(dim=1)  # [n, 1, 3]
+    f = feat.unsqueeze(dim=-1)
+    f = (f[:, ::4, :1].repeat([1, 4, 1]) * bank_weight[:, :, :1] + f[:, ::2, :1].repeat([1, 2, 1]) * bank_weight[:, :, 1:2]
+         + f[:, ::1, :1] * bank_weight[:, :, 2:])
+    out = decode(f.squeeze(dim=-1), anchor, grid_offsets, grid_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,
+                 pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp, None)
+    return out if is_training else out[:6]
+
+
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
     if getattr(pc, "use_feat_bank", False):
-        raise NotImplementedError("use_feat_bank=True is not implemented (False in every GScream config)")
+        return _generate_with_feature_bank(viewpoint_camera, pc, visible_mask, is_training)
     # gaussian_renderer/__init__.py:20-28: `x[visible_mask]` for four tensors.  Here the mask becomes a row list once
     # and the kernels read (and, in the backward, write) the model-sized tensors through it; no mask = every row.
     vis_idx = None if visible_mask is None else torch.nonzero(visible_mask, as_tuple=False).view(-1).int()

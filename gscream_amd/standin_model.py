@@ -13,11 +13,11 @@ class Camera:
 class Model(nn.Module):
     """What generate_neural_gaussians reads from GaussianModel."""
 
-    def __init__(self, N, K=10, feat_dim=32, seed=0, dtype=torch.float64, spread=3.0):
+    def __init__(self, N, K=10, feat_dim=32, seed=0, dtype=torch.float64, spread=3.0, use_feat_bank=False):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
-        self.n_offsets, self.use_feat_bank = K, False
+        self.n_offsets, self.use_feat_bank = K, bool(use_feat_bank)
         self._anchor = nn.Parameter((r(N, 3) * spread).to(dtype))
         self._anchor_feat = nn.Parameter((r(N, feat_dim) * 0.5).to(dtype))
         self._offset = nn.Parameter((r(N, K, 3) * 0.3).to(dtype))
@@ -30,6 +30,9 @@ class Model(nn.Module):
         self.mlp_cov = mk(7 * K, None)                   # :133-137
         self.mlp_color = mk(3 * K, nn.Sigmoid())         # :139-144
         self.rotation_activation = torch.nn.functional.normalize  # :54
+        if use_feat_bank:                                # :107-113 (view-adaptive feature bank, off in every shipped config)
+            self.mlp_feature_bank = nn.Sequential(nn.Linear(3 + 1, feat_dim), nn.ReLU(True), nn.Linear(feat_dim, 3),
+                                                  nn.Softmax(dim=1)).to(dtype)
 
     get_anchor = property(lambda self: self._anchor)
     get_scaling = property(lambda self: 1.0 * torch.exp(self._scaling))  # :241-242
@@ -37,3 +40,4 @@ class Model(nn.Module):
     get_uncertainty_mlp = property(lambda self: self.mlp_uncertainty)
     get_cov_mlp = property(lambda self: self.mlp_cov)
     get_color_mlp = property(lambda self: self.mlp_color)
+    get_featurebank_mlp = property(lambda self: self.mlp_feature_bank)  # :245-246

@@ -1,12 +1,13 @@
 """CPU oracle for the neural-Gaussian decode.  TEST INFRASTRUCTURE ONLY.
 
-`generate_neural_gaussians` below restates gaussian_renderer/__init__.py:18-102 line by line in plain torch (the
-feature-bank branch :39-49 omitted: use_feat_bank is False in every GScream config); `make_model` builds a stand-in for
-the parts of scene/gaussian_model.py the function touches (MLPs as :118-144, activations :43-54).
+`generate_neural_gaussians` below restates gaussian_renderer/__init__.py:18-102 line by line in plain torch (including
+the feature-bank branch :39-49, off in every GScream config); the stand-in for the parts of scene/gaussian_model.py the
+function touches (MLPs as :118-144, activations :43-54) lives in gscream_amd/standin_model.py.
 
-PARITY UNPINNED: the reference module cannot be imported here (it imports einops' `repeat` -- present -- but also
-scene.gaussian_model, which needs simple_knn / plyfile / torch_scatter builds that are absent), and the reference
-ships no vectors for it; the restatement follows the cited lines one to one."""
+PINNED against the reference's own code: tests/golden/make_reference_vectors2.py imports the reference's
+gaussian_renderer.generate_neural_gaussians and GaussianModel.training_statis in the build container (stubs that raise
+on use for the modules those functions never touch) and runs them on the same stand-in; tests/golden/ref_decode.npz /
+ref_stats.npz hold what they computed (outputs, mask, all parameter gradients), tests/test_reference_vectors2.py compares."""
 import os
 import sys
 
@@ -26,6 +27,13 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     ob_view = anchor - viewpoint_camera.camera_center                     # :31
     ob_dist = ob_view.norm(dim=1, keepdim=True)                           # :33
     ob_view = ob_view / ob_dist                                           # :35
+    if getattr(pc, "use_feat_bank", False):                               # :39-49 view-adaptive feature bank
+        cat_view = torch.cat([ob_view, ob_dist], dim=1)
+        bank_weight = pc.get_featurebank_mlp(cat_view).unsqueeze(dim=1)   # [n, 1, 3]
+        feat = feat.unsqueeze(dim=-1)
+        feat = (feat[:, ::4, :1].repeat([1, 4, 1]) * bank_weight[:, :, :1] + feat[:, ::2, :1].repeat([1, 2, 1]) * bank_weight[:, :, 1:2]
+                + feat[:, ::1, :1] * bank_weight[:, :, 2:])
+        feat = feat.squeeze(dim=-1)
     cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)           # :52
     neural_opacity = pc.get_opacity_mlp(cat_local_view)                   # :55
     neural_opacity = neural_opacity.reshape([-1, 1])                      # :58

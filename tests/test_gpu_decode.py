@@ -73,10 +73,6 @@ def test_eval_path_empty_and_errors():
     assert torch.allclose(out[5].norm(dim=1), torch.ones_like(out[5][:, 0]), atol=1e-5)
     none = generate_neural_gaussians(cam_d, dut, torch.zeros(500, dtype=torch.bool, device="cuda"), True)
     assert none[0].shape == (0, 3) and none[6].shape == (0, 1) and none[7].shape == (0,)
-    dut.use_feat_bank = True
-    with pytest.raises(NotImplementedError):
-        generate_neural_gaussians(cam_d, dut, None, False)
-    dut.use_feat_bank = False
     with pytest.raises(RuntimeError):
         generate_neural_gaussians(DO.Camera(torch.tensor(CAM)), copy.deepcopy(ref).float(), None, False)
 

@@ -1,0 +1,42 @@
+"""The parity build (libgsraster_precise.so: the reference's own falloff expression with libm expf, IEEE division and no
+FMA contraction in the blend loops) against the oracle, next to the shipped build: demonstrates that the shipped build's
+outliers are alpha = 1/255 / T = 1e-4 threshold flips caused by v_exp_f32 / v_rcp_f32 / the pre-scaled quadratic form,
+not arithmetic errors.  Both libraries are driven through the same C ABI (GSR_LIB selects the file)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(lib):
+    env = dict(os.environ)
+    env.pop("GSR_LIB", None)
+    if lib:
+        env["GSR_LIB"] = os.path.join(ROOT, "gscream_amd", lib)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "flip_report.py")], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_parity_build_has_no_outliers_and_shipped_build_only_threshold_flips(native_lib):
+    assert os.path.exists(os.path.join(ROOT, "gscream_amd", "libgsraster_precise.so")), "build() makes the parity build"
+    precise, shipped = _run("libgsraster_precise.so"), _run(None)
+    assert precise["lib"] == "libgsraster_precise.so" and shipped["lib"] == "libgsraster.so"
+    print("\ncase            | shipped: px>1e-4  grad>1e-3 (max rel) | parity build: px>1e-4  grad>1e-3 (max rel)")
+    for k in sorted(shipped["cases"]):
+        a, b = shipped["cases"][k], precise["cases"][k]
+        print(f"{k:15s} | {a['pixels_gt_1e-4']:6d} {a['grad_gt_1e-3']:8d} ({a['grad_max_rel']:.2e})          | "
+              f"{b['pixels_gt_1e-4']:6d} {b['grad_gt_1e-3']:8d} ({b['grad_max_rel']:.2e})")
+    for k, b in precise["cases"].items():
+        assert b["radii_equal"], k
+        assert b["pixels_gt_1e-4"] == 0, (k, b)                 # every pixel within the north-star's 1e-4
+        assert b["grad_gt_1e-3"] == 0, (k, b)                   # every gradient element within 1e-3 rel
+    for k, a in shipped["cases"].items():
+        assert a["radii_equal"], k
+        assert a["pixels_gt_1e-4"] <= max(2, 2e-5 * a["pixels"]), (k, a)
+        assert a["grad_gt_1e-3"] <= max(8, 2e-4 * a["grad_elems"]) and a["grad_max_rel"] <= 0.05, (k, a)

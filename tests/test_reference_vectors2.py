@@ -1,0 +1,324 @@
+"""Vectors computed by RUNNING the reference's own Python in the build container (tests/golden/make_reference_vectors2.py):
+utils/loss_utils.py, gaussian_renderer.generate_neural_gaussians, GaussianModel.training_statis,
+utils/general_utils.build_rotation / build_scaling_rotation, and the reference rasterizer wrapper with a recording `_C`.
+CPU tests pin the oracles (and the host mirror's plumbing) to them; `-m gpu` tests pin the HIP kernels to them directly."""
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers as Hh  # noqa: E402
+from golden import make_reference_vectors2 as MR  # noqa: E402
+from gscream_amd import synthetic as S  # noqa: E402
+from oracle import decode_oracle as DO  # noqa: E402
+from oracle import loss_oracle as LO  # noqa: E402
+
+G = lambda name: np.load(os.path.join(ROOT, "tests", "golden", name))
+LOSS, DEC, STATS, ROT, WRAP = G("ref_loss.npz"), G("ref_decode.npz"), G("ref_stats.npz"), G("ref_rotation.npz"), G("ref_wrapper.npz")
+t64 = lambda a: torch.from_numpy(np.asarray(a)).double()
+
+
+def _sample(g, tag):
+    return np.asarray(g).reshape(-1)[::MR.GRAD_SAMPLE_STRIDE[tag]]
+
+
+# ---- loss oracle vs utils/loss_utils.py -------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s", "m", "l"])
+def test_loss_oracle_matches_reference_loss_utils(tag):
+    H, W = MR.LOSS_SIZES[tag]
+    img, gt, w = MR.loss_inputs(100 + H, 3, H, W)
+    for name, fn, args in (("l1", LO.l1_loss, ()), ("l1m", LO.l1_loss_masked, (t64(w),)), ("ssim", LO.ssim, ()), ("ssimm", LO.ssim_masked, (t64(w),))):
+        x = t64(img).requires_grad_(True)
+        v = fn(x, t64(gt), *args)
+        v.backward()
+        assert abs(v.item() - float(LOSS[f"{tag}_{name}"])) < 1e-12, name
+        g = x.grad.numpy()
+        assert np.allclose(_sample(g, tag), LOSS[f"{tag}_{name}_g"], rtol=1e-6, atol=1e-12), name
+        assert abs(g.sum() - float(LOSS[f"{tag}_{name}_gsum"])) < 1e-10 and abs(np.sqrt((g * g).sum()) - float(LOSS[f"{tag}_{name}_gnorm"])) < 1e-12
+    # train.py:538-540: reference view, lr 1, lr_fg 20 == two calls of the oracle's composition
+    x = t64(img).requires_grad_(True)
+    loss = LO.rgb_loss(x, t64(gt), None, 0.2, 1.0) + LO.rgb_loss(x, t64(gt), t64(w), 0.2, 19.0)
+    loss.backward()
+    assert abs(loss.item() - float(LOSS[f"{tag}_rgb_refview"])) < 1e-10
+    assert np.allclose(_sample(x.grad.numpy(), tag), LOSS[f"{tag}_rgb_refview_g"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["s", "m", "l"])
+@pytest.mark.parametrize("view", ["ref", "other"])
+def test_depth_oracle_matches_reference_train_terms(tag, view):
+    H, W = MR.LOSS_SIZES[tag]
+    d, y, mk, fg = MR.depth_inputs(200 + H, H, W)
+    if view == "ref":   # train.py:548-561 with refer_depth_lr 1, refer_depth_lr_fg 100, smooth 1 (scripts/run.py)
+        loss, s, sh, g = LO.depth_value_and_grad(d, y, mk, None, None, 1.0, 1.0, fg_mask=fg, lambda_fg=99.0)
+    else:               # :563-573 with other_depth_lr 0.1, smooth 0.1
+        loss, s, sh, g = LO.depth_value_and_grad(d, y, mk, mk, mk, 0.1, 0.1)
+    assert abs(loss - float(LOSS[f"{tag}_depth_{view}"])) < 1e-10
+    assert abs(s - abs(float(LOSS[f"{tag}_depth_{view}_scale_signed"]))) < 1e-12 and abs(sh - float(LOSS[f"{tag}_depth_{view}_shift"])) < 1e-12
+    assert np.allclose(_sample(g, tag), LOSS[f"{tag}_depth_{view}_g"], rtol=1e-5, atol=1e-11)
+
+
+# ---- decode oracle vs gaussian_renderer.generate_neural_gaussians ---------------------------------------------------
+@pytest.mark.parametrize("name", sorted(MR.DECODE_CASES))
+def test_decode_oracle_matches_reference_generate_neural_gaussians(name):
+    c = MR.DECODE_CASES[name]
+    m, cam, vis = MR.decode_case_inputs(c)
+    res = DO.generate_neural_gaussians(cam, m, vis, is_training=True)
+    for k, v in zip(MR.DECODE_OUT, res[:6]):
+        assert np.array_equal(v.detach().numpy(), DEC[f"{name}_{k}"]), k   # same torch ops on the same inputs: bit-equal
+    assert np.array_equal(res[6].detach().numpy(), DEC[f"{name}_neural_opacity"]) and np.array_equal(res[7].numpy(), DEC[f"{name}_mask"])
+    loss = MR.decode_loss(res[:6], c["seed"])
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    for k, g in zip(params, grads):
+        ref = DEC[f"{name}_grad_{k}"]
+        assert np.allclose(np.zeros_like(ref) if g is None else g.numpy(), ref, rtol=1e-9, atol=1e-12), k
+    assert len(DO.generate_neural_gaussians(cam, m, vis, is_training=False)) == 6
+
+
+def test_stats_oracle_matches_reference_training_statis():
+    anchor_vis, opacity, sel, uf, grad, acc0 = MR.stats_inputs()
+    self = types.SimpleNamespace(n_offsets=10, **{k: torch.from_numpy(v.copy()) for k, v in acc0.items()})
+    vpt = types.SimpleNamespace(grad=torch.from_numpy(grad))
+    for _ in range(2):
+        DO.training_statis(self, vpt, torch.from_numpy(opacity), torch.from_numpy(uf), torch.from_numpy(sel), torch.from_numpy(anchor_vis))
+    for k in acc0:
+        assert np.array_equal(getattr(self, k).numpy(), STATS[k]), k
+
+
+# ---- Sigma_3D convention vs build_scaling_rotation -------------------------------------------------------------------
+def _cov_scene():
+    P = ROT["quat"].shape[0]
+    s = S.scene_config1(seed=9, P=P, W=96, H=64)
+    s["rotations"] = ROT["quat_normalised"].astype(np.float32)   # callers normalise (gaussian_renderer :91); computeCov3D does not
+    s["scales"] = ROT["scale"].astype(np.float32)
+    return s
+
+
+def test_oracle_cov3d_matches_reference_build_scaling_rotation():
+    """computeCov3D (forward.cu:120-154) must give Sigma = L L^T of general_utils.build_scaling_rotation, stored as the six
+    upper-triangle entries [xx, xy, xz, yy, yz, zz] of strip_symmetric (:140-151)."""
+    st = Hh.oracle_forward(_cov_scene())
+    assert np.allclose(st["cov3D"].reshape(-1, 6), ROT["cov6"], rtol=2e-5, atol=1e-9)
+    # and build_rotation's matrix is the textbook rotation of the normalised quaternion (r, x, y, z)
+    q = ROT["quat_normalised"].astype(np.float64)
+    r, x, y, z = q.T
+    R00, R01 = 1 - 2 * (y * y + z * z), 2 * (x * y - r * z)
+    assert np.allclose(ROT["R"][:, 0, 0], R00, atol=1e-6) and np.allclose(ROT["R"][:, 0, 1], R01, atol=1e-6)
+
+
+# ---- wrapper plumbing vs the reference's diff_gaussian_rasterization/__init__.py -------------------------------------
+FWD_ROLE = {"background": "bg", "colors": "colors_precomp", "opacity": "opacities", "uncertainty": "uncertainties",
+            "cov3D_precomp": "cov3Ds_precomp", "tan_fovx": "tanfovx", "tan_fovy": "tanfovy", "degree": "sh_degree"}
+BWD_ROLE = dict(FWD_ROLE, dL_dout_color="grad_out_color", dL_dout_depth="grad_out_depth", dL_dout_uncertainty="grad_out_uncertainty",
+                R="num_rendered", imageBuffer="imgBuffer")
+
+
+def _slots_match(fn, recorded, role):
+    ours = [role.get(p, p) for p in inspect.signature(fn).parameters]
+    assert len(ours) == len(recorded)
+    for a, b in zip(ours, recorded):
+        assert b == a or b == "<empty>", (a, b)    # <empty>: an absent optional input travelled as an empty tensor
+    return ours
+
+
+def test_C_stub_takes_the_argument_slots_the_reference_wrapper_fills():
+    import diff_gaussian_rasterization._C as C
+    for variant in ("colors_scales", "sh_cov"):
+        f = _slots_match(C.rasterize_gaussians, list(WRAP[f"{variant}_forward_slots"]), FWD_ROLE)
+        b = _slots_match(C.rasterize_gaussians_backward, list(WRAP[f"{variant}_backward_slots"]), BWD_ROLE)
+        assert len(f) == 20 and len(b) == 23
+    # across the two call variants every optional slot was seen filled once
+    for kind, role, fn in (("forward", FWD_ROLE, C.rasterize_gaussians), ("backward", BWD_ROLE, C.rasterize_gaussians_backward)):
+        ours = [role.get(p, p) for p in inspect.signature(fn).parameters]
+        seen = [a if a != "<empty>" else b for a, b in zip(WRAP[f"colors_scales_{kind}_slots"], WRAP[f"sh_cov_{kind}_slots"])]
+        assert seen == ours, kind
+    filt_role = dict(FWD_ROLE)
+    _slots_match(C.rasterize_aussians_filter, list(WRAP["visible_filter_slots"]), filt_role)
+    _slots_match(C.rasterize_aussians_filter_position2D, list(WRAP["position2D_filter_slots"]), filt_role)
+    assert list(WRAP["mark_visible_slots"]) == ["positions", "viewmatrix", "projmatrix"] and len(inspect.signature(C.mark_visible).parameters) == 3
+
+
+def test_host_mirror_routes_gradients_and_errors_like_the_reference_wrapper(monkeypatch):
+    from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from gscream_amd import rasterizer as RZ
+    assert list(GaussianRasterizationSettings._fields) == list(WRAP["settings_fields"])
+    P, H, W = 5, 33, 47
+    names = list(WRAP["native_backward_returns"])
+    shapes = dict(dL_dmeans2D=(P, 3), dL_dcolors=(P, 3), dL_dopacity=(P, 1), dL_duncertainty=(P, 1), dL_dmeans3D=(P, 3), dL_dcov3D=(P, 6),
+                  dL_dsh=(P, 4, 3), dL_dscales=(P, 3), dL_drotations=(P, 4))
+
+    def fake_forward(means3D, sh, colors_precomp, opacities, uncertainties, scales, rotations, cov3Ds_precomp, rs):
+        e = torch.empty(0, dtype=torch.uint8)
+        return 1234, torch.zeros(3, H, W), torch.zeros(1, H, W), torch.zeros(1, H, W), torch.ones(P, dtype=torch.int32), e, e, e, 1234
+
+    def fake_backward(*a):
+        return tuple(torch.full(shapes[n], float(i + 1)) for i, n in enumerate(names))  # the native return order of the reference
+    monkeypatch.setattr(RZ, "_forward_native", fake_forward)
+    monkeypatch.setattr(RZ, "_backward_native", fake_backward)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=0.51, tanfovy=0.37, bg=torch.zeros(3), scale_modifier=0.77,
+                                       viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=2, campos=torch.zeros(3), prefiltered=True, debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    r = lambda *s: torch.rand(*s).requires_grad_(True)
+    for variant in ("colors_scales", "sh_cov"):
+        inp = dict(means3D=r(P, 3), means2D=r(P, 3), opacities=r(P, 1), uncertainties=r(P, 1))
+        inp.update(dict(colors_precomp=r(P, 3), scales=r(P, 3), rotations=r(P, 4)) if variant == "colors_scales" else dict(shs=r(P, 4, 3), cov3D_precomp=r(P, 6)))
+        out = rast(**inp)
+        assert len(out) == 4
+        torch.autograd.backward(list(out[:3]), [torch.ones_like(o) for o in out[:3]])
+        route = {k: (0 if v.grad is None else int(v.grad.reshape(-1)[0])) for k, v in inp.items()}
+        assert list(route) == list(WRAP[f"{variant}_grad_route_inputs"])
+        assert [route[k] for k in route] == list(WRAP[f"{variant}_grad_route_native_index"]), variant
+    errs = []
+    t = lambda *s: torch.rand(*s)
+    for kw in (dict(), dict(shs=t(P, 4, 3), colors_precomp=t(P, 3)), dict(colors_precomp=t(P, 3)), dict(colors_precomp=t(P, 3), scales=t(P, 3), rotations=t(P, 4), cov3D_precomp=t(P, 6))):
+        with pytest.raises(Exception) as ei:
+            rast(t(P, 3), t(P, 3), t(P, 1), t(P, 1), **kw)
+        errs.append(str(ei.value))
+    assert errs == list(WRAP["forward_errors"])
+
+
+# =====================================================================================================================
+# GPU: the HIP kernels against the reference-run vectors directly
+# =====================================================================================================================
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["s", "m", "l"])
+def test_hip_losses_match_reference_loss_utils(tag):
+    from gscream_amd import loss_utils as L
+    H, W = MR.LOSS_SIZES[tag]
+    img, gt, w = MR.loss_inputs(100 + H, 3, H, W)
+    c = lambda a: torch.from_numpy(a).cuda()
+    for name, fn, args in (("l1", L.l1_loss, ()), ("l1m", L.l1_loss_masked, (c(w),)), ("ssim", L.ssim, ()), ("ssimm", L.ssim_masked, (c(w),))):
+        x = c(img).requires_grad_(True)
+        v = fn(x, c(gt), *args)
+        v.backward()
+        assert abs(float(v.detach()) - float(LOSS[f"{tag}_{name}"])) < 2e-6, name          # fp32 kernel vs the reference in fp64
+        ref = LOSS[f"{tag}_{name}_g"]
+        got = _sample(x.grad.cpu().numpy(), tag)
+        if name.startswith("l1"):   # sign(d): a |d| within fp32 rounding of zero may take the other sign
+            assert (np.abs(got - ref) > 1e-4 * np.abs(ref).max()).mean() < 1e-3, name
+        else:
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+    x = c(img).requires_grad_(True)
+    loss = L.rgb_loss(x, c(gt), None, 0.2, 1.0) + L.rgb_loss(x, c(gt), c(w), 0.2, 19.0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(LOSS[f"{tag}_rgb_refview"])) < 2e-5
+    ref = LOSS[f"{tag}_rgb_refview_g"]
+    assert (np.abs(_sample(x.grad.cpu().numpy(), tag) - ref) > 1e-4 * np.abs(ref).max()).mean() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["s", "m", "l"])
+@pytest.mark.parametrize("view", ["ref", "other"])
+def test_hip_depth_loss_matches_reference_train_terms(tag, view):
+    from gscream_amd import loss_utils as L
+    H, W = MR.LOSS_SIZES[tag]
+    d, y, mk, fg = MR.depth_inputs(200 + H, H, W)
+    c = lambda a: torch.from_numpy(a).cuda()
+    x = c(d).requires_grad_(True)
+    if view == "ref":
+        loss, parts = L.depth_loss(x, c(y), c(mk), None, None, 1.0, 1.0, return_parts=True, fg_mask=c(fg), lambda_fg=99.0)
+    else:
+        loss, parts = L.depth_loss(x, c(y), c(mk), c(mk), c(mk), 0.1, 0.1, return_parts=True)
+    loss.backward()
+    ref = float(LOSS[f"{tag}_depth_{view}"])
+    assert abs(float(loss.detach()) - ref) < 5e-6 * max(1.0, abs(ref))
+    assert abs(float(parts[3]) - abs(float(LOSS[f"{tag}_depth_{view}_scale_signed"]))) < 5e-6
+    assert abs(float(parts[4]) - float(LOSS[f"{tag}_depth_{view}_shift"])) < 2e-5
+    rg = LOSS[f"{tag}_depth_{view}_g"]
+    assert (np.abs(_sample(x.grad.cpu().numpy(), tag) - rg) > 1e-4 * np.abs(rg).max()).mean() <= 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(MR.DECODE_CASES))
+def test_hip_decode_matches_reference_generate_neural_gaussians(name):
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    from gscream_amd import standin_model as SM
+    c = MR.DECODE_CASES[name]
+    m, cam, vis = MR.decode_case_inputs(c)
+    dut = m.float().cuda()
+    camd = SM.Camera(cam.camera_center.float().cuda())
+    visd = None if vis is None else vis.cuda()
+    res = generate_neural_gaussians(camd, dut, visd, True)
+    nop_ref, mask_ref = DEC[f"{name}_neural_opacity"], DEC[f"{name}_mask"]
+    sure = np.abs(nop_ref.reshape(-1)) > 1e-5                       # an opacity within rounding of 0 may flip the mask
+    mask = res[7].cpu().numpy()
+    assert np.array_equal(mask[sure], mask_ref[sure])
+    if not np.array_equal(mask, mask_ref):
+        pytest.skip("an opacity within fp32 rounding of zero flipped the mask on this case; rows are not comparable one to one")
+    for k, v in zip(MR.DECODE_OUT, res[:6]):
+        ref = DEC[f"{name}_{k}"]
+        assert np.abs(v.detach().cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+    loss = MR.decode_loss([r.double() for r in res[:6]], c["seed"])
+    params = dict(dut.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    for k, g in zip(params, grads):
+        ref = DEC[f"{name}_grad_{k}"]
+        got = np.zeros_like(ref) if g is None else g.cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12), k
+
+
+@pytest.mark.gpu
+def test_hip_training_stats_match_reference_training_statis():
+    from gscream_amd.densify_stats import training_statis
+    anchor_vis, opacity, sel, uf, grad, acc0 = MR.stats_inputs()
+    self = types.SimpleNamespace(n_offsets=10, **{k: torch.from_numpy(v.copy()).cuda() for k, v in acc0.items()})
+    vpt = types.SimpleNamespace(grad=torch.from_numpy(grad).cuda())
+    for _ in range(2):
+        training_statis(self, vpt, torch.from_numpy(opacity).cuda(), torch.from_numpy(uf).cuda(), torch.from_numpy(sel).cuda(), torch.from_numpy(anchor_vis).cuda())
+    for k in acc0:
+        assert np.allclose(getattr(self, k).cpu().numpy(), STATS[k], rtol=1e-6, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_hip_cov3d_matches_reference_build_scaling_rotation():
+    """Rendering from scales + rotations must equal rendering from the reference's own Sigma_3D handed in as cov3D_precomp
+    (the kernel does not export its covariance; radii and images depend on every entry of it)."""
+    s = _cov_scene()
+    a = Hh.hip_run(s)
+    b_scene = dict(s)
+    b_scene["cov3D_precomp"] = ROT["cov6"].astype(np.float32)
+    b = Hh.hip_run(b_scene)
+    assert (a["radii"] > 0).sum() > 20 and np.array_equal(a["radii"], b["radii"])
+    for k in ("out_color", "out_depth", "out_unc"):
+        assert np.abs(a[k] - b[k]).max() < 2e-5, k
+
+
+@pytest.mark.gpu
+def test_C_stub_under_the_reference_argument_order_equals_the_class_api():
+    """The five `_C` entry points, called positionally in the slot order recorded from the reference wrapper."""
+    import diff_gaussian_rasterization._C as C
+    s = S.scene_config1(seed=21, P=1500, W=112, H=80)
+    grads = S.upstream_grads(22, s["W"], s["H"])
+    ref = Hh.hip_run(s, grads)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    e = torch.Tensor([])
+    vals = dict(bg=c(s["bg"]), means3D=c(s["means3D"]), colors_precomp=c(s["colors"]), opacities=c(s["opacities"]), uncertainties=c(s["uncertainties"]),
+                scales=c(s["scales"]), rotations=c(s["rotations"]), scale_modifier=1.0, viewmatrix=c(s["viewmatrix"]), projmatrix=c(s["projmatrix"]),
+                tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], image_height=s["H"], image_width=s["W"], sh_degree=1, campos=c(s["campos"]),
+                prefiltered=False, debug=False)
+    args = [vals.get(str(k), e) for k in WRAP["colors_scales_forward_slots"]]
+    R, color, depth, unc, radii, geom, binning, img = C.rasterize_gaussians(*args)
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    for k, v in (("out_color", color), ("out_depth", depth), ("out_unc", unc)):
+        assert np.array_equal(v.cpu().numpy(), ref[k]), k
+    vals.update(radii=radii, geomBuffer=geom, binningBuffer=binning, imgBuffer=img, num_rendered=R, grad_out_color=c(grads[0]),
+                grad_out_depth=c(grads[1]), grad_out_uncertainty=c(grads[2]))
+    out = C.rasterize_gaussians_backward(*[vals.get(str(k), e) for k in WRAP["colors_scales_backward_slots"]])
+    got = {n: o.cpu().numpy() for n, o in zip(WRAP["native_backward_returns"], out)}
+    got["dL_dmeans2D"], got["dL_dcolors"] = got["dL_dmeans2D"], got["dL_dcolors"]
+    Hh.assert_grads_nearly_equal(got, ref, context="_C stub vs class API")
+    assert (got["dL_dcov3D"] == 0).all() and got["dL_dsh"].shape == (1500, 0, 3)
+    fvals = dict(vals)
+    r1 = C.rasterize_aussians_filter(*[fvals.get(str(k), e) for k in WRAP["visible_filter_slots"]])
+    r2, px, py = C.rasterize_aussians_filter_position2D(*[fvals.get(str(k), e) for k in WRAP["position2D_filter_slots"]])
+    assert np.array_equal(r1.cpu().numpy(), ref["radii"]) and np.array_equal(r2.cpu().numpy(), ref["radii"])
+    assert (px[r2 > 0] > -50).all() and (px[r2 == 0] == 0).all() and py.shape == px.shape
+    vis = C.mark_visible(vals["means3D"], vals["viewmatrix"], vals["projmatrix"])
+    assert vis.dtype == torch.bool and bool((vis | (r1 == 0)).all())

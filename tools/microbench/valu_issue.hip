@@ -39,7 +39,7 @@
 #define CNDMASK(i) "v_cndmask_b32 %" #i ", %" #i ", %16, vcc\n"
 #define CMP(i)    "v_cmp_gt_f32 vcc, %" #i ", %16\n"
 #define MAXF(i)   "v_max_f32 %" #i ", %" #i ", %16\n"
-#define SWAP32(i) "v_permlane32_swap %" #i ", %" #i "\n"
+#define SWAP32(i) "v_permlane32_swap_b32 %" #i ", %" #i "\n"
 #define CVT(i)    "v_cvt_f32_i32 %" #i ", %" #i "\n"
 #define FMADEP(i) "v_fma_f32 %0, %0, %16, %17\n"
 #define PKFMADEP(i) "v_pk_fma_f32 %0, %0, %18, %19\n"
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_issue(uint64_t* __restrict__ out, float
         if (KIND == K_CNDMASK) BODY(X8(STREAM8(CNDMASK)));
         if (KIND == K_CMP) BODY(X8(STREAM8(CMP)));
         if (KIND == K_MAX) BODY(X8(STREAM8(MAXF)));
-        if (KIND == K_SWAP32) BODY(X8("v_permlane32_swap %0, %1\nv_permlane32_swap %2, %3\nv_permlane32_swap %4, %5\nv_permlane32_swap %6, %7\n"
-                                      "v_permlane32_swap %1, %2\nv_permlane32_swap %3, %4\nv_permlane32_swap %5, %6\nv_permlane32_swap %7, %0\n"));
+        if (KIND == K_SWAP32) BODY(X8("v_permlane32_swap_b32 %0, %1\nv_permlane32_swap_b32 %2, %3\nv_permlane32_swap_b32 %4, %5\nv_permlane32_swap_b32 %6, %7\n"
+                                      "v_permlane32_swap_b32 %1, %2\nv_permlane32_swap_b32 %3, %4\nv_permlane32_swap_b32 %5, %6\nv_permlane32_swap_b32 %7, %0\n"));
         if (KIND == K_CVT) BODY(X8(STREAM8(CVT)));
         if (KIND == K_FMADEP) BODY(X8(STREAM8(FMADEP)));
         if (KIND == K_PKFMADEP) BODY(X8("v_pk_fma_f32 %8, %8, %18, %19\nv_pk_fma_f32 %8, %8, %18, %19\nv_pk_fma_f32 %8, %8, %18, %19\nv_pk_fma_f32 %8, %8, %18, %19\n"

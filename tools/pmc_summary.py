@@ -39,6 +39,11 @@ def load(db):
     return out
 
 
+def launches_of(tot, stage):
+    """dispatch count of the stage's most-launched kernel in the SQ_INSTS_VALU pass"""
+    return max((v["SQ_INSTS_VALU"][1] for k, v in tot.items() if STAGE_OF.get(k) == stage and "SQ_INSTS_VALU" in v), default=0)
+
+
 def main():
     d, workload = sys.argv[1], sys.argv[2]
     res = collections.defaultdict(dict)
@@ -73,6 +78,13 @@ def main():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")
     cur = json.load(open(path)) if os.path.exists(path) else {}
     cur[workload] = {k: round(v) for k, v in traffic.items()}
+    # wave-level VALU instructions per launch of each stage (bench.py: roofline.valu)
+    insts = collections.defaultdict(float)
+    for k, v in tot.items():
+        st = STAGE_OF.get(k)
+        if st and "SQ_INSTS_VALU" in v and launches[st]["FETCH_SIZE"]:
+            insts[st] += v["SQ_INSTS_VALU"][0] / max(v["SQ_INSTS_VALU"][1], 1) * (v["SQ_INSTS_VALU"][1] / max(launches_of(tot, st), 1))
+    cur[workload]["_insts_valu"] = {k: round(v) for k, v in insts.items()}
     json.dump(cur, open(path, "w"), indent=1)
 
 
