@@ -38,6 +38,7 @@
 //   * Scheduling (measured with the `make trace` build, tools/wave_trace.py): nearly all wavefronts of a launch are
 //     resident from the start, so a launch lasts as long as its most loaded SIMD.  Hence independent quadrant waves in
 //     the forward and uniform depth-segment tasks, several per wavefront slot, in the backward.
+#include <stdlib.h>
 #include "gsr_math.h"
 
 // Fast-math knobs of the blend inner loops.  Default: exp via v_exp_f32 (the records hold the quadratic form
@@ -81,6 +82,10 @@ extern "C" int gsr_debug_trace(void* host_dst, size_t bytes)
 #define GSR_TRACE_END(NW)
 #define GSR_TRACE_END_AT(NW, BASE)
 #endif
+
+// Lane selects on wave-uniform 64-bit masks (compares write SGPR pairs, the logic between them is scalar).
+__device__ __forceinline__ float gsr_sel(unsigned long long m, float if_set, float if_clear) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : if_clear; }
+__device__ __forceinline__ float gsr_sel0(unsigned long long m, float if_set) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : 0.0f; }
 
 __device__ __forceinline__ int gsr_tile_of_block(int b, int T)
 {
@@ -178,6 +183,12 @@ __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const floa
 // run on the same XCD).
 // ---------------------------------------------------------------------------------------------
 #define GSR_FWB 64
+// Dynamic LDS requested (and never touched) per forward workgroup: it caps how many quadrant waves are resident per CU, so
+// that the rest of the 4T workgroups are handed out as earlier ones finish (the dispatcher then balances the SIMDs; with
+// every wave resident from the start a launch lasts as long as its most loaded SIMD).  Experiment knob: GSR_FWD_LDS_PAD.
+#ifndef GSR_FWD_LDS_PAD
+#define GSR_FWD_LDS_PAD 0
+#endif
 typedef float gsr_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gsr_f2 gsr_splat(float v) { gsr_f2 r = {v, v}; return r; }
 __device__ __forceinline__ gsr_f2 gsr_fma2(gsr_f2 a, gsr_f2 b, gsr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -307,25 +318,38 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 #endif
             const gsr_f2 G = {gsr_gauss1(power.x), gsr_gauss1(power.y)};
             const gsr_f2 al = OP * G;
-            const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
-            const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
-            const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
-            auto blend = [&](const unsigned long long okm, const float al1, const int j, const float feat) {
+            // alpha >= 1/255 is tested on the unclamped product (0.99 > 1/255: same truth value); the clamp of
+            // forward.cu:531 is applied only to instances that blend
+            const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
+            const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
+            auto blend = [&](const unsigned long long okm, const float alu, const int j, const float feat) {
+                const float al1 = __builtin_amdgcn_fmed3f(alu, 0.99f, -3.0e38f);  // = min(0.99, alu), one instruction (no NaN canonicalisation in front)
                 const float test_T = Tr * (1.0f - al1);
                 const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
                 donem |= stopm;
-                const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm & ~stopm);
-                const float w = ok ? al1 * Tr : 0.0f;
+                const unsigned long long okf = okm & ~stopm;
+#ifdef GSR_FWD_EXEC_MASK
+                if (__builtin_amdgcn_inverse_ballot_w64(okf)) {  // EXEC = the pixels that blend: no selects
+                    const float w = al1 * Tr;
+                    const float4 C = sC[j];
+                    C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
+                    Dp += C.w * w; Uf += feat * w;
+                    Tr = test_T;
+                    last = (uint32_t)(base + j + 1);
+                }
+#else
+                const float w = gsr_sel0(okf, al1 * Tr);
                 const float4 C = sC[j];
                 C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
                 Dp += C.w * w; Uf += feat * w;
-                Tr = ok ? test_T : Tr;
-                last = ok ? (uint32_t)(base + j + 1) : last;
+                Tr = gsr_sel(okf, test_T, Tr);
+                last = __float_as_uint(gsr_sel(okf, __uint_as_float((uint32_t)(base + j + 1)), __uint_as_float(last)));
+#endif
             };
             const unsigned long long okma = cma & ~donem;
-            if (okma != 0ull) blend(okma, alpha.x, __builtin_amdgcn_readfirstlane(__float_as_int(P3.x)), P3.z);
+            if (okma != 0ull) blend(okma, al.x, __builtin_amdgcn_readfirstlane(__float_as_int(P3.x)), P3.z);
             const unsigned long long okmb = cmb & ~donem;  // after a: pixels it finished no longer blend b
-            if (okmb != 0ull) blend(okmb, alpha.y, __builtin_amdgcn_readfirstlane(__float_as_int(P3.y)), P3.w);
+            if (okmb != 0ull) blend(okmb, al.y, __builtin_amdgcn_readfirstlane(__float_as_int(P3.y)), P3.w);
             P0 = N0; P1 = N1; P2 = N2; P3 = N3;
         }
         __syncthreads();
@@ -388,8 +412,11 @@ __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, 
     return n;
 }
 
+#ifndef GSR_BWD_WAVES
+#define GSR_BWD_WAVES 5
+#endif
 template <bool AUX>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))) gsr_blend_bwd_kernel(
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, GSR_BWD_WAVES))) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
@@ -541,9 +568,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
                     const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
                                                     __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
-                        const bool oka = __builtin_amdgcn_inverse_ballot_w64(okma), okb = __builtin_amdgcn_inverse_ballot_w64(okmb);
-                        const gsr_f2 ae = {oka ? alpha.x : 0.f, okb ? alpha.y : 0.f};
-                        const gsr_f2 Ge = {oka ? G.x : 0.f, okb ? G.y : 0.f};
+                        const gsr_f2 ae = {gsr_sel0(okma, alpha.x), gsr_sel0(okmb, alpha.y)};
+                        const gsr_f2 Ge = {gsr_sel0(okma, G.x), gsr_sel0(okmb, G.y)};
                         const float4 C = sC[j];
                         const gsr_f2 oma = 1.0f - ae;
                         const gsr_f2 rinv = {GSR_RCP(oma.x), GSR_RCP(oma.y)};
@@ -574,10 +600,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
                         } else {
                             s[3] = 0.f; s[4] = 0.f;
                         }
-                        const gsr_f2 gdx = g * dx, gdy = g * dy;
-                        const gsr_f2 mxx = gdx * dx, mxy = gdx * dy, myy = gdy * dy;
-                        s[5] = gdx.x + gdx.y; s[6] = gdy.x + gdy.y; s[7] = mxx.x + mxx.y; s[8] = mxy.x + mxy.y;
-                        s[9] = myy.x + myy.y; s[10] = g.x + g.y;
+                        // both pixels of a lane share dy: sum(g dy) = dy sum(g), sum(g dx dy) = dy sum(g dx), sum(g dy^2) = dy^2 sum(g)
+                        const gsr_f2 gdx = g * dx, mxx = gdx * dx;
+                        const float gs = g.x + g.y, sx = gdx.x + gdx.y;
+                        s[5] = sx; s[7] = mxx.x + mxx.y; s[10] = gs;
+                        s[6] = gs * dy; s[8] = sx * dy; s[9] = s[6] * dy;
                         // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly whose pair steps need no
                         // selects: within a DPP row the two bank-level steps (row_ror:4, row_ror:8) write the two
                         // halves of the destination with complementary bank masks (gsr_bank_reduce), the cross-row
@@ -603,7 +630,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5, 5))
                         }
                         x += gsr_dpp<0xB1>(x);
                         x += gsr_dpp<0x4E>(x);
-                        if (accfield >= 0) atomicAdd(acc + j * GSR_SLOT_FLOATS + accfield, x);
+                        if (accfield >= 0) atomicAdd(&acc[(uint32_t)j * GSR_SLOT_FLOATS + (uint32_t)accfield], x);  // 32-bit index math: no v_mad_u64_u32
                     }
                     j = jn; A = An; B = Bn;
                 }
@@ -645,7 +672,8 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
                                     float* out_feature, int capacity, int max_tile_count, bool only_flagged, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
+    static const int fwd_lds_pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : GSR_FWD_LDS_PAD;
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), fwd_lds_pad, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,
                        image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr);

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""How well do 'lanes = pixels' blend kernels use their lanes on the bench scene, and what would finer work units buy?
+CPU analysis on the oracle's forward state (sampled tiles): for every traversed (instance, pixel) pair that really blends
+(alpha >= 1/255, position < the pixel's n_contrib) count, per granularity G in {16x8 strip, 8x8 quadrant, 8x4, 4x4}:
+  pairs_G  = (instance, block) pairs with at least one blending pixel        (what a block-level compaction would walk)
+  util_G   = blending (instance, pixel) pairs / (pairs_G * pixels per block)  (lane utilisation of those iterations)
+  iters_4  = sum over groups of 4 sibling blocks of max(block list length)    (4 blocks per wavefront, one per DPP row)
+usage: python tools/lane_utilisation.py [ntiles]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as Hh  # noqa: E402
+from gscream_amd import synthetic as S  # noqa: E402
+
+
+def main():
+    ntiles = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    P, W, H = 1_000_000, 1008, 567
+    s = S.scene_slab(1, P, W, H)
+    st = Hh.oracle_forward(s, nthreads=os.cpu_count())
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    rng = np.random.default_rng(0)
+    tiles = rng.choice(gx * (gy - 1), size=ntiles, replace=False)  # full tiles only
+    m2, con, ncon = st["means2D"].reshape(-1, 2), st["conic_opacity"].reshape(-1, 4), st["n_contrib"]
+    grans = {"16x8": (16, 8), "8x8": (8, 8), "8x4": (8, 4), "4x4": (4, 4)}
+    tot_pairs = 0
+    acc = {k: dict(pairs=0, iters4=0) for k in grans}
+    trav = 0
+    for t in tiles:
+        tx, ty = t % gx, t // gx
+        a, b = st["ranges"][t]
+        ids = st["point_list"][a:b].astype(np.int64)
+        nc = ncon[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].astype(np.int64)   # [16,16]
+        depth = int(nc.max())
+        ids = ids[:depth]
+        trav += depth
+        xs, ys = np.arange(tx * 16, tx * 16 + 16, dtype=np.float32), np.arange(ty * 16, ty * 16 + 16, dtype=np.float32)
+        dx = m2[ids, 0][:, None, None] - xs[None, None, :]
+        dy = m2[ids, 1][:, None, None] - ys[None, :, None]
+        power = -0.5 * (con[ids, 0][:, None, None] * dx * dx + con[ids, 2][:, None, None] * dy * dy) - con[ids, 1][:, None, None] * dx * dy
+        alpha = np.minimum(0.99, con[ids, 3][:, None, None] * np.exp(power))
+        blend = (power <= 0) & (alpha >= 1 / 255) & (np.arange(depth)[:, None, None] < nc[None])   # [n,16,16]
+        tot_pairs += int(blend.sum())
+        for k, (bw, bh) in grans.items():
+            blk = blend.reshape(depth, 16 // bh, bh, 16 // bw, bw).any(axis=(2, 4))   # [n, by, bx]
+            cnt = blk.sum(0)                                                        # list length per block
+            acc[k]["pairs"] += int(cnt.sum())
+            flat = cnt.reshape(-1)
+            # groups of 4 sibling blocks (as laid out row-major): one wavefront
+            acc[k]["iters4"] += int(flat.reshape(-1, 4).max(1).sum()) if flat.size >= 4 else int(flat.max())
+    print(f"{ntiles} tiles, traversed instances per tile {trav / ntiles:.0f}, blending (instance, pixel) pairs per tile {tot_pairs / ntiles:.0f}")
+    for k, (bw, bh) in grans.items():
+        p = acc[k]["pairs"]
+        print(f"  {k:5s}: (instance, block) pairs per tile {p / ntiles:8.0f}   lane utilisation {tot_pairs / (p * bw * bh):.3f}   "
+              f"4-block wave iterations per tile {acc[k]['iters4'] / ntiles:8.0f}  (balance {p / 4 / max(acc[k]['iters4'], 1):.2f})")
+
+
+if __name__ == "__main__":
+    main()
