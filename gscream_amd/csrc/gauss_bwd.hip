@@ -99,7 +99,10 @@ __device__ __forceinline__ float3 gsr_sh_backward(int idx, int deg, int M, float
 #ifndef GSR_K7_BS
 #define GSR_K7_BS 64
 #endif
-__global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
+#ifndef GSR_K7_WAVES
+#define GSR_K7_WAVES 4  // minimum waves per SIMD the register allocation has to leave room for (3: 72 us, 4: 68 us, 5: spills, 109 us)
+#endif
+__global__ void __launch_bounds__(GSR_K7_BS, GSR_K7_WAVES) gsr_gauss_bwd_kernel(
     int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
@@ -153,15 +156,15 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
     // schemes give the same bits).  Wave-uniform choice from the slot counts.  (Costs registers: 3 instead of 4 waves
     // per SIMD; measured faster on every bench workload all the same: 75 -> 74, 100 -> 85, 218 -> 194 us, and 496 -> ~150
     // on a scene of large splats.)
-    __shared__ double accG[BS * 11];
+    // (the per-lane task sums of the spread scheme stay in registers, acc[k] for task k * 64 + lane; one transposition
+    // through LDS -- aliased onto `stage`, which is free by then -- hands every Gaussian's 11 sums to its own lane)
+    double* accG = reinterpret_cast<double*>(stage);
+    static_assert(sizeof(double) * BS * 11 <= sizeof(float4) * WCH * 3, "accG must fit into the staging buffer");
     __shared__ uint32_t sCi0[BS], sCi1[BS];
     uint32_t cmax = cnt;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
     const bool spread = cmax > 24u;
-    if (spread) {
-        for (int i = lane; i < BS * 11; i += BS) accG[i] = 0.0;
-    }
     for (uint32_t base = S0; base < S1; base += FCH) {
         const uint32_t nf = min(S1 - base, (uint32_t)FCH);
         uint8_t f[FCH / 64];
@@ -202,15 +205,11 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
                 if (w0 == 0) { sCi0[lane] = ci0; sCi1[lane] = ci1; }
                 __syncthreads();
                 const float* sf = reinterpret_cast<const float*>(stage);
-#pragma unroll 1
+#pragma unroll
                 for (int k = 0; k < 11; k++) {
                     const int task = k * BS + lane, g = task / 11, v = task - g * 11;
                     const uint32_t e0 = max(sCi0[g], w0), e1 = min(sCi1[g], w0 + nw);
-                    if (e0 < e1) {
-                        double sum = accG[task];  // accG[g * 11 + v]
-                        for (uint32_t e = e0; e < e1; e++) sum += sf[(e - w0) * 12 + v];
-                        accG[task] = sum;
-                    }
+                    for (uint32_t e = e0; e < e1; e++) acc[k] += sf[(e - w0) * 12 + v];
                 }
             } else {
                 const uint32_t e0 = max(ci0, w0), e1 = min(ci1, w0 + nw);
@@ -225,7 +224,10 @@ __global__ void __launch_bounds__(GSR_K7_BS) gsr_gauss_bwd_kernel(
         }
         __syncthreads();
     }
-    if (spread) {
+    if (spread) {  // transpose: task sums (k * 64 + lane) -> the 11 sums of Gaussian `lane`
+#pragma unroll
+        for (int k = 0; k < 11; k++) accG[k * BS + lane] = acc[k];
+        __syncthreads();
 #pragma unroll
         for (int v = 0; v < 11; v++) acc[v] = accG[lane * 11 + v];
     }

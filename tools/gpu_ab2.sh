@@ -8,4 +8,4 @@ run() { local name=$1; shift
 run base A=1
 for v in "$@"; do run $v GSR_LIB=$PWD/gscream_amd/libgsraster_$v.so; done
 run base_again A=1
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3; for wl in config3 config4; do for v in "" "$@"; do L=libgsraster${v:+_$v}.so; GSR_LIB=$PWD/gscream_amd/$L timeout 300 python bench.py --no-cpu-baseline --no-next-rows --steps 30 --warmup 5 --workload $wl 2>>"$OUT/err.log" | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl $L', d['value'], {k:round(v['avg_ms']*1e3,1) for k,v in d['stages'].items()})"; done; done
