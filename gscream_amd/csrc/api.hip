@@ -580,6 +580,22 @@ extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, co
     return GSR_OK;
 }
 
+extern "C" int gsr_decode_ld(int N) { return gsd_leading_dim(N > 0 ? N : 0); }
+extern "C" size_t gsr_decode_weight_grad_workspace_bytes(void) { return gsd_weight_grad_workspace_bytes(); }
+
+extern "C" int gsr_decode_weight_grads(int N, int K, const float* D2, const float* D1, const float* H, const float* X, void* workspace,
+                                       float* const* grads16, void* stream)
+{
+    if (N < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: N must be >= 0 (got %d)", N);
+    if (K < 1 || K > 10) return gsr_fail(GSR_ERR_UNSUPPORTED, "decode: n_offsets must be in 1..10 (got %d)", K);
+    if (!workspace || !grads16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: workspace / grads16 is NULL");
+    for (int i = 0; i < 16; i++)
+        if (!grads16[i]) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: grads16[%d] is NULL", i);
+    if (N > 0 && (!D2 || !D1 || !H || !X)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    GSR_HIP(gsd_launch_weight_grads(N, K, D2, D1, H, X, workspace, grads16, (hipStream_t)stream), "decode weight gradients");
+    return GSR_OK;
+}
+
 // ---- depth loss (depth_loss.hip) ----
 extern "C" size_t gsr_depth_loss_workspace_bytes(int H, int W) { return gdl_workspace_bytes(H, W); }
 

@@ -31,6 +31,14 @@
 #define GSD_HID 32
 #define GSD_MAXK 10     // n_offsets (arguments/__init__.py:51); the kernels handle K <= 10
 #define GSD_THREADS 256
+// Layout of the per-anchor arrays D2 / D1 / H / X (deltas and activations kept for the weight gradients): chunks of 64
+// anchors, feature-major inside a chunk -- element (row, anchor n) of an array with ROWS rows lives at
+// ((n / 64) * ROWS + row) * 64 + n % 64.  A wavefront (64 consecutive anchors) writes 256 contiguous bytes per row and all
+// rows of its chunk lie within 64 KB; the weight-gradient kernel reads 16-byte groups of 4 anchors.  (Plain [row][N] kept
+// the 64 anchors contiguous too, but put the rows 800 KB apart: every wave touched ~100 pages per step.)  Arrays are
+// sized for N rounded up to a whole chunk.
+__host__ __device__ static inline int gsd_ld(int N) { return (N + 63) & ~63; }
+#define GSD_AT(ROWS, row, n) ((((size_t)(n) >> 6) * (size_t)(ROWS) + (size_t)(row)) * 64 + ((size_t)(n) & 63))
 
 struct GsdMlps {  // device pointers; m = 0 opacity (K, tanh), 1 uncertainty (K, sigmoid), 2 color (3K, sigmoid), 3 cov (7K)
     const float* w1[4];  // [32][36] row-major (torch Linear.weight)
@@ -274,7 +282,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
     gsd_input(feat, anchor, campos, a, x, dist);
     if (M == 0) {
 #pragma unroll
-        for (int i = 0; i < GSD_IN; i++) Xout[(size_t)i * N + n] = x[i];
+        for (int i = 0; i < GSD_IN; i++) Xout[GSD_AT(GSD_IN, i, n)] = x[i];
     }
     uint32_t keep = 0;
     for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
@@ -286,7 +294,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
     }
     gsd_layer1(sw, L, M, x, h);
 #pragma unroll
-    for (int j = 0; j < GSD_HID; j++) { Hout[(size_t)(M * 32 + j) * N + n] = h[j]; dh[j] = 0.f; }
+    for (int j = 0; j < GSD_HID; j++) { Hout[GSD_AT(128, M * 32 + j, n)] = h[j]; dh[j] = 0.f; }
     constexpr int per = M == 0 || M == 1 ? 1 : (M == 2 ? 3 : 7);
     const int out_base = M == 0 ? 0 : (M == 1 ? K : (M == 2 ? 2 * K : 5 * K));
 #pragma unroll 1
@@ -334,7 +342,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
 #pragma unroll
         for (int c = 0; c < per; c++) {
             const int o = per * k + c;
-            D2[(size_t)(out_base + o) * N + n] = dz[c];
+            D2[GSD_AT(12 * K, out_base + o, n)] = dz[c];
             const float* w = sw + L.w2[M] + o * GSD_HID;
 #pragma unroll
             for (int j = 0; j < GSD_HID; j++) dh[j] += w[j] * dz[c];
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
         }
     }
 #pragma unroll
-    for (int j = 0; j < GSD_HID; j++) D1[(size_t)(M * 32 + j) * N + n] = h[j] > 0.0f ? dh[j] : 0.0f;  // through the ReLU
+    for (int j = 0; j < GSD_HID; j++) D1[GSD_AT(128, M * 32 + j, n)] = h[j] > 0.0f ? dh[j] : 0.0f;  // through the ReLU
     if (M == 3) {
 #pragma unroll
         for (int c = 0; c < 3; c++) d_gscale[6 * (size_t)a + 3 + c] = dgs3[c];
@@ -371,7 +379,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
         const float* w1 = sw + L.w1[m];
 #pragma unroll 4
         for (int j = 0; j < GSD_HID; j++) {
-            const float d1 = D1[(size_t)(m * 32 + j) * N + n];
+            const float d1 = D1[GSD_AT(128, m * 32 + j, n)];
 #pragma unroll
             for (int i = 0; i < GSD_IN; i++) dx[i] += w1[j * GSD_IN + i] * d1;
         }
@@ -404,6 +412,206 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) { d_anchor[3 * (size_t)a + c] = da[c]; d_gscale[6 * (size_t)a + c] = dgs[c]; }
+}
+
+// ---- weight gradients: D @ A^T over the anchors, on the f32 matrix cores ------------------------------------------------
+// gw2[m][o][j] = sum_n D2[base_m + o][n] H[32 m + j][n],  gb2[m][o] = sum_n D2[base_m + o][n]
+// gw1[m][j][i] = sum_n D1[32 m + j][n]  X[i][n],           gb1[m][j] = sum_n D1[32 m + j][n]
+// (only the diagonal blocks of the two big products exist: MLP m's deltas meet MLP m's activations).  All reduction, no
+// reuse beyond the tile: the kernel is bound by reading the four arrays once (1.3 KB per anchor).  v_mfma_f32_16x16x4_f32
+// (exact fp32, k-ordered fma chain) with the ANCHORS as the K dimension: lane l supplies A[row l & 15][k = l >> 4] and
+// B[k = l >> 4][col l & 15]; one 16-byte load per lane and tile (row l & 15, anchors n0 + 4 (l >> 4) .. + 3) feeds four
+// MFMA steps (step e takes component e: both operands use the same anchor -> k mapping, which is all that matters).
+// ROLE 0 = second layers (9 delta tiles x 2 hidden tiles per 16 anchors = 18 MFMA per step), ROLE 1 = first layers (per
+// MLP 2 delta tiles x 3 input tiles = 24 MFMA per step; input row 36 is a row of ones, so gb1 falls out of the product).
+// gb2: each lane adds up the delta components it loads (VALU), reduced over the four k-groups at the end.
+// A wave owns every (total waves)-th group of 16 anchors; the four waves of a workgroup are summed through LDS in wave
+// order, workgroup partials go to the workspace and gsd_weight_grad_finish_kernel adds them in workgroup order (double):
+// bit-reproducible.
+typedef float gsd_f4 __attribute__((ext_vector_type(4)));
+#define GSD_WG_BLOCKS 512
+#define GSD_WG2_ROWS (12 * GSD_MAXK)   // delta rows of the second layers (K | K | 3K | 7K)
+#define GSD_WG2_COLS 33                // 32 hidden + bias
+#define GSD_WG1_ROWS 128
+#define GSD_WG1_COLS 48                // 36 inputs + ones row (bias) + padding of the third tile
+
+__device__ __forceinline__ float4 gsd_load_tile(const float* __restrict__ base, int rows, int row, int row_end, int n, int N)
+{
+    // 4 consecutive anchors of one row.  The load itself is unconditional (row clamped into the array; n < the padded
+    // anchor count by construction), so that all the loads of a step are in flight together; rows beyond the block and
+    // anchors beyond N are zeroed afterwards by selects (the padding may hold anything, NaNs included).
+    const bool rok = row < row_end;
+    float4 v = *reinterpret_cast<const float4*>(base + GSD_AT(rows, rok ? row : 0, n));
+    v.x = (rok && n < N) ? v.x : 0.f;
+    v.y = (rok && n + 1 < N) ? v.y : 0.f;
+    v.z = (rok && n + 2 < N) ? v.z : 0.f;
+    v.w = (rok && n + 3 < N) ? v.w : 0.f;
+    return v;
+}
+__device__ __forceinline__ float gsd_comp(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+template <int ROLE>
+__global__ void __launch_bounds__(256) gsd_weight_grad_kernel(int N, int K, const float* __restrict__ Dm /* D2 | D1 */,
+                                                              const float* __restrict__ Am /* H | X */,
+                                                              const float* __restrict__ Hm /* ROLE 1: unused */,
+                                                              float* __restrict__ partial)
+{
+    constexpr int ROWS = ROLE == 0 ? GSD_WG2_ROWS : GSD_WG1_ROWS, COLS = ROLE == 0 ? GSD_WG2_COLS : GSD_WG1_COLS;
+    __shared__ float red[ROWS * COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kg = lane >> 4;
+    const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int nchunks = (N + 63) >> 6;  // a wave takes whole chunks of 64 anchors: four steps of 16
+    for (int i = threadIdx.x; i < ROWS * COLS; i += 256) red[i] = 0.f;
+    if (ROLE == 0) {
+        // delta tiles: MLP m owns rows [base_m, base_m + out_m), ceil(out_m / 16) tiles; tile list for K = 10: 1, 1, 2, 5
+        const int outs[4] = { K, K, 3 * K, 7 * K }, base[4] = { 0, K, 2 * K, 5 * K };
+        constexpr int NT[4] = { 1, 1, 2, 5 }, T0[4] = { 0, 1, 2, 4 };  // tiles per MLP at GSD_MAXK, first tile index
+        gsd_f4 acc[9][2];
+        float bsum[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) { bsum[t] = 0.f; acc[t][0] = acc[t][1] = (gsd_f4){0.f, 0.f, 0.f, 0.f}; }
+        for (int g = gw * 4; g < nchunks * 4; g = (g & 3) == 3 ? g + 4 * nwaves - 3 : g + 1) {
+            const int n = g * 16 + kg * 4;
+            float4 d[9], h[8];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+#pragma unroll
+                for (int tt = 0; tt < NT[m]; tt++) d[T0[m] + tt] = gsd_load_tile(Dm, 12 * K, base[m] + tt * 16 + r16, base[m] + outs[m], n, N);
+#pragma unroll
+                for (int c = 0; c < 2; c++) h[2 * m + c] = gsd_load_tile(Am, 128, 32 * m + c * 16 + r16, 128, n, N);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; t++) bsum[t] += (d[t].x + d[t].y) + (d[t].z + d[t].w);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+#pragma unroll
+                    for (int tt = 0; tt < NT[m]; tt++) {
+#pragma unroll
+                        for (int c = 0; c < 2; c++)
+                            acc[T0[m] + tt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gsd_comp(d[T0[m] + tt], e), gsd_comp(h[2 * m + c], e), acc[T0[m] + tt][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // wave -> LDS, in wave order (C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg)
+        for (int w = 0; w < 4; w++) {
+            __syncthreads();
+            if (wave != w) continue;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+#pragma unroll
+                for (int tt = 0; tt < NT[m]; tt++) {
+                    const int t = T0[m] + tt;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int o = tt * 16 + kg * 4 + rg;  // output row inside the MLP's block
+                        if (o < outs[m]) {
+#pragma unroll
+                            for (int c = 0; c < 2; c++) red[(base[m] + o) * COLS + c * 16 + r16] += acc[t][c][rg];
+                        }
+                    }
+                    // bias: lanes r16, r16 + 16, r16 + 32, r16 + 48 hold the four k-group partial sums of row tt * 16 + r16
+                    float b = bsum[t];
+                    b += __shfl_xor(b, 16, 64);
+                    b += __shfl_xor(b, 32, 64);
+                    if (kg == 0 && tt * 16 + r16 < outs[m]) red[(base[m] + tt * 16 + r16) * COLS + 32] += b;
+                }
+            }
+        }
+    } else {
+        gsd_f4 acc[4][2][3];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[m][a][c] = (gsd_f4){0.f, 0.f, 0.f, 0.f};
+        for (int g = gw * 4; g < nchunks * 4; g = (g & 3) == 3 ? g + 4 * nwaves - 3 : g + 1) {
+            const int n = g * 16 + kg * 4;
+            float4 d[8], x[3];
+#pragma unroll
+            for (int t = 0; t < 8; t++) d[t] = gsd_load_tile(Dm, 128, t * 16 + r16, 128, n, N);
+#pragma unroll
+            for (int c = 0; c < 3; c++) x[c] = gsd_load_tile(Am, GSD_IN, c * 16 + r16, 36, n, N);
+            if (r16 == 4) {  // row 36 of the input tile: ones where the anchor exists -> the bias gradient
+                x[2] = make_float4(n < N ? 1.f : 0.f, n + 1 < N ? 1.f : 0.f, n + 2 < N ? 1.f : 0.f, n + 3 < N ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            acc[m][a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gsd_comp(d[2 * m + a], e), gsd_comp(x[c], e), acc[m][a][c], 0, 0, 0);
+            }
+        }
+        for (int w = 0; w < 4; w++) {
+            __syncthreads();
+            if (wave != w) continue;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) red[(32 * m + 16 * a + kg * 4 + rg) * COLS + c * 16 + r16] += acc[m][a][c][rg];
+        }
+    }
+    __syncthreads();
+    float* dst = partial + (size_t)blockIdx.x * ROWS * COLS;
+    for (int i = threadIdx.x; i < ROWS * COLS; i += 256) dst[i] = red[i];
+}
+
+// sums the workgroup partials in workgroup order (double) and scatters them into the 16 gradient tensors
+struct GsdGrads { float* g[16]; };  // { gw1[4], gb1[4], gw2[4], gb2[4] }
+__global__ void __launch_bounds__(256) gsd_weight_grad_finish_kernel(int K, int nblocks, const float* __restrict__ partial2,
+                                                                     const float* __restrict__ partial1, GsdGrads G)
+{
+    // 64 elements per workgroup, four threads per element: thread (q, l) adds the q-th quarter of the workgroup partials of
+    // element l (loads unrolled), the four quarter sums meet in LDS and are added in order
+    __shared__ double quarter[4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + l;
+    constexpr int n2 = GSD_WG2_ROWS * GSD_WG2_COLS, n1 = GSD_WG1_ROWS * GSD_WG1_COLS;
+    const bool live = i < n2 + n1, second = i < n2;
+    const int e = second ? i : i - n2;
+    const float* p = second ? partial2 : partial1;
+    const int stride = second ? n2 : n1;
+    double s = 0.0;
+    if (live) {
+        const int per = (nblocks + 3) / 4, b0 = q * per, b1 = min(nblocks, b0 + per);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = p[(size_t)(b + u) * stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += (double)v[u];
+        }
+        for (; b < b1; b++) s += (double)p[(size_t)b * stride + e];
+    }
+    quarter[q][l] = s;
+    __syncthreads();
+    if (q != 0 || !live) return;
+    const float v = (float)(((quarter[0][l] + quarter[1][l]) + quarter[2][l]) + quarter[3][l]);
+    if (second) {
+        const int row = e / GSD_WG2_COLS, col = e - row * GSD_WG2_COLS;
+        if (row >= 12 * K) return;
+        const int m = row < K ? 0 : row < 2 * K ? 1 : row < 5 * K ? 2 : 3;
+        const int o = row - (m == 0 ? 0 : m == 1 ? K : m == 2 ? 2 * K : 5 * K);
+        if (col < 32) G.g[8 + m][o * 32 + col] = v;
+        else G.g[12 + m][o] = v;
+    } else {
+        const int row = e / GSD_WG1_COLS, col = e - row * GSD_WG1_COLS;
+        const int m = row >> 5, j = row & 31;
+        if (col < 36) G.g[m][j * 36 + col] = v;
+        else if (col == 36) G.g[4 + m][j] = v;
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -456,5 +664,23 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
 #undef GSD_BWD
     hipLaunchKernelGGL(gsd_backward_input_kernel, grid, block, 4 * GSD_HID * GSD_IN * sizeof(float), stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
                        first, g_xyz, D1, d_feat, d_anchor, d_offsets, d_gscale);
+    return hipGetLastError();
+}
+
+size_t gsd_weight_grad_workspace_bytes() { return (size_t)GSD_WG_BLOCKS * (GSD_WG2_ROWS * GSD_WG2_COLS + GSD_WG1_ROWS * GSD_WG1_COLS) * sizeof(float); }
+int gsd_leading_dim(int N) { return gsd_ld(N); }
+
+hipError_t gsd_launch_weight_grads(int N, int K, const float* D2, const float* D1, const float* H, const float* X, void* workspace,
+                                   float* const* grads16, hipStream_t stream)
+{
+    GsdGrads G;
+    for (int i = 0; i < 16; i++) G.g[i] = grads16[i];
+    float* p2 = (float*)workspace;
+    float* p1 = p2 + (size_t)GSD_WG_BLOCKS * GSD_WG2_ROWS * GSD_WG2_COLS;
+    // N == 0: the partials are zeros (nothing to add up) -- the kernels still run so that every output is written
+    hipLaunchKernelGGL(gsd_weight_grad_kernel<0>, dim3(GSD_WG_BLOCKS), dim3(256), 0, stream, N, K, D2, H, (const float*)nullptr, p2);
+    hipLaunchKernelGGL(gsd_weight_grad_kernel<1>, dim3(GSD_WG_BLOCKS), dim3(256), 0, stream, N, K, D1, X, (const float*)nullptr, p1);
+    const int total = GSD_WG2_ROWS * GSD_WG2_COLS + GSD_WG1_ROWS * GSD_WG1_COLS;
+    hipLaunchKernelGGL(gsd_weight_grad_finish_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, K, GSD_WG_BLOCKS, p2, p1, G);
     return hipGetLastError();
 }

@@ -226,6 +226,10 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
                                const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
                                float* d_anchor, float* d_offsets, float* d_gscale, float* D2, float* D1, float* H, float* X,
                                hipStream_t stream);
+size_t gsd_weight_grad_workspace_bytes();
+int gsd_leading_dim(int N);
+hipError_t gsd_launch_weight_grads(int N, int K, const float* D2, const float* D1, const float* H, const float* X, void* workspace,
+                                   float* const* grads16, hipStream_t stream);
 
 // ---- depth_loss.hip (depth terms) ----
 size_t gdl_workspace_bytes(int H, int W);
