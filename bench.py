@@ -84,6 +84,8 @@ def cpu_baseline(P, W, H, seed, gsel, budget_s=12.0):
         if dt > budget_s or n >= 200:
             break
     return {"value": n / dt, "unit": "iters/s", "cores": threads, "kind": "port",
+            "cores_note": f"OpenMP threads the oracle ran on (capped at 64: its parallel loops are over tiles / Gaussian chunks and stop "
+                          f"scaling there); the box reports {os.cpu_count()} logical CPUs, which is what cpu_torch_naive's torch thread pool uses",
             "sample": f"oracle/gs_oracle.c fwd+bwd on the bench workload itself ({P} Gaussians @ {W}x{H}, "
                       f"R={st['num_rendered']} without tile culling), {n} iterations in {dt:.1f}s"}
 

@@ -85,11 +85,17 @@ class _FusedLoss(torch.autograd.Function):
         return grad.reshape(ctx.in_shape), None, None, None, None
 
 
-def _check_window(window_size, size_average):
+def _check_window(window_size, size_average, img):
     if window_size != 11:
         raise NotImplementedError("only window_size=11 (what GScream uses everywhere) is implemented")
-    if not size_average:
-        raise NotImplementedError("size_average=False is never used by GScream's trainer and is not implemented")
+    if not size_average and not (img.dim() == 4 and img.shape[0] == 1):
+        # loss_utils.py:160 `ssim_map.mean(1).mean(1).mean(1)`: a per-image mean, defined for [B,C,H,W] input only
+        # (the reference itself fails on the [C,H,W] images the trainer passes); one image per call here
+        raise NotImplementedError("size_average=False needs a [1,C,H,W] input (one image per call)")
+
+
+def _per_image(v, size_average):
+    return v if size_average else v.reshape(1)  # loss_utils.py:157-160: mean over the whole map, or one mean per image
 
 
 def l1_loss(network_output, gt):
@@ -101,13 +107,13 @@ def l1_loss_masked(network_output, gt, mask):
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
-    _check_window(window_size, size_average)
-    return _FusedLoss.apply(img1, img2, None, 0.0, 1.0)[0]
+    _check_window(window_size, size_average, img1)
+    return _per_image(_FusedLoss.apply(img1, img2, None, 0.0, 1.0)[0], size_average)
 
 
 def ssim_masked(img1, img2, mask, window_size=11, size_average=True):
-    _check_window(window_size, size_average)
-    return _FusedLoss.apply(img1, img2, mask, 0.0, 1.0)[0]
+    _check_window(window_size, size_average, img1)
+    return _per_image(_FusedLoss.apply(img1, img2, mask, 0.0, 1.0)[0], size_average)
 
 
 def rgb_loss(image, gt, weight=None, lambda_dssim=0.2, scale=1.0, return_parts=False):

@@ -128,6 +128,8 @@ def assert_images_close(got, ref, name, max_outlier_frac=2e-4, hard_cap=2e-2):
     """<= 1e-4 abs on (almost) every pixel; a bounded handful of threshold-flip pixels is tolerated
     and reported, none may exceed hard_cap."""
     rep = image_report(got, ref)
+    if rep["outliers"]:
+        print(f"[threshold flips] {name}: {rep['outliers']} of {rep['n']} pixels beyond {IMG_ABS_TOL} (max {rep['max_abs']:.2e})")
     frac = rep["outliers"] / max(rep["n"], 1)
     assert frac <= max_outlier_frac, f"{name}: {rep['outliers']}/{rep['n']} pixels differ by > {IMG_ABS_TOL} (max {rep['max_abs']:.3e})"
     assert rep["max_abs"] <= hard_cap, f"{name}: max abs error {rep['max_abs']:.3e}"
@@ -142,21 +144,26 @@ def grad_report(got, ref, tol=GRAD_REL_TOL):
     return dict(max=float(rel.max()), p999=float(np.quantile(rel, 0.999)), n_bad=int((rel > tol).sum()), n=int(rel.size))
 
 
-def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-4, min_bad_allowed=4):
+def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-4, min_bad_allowed=4, max_rel=0.05):
     """Every gradient family within `tol` rel (denominator |ref| + 1e-3 max|ref|) on all but a bounded
     handful of elements.  The handful exists because a (pixel, Gaussian) pair whose alpha sits within an
     ulp of 1/255 (or whose T sits at 1e-4) can be blended by one implementation and skipped by the other
     (exp() and FMA contraction differ by ulps); that moves one pixel's worth of gradient for that Gaussian.
     Measured on the GPU box: 0-9 such elements out of 240k (tools/grad_diag.py).  One flipped pair moves ALL components
     of that Gaussian's gradient (4 for the quaternion), hence at least 4 elements are tolerated per family.  The 99.9th
-    percentile must be inside `tol` regardless (families of >= 1000 x the handful)."""
+    percentile must be inside `tol` regardless (families of >= 1000 x the handful).  No element may be off by more than
+    `max_rel` (0.05: one flipped pixel of one Gaussian; the parity build libgsraster_precise.so, which evaluates the
+    reference's own expression, has NO element beyond `tol` on the same cases -- tests/test_gpu_precise.py)."""
     rep = {}
     for k in keys:
         if k not in ref or k not in got:
             continue
         rep[k] = grad_report(got[k], ref[k], tol)
+    flips = {k: (v["n_bad"], round(v["max"], 5)) for k, v in rep.items() if v["n_bad"]}
+    if flips:  # shows with `pytest -s` / in the failure report: (elements beyond tol, worst relative error) per family
+        print(f"[threshold flips] {context}: {flips}")
     bad = {k: v for k, v in rep.items()
-           if v["n_bad"] > max(min_bad_allowed, max_bad_frac * v["n"]) or not v["max"] <= 0.5
+           if v["n_bad"] > max(min_bad_allowed, max_bad_frac * v["n"]) or not v["max"] <= max_rel
            # the 99.9th percentile says something only where 0.1 % of the elements is more than the tolerated handful
            or (v["n"] >= 1000 * min_bad_allowed and not v["p999"] <= tol)}
     assert not bad, f"{context} gradient mismatch (rel tol {tol}): {bad}; all: {rep}"

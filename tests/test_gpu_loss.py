@@ -73,6 +73,11 @@ def test_mirrored_functions_and_upstream_gradient():
         L.ssim(x, y, window_size=7)
     with pytest.raises(RuntimeError):
         L.ssim(x.detach().cpu(), y.cpu())
+    # size_average=False (loss_utils.py:157-160): one mean per image of a [B,C,H,W] batch; B = 1 here
+    per = L.ssim(x.detach()[None], y[None], size_average=False)
+    assert per.shape == (1,) and abs(float(per[0]) - float(LO.ssim(xr.detach(), yr))) < 3e-6
+    with pytest.raises(NotImplementedError):
+        L.ssim(x, y, size_average=False)  # the reference's .mean(1).mean(1).mean(1) needs the batch dimension too
 
 
 def test_full_size_properties_and_reproducibility():
