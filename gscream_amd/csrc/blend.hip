@@ -28,8 +28,8 @@
 //     -amdgpu-atomic-optimizer-strategy=None so it stays one instruction).  After the batch, thread i stores the
 //     12 floats of instance i with three plain 16-byte stores into that instance's private gradient slot (slot =
 //     Gaussian's scan offset + rank of the tile among the surviving tiles of its rectangle); gauss_bwd.hip sums each
-//     Gaussian's slots.  No atomics on global memory at all.  (The LDS adds of a task's 2 wavefronts are unordered,
-//     so two runs agree to rounding, not bit for bit.)
+//     Gaussian's slots.  No atomics on global memory at all; each of a task's 2 wavefronts has its own LDS accumulator and
+//     the flush adds them in a fixed order, so the backward is bit-reproducible.
 //   * AUX = false specialises the backward for "no gradient flows into the depth and feature maps" (GScream's
 //     RGB-only iterations): 9 instead of 11 reductions and no depth/feature recurrences.
 //   * XCD awareness: workgroup b runs on XCD b % 8 (observed dispatch rule); the block->tile maps hand each
@@ -397,12 +397,12 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 // largest fixed cost per (wave, instance) -- is paid once per 128 pixels instead of once per 64.
 // ---------------------------------------------------------------------------------------------
 // Wave-private compaction: indices i < cnt whose quadrant mask sQ[i] meets `qmask` and pred(i), in ascending order.
-template <typename Pred>
+template <int SL, typename Pred>
 __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, int cnt, uint32_t qmask, int lane, Pred pred)
 {
     int n = 0;
 #pragma unroll
-    for (int c = 0; c < GSR_SEG_LEN / 64; c++) {
+    for (int c = 0; c < SL / 64; c++) {
         const int i = c * 64 + lane;
         const bool hit = i < cnt && (sQ[i] & qmask) && pred(i);
         const unsigned long long bal = __ballot(hit);
@@ -415,7 +415,8 @@ __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, 
 #ifndef GSR_BWD_WAVES
 #define GSR_BWD_WAVES 5
 #endif
-template <bool AUX>
+// SL = the launch's segment length (64 up to 4096 tiles, 128 beyond): sizes the LDS arrays.
+template <bool AUX, int SL>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, GSR_BWD_WAVES))) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -423,10 +424,14 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
     int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
 {
-    __shared__ float4 sA[GSR_SEG_LEN], sB[GSR_SEG_LEN], sC[GSR_SEG_LEN];
-    __shared__ __attribute__((aligned(16))) float acc[GSR_SEG_LEN * GSR_SLOT_FLOATS];
-    __shared__ uint32_t sSlot[GSR_SEG_LEN], sQ[GSR_SEG_LEN];
-    __shared__ uint16_t sList[2][GSR_SEG_LEN];
+    static_assert(SL == 64 || SL == GSR_SEG_LEN, "segment lengths of gsr_seg_len()");
+    __shared__ float4 sA[SL], sB[SL], sC[SL];
+    // one accumulator array PER WAVEFRONT: a wave's LDS adds are program-ordered and nobody else touches its copy, the flush
+    // adds the two copies in a fixed order -> the backward is bit-reproducible (it was not while both waves added into one
+    // array in whatever order they arrived)
+    __shared__ __attribute__((aligned(16))) float acc[2][SL * GSR_SLOT_FLOATS];
+    __shared__ uint32_t sSlot[SL], sQ[SL];
+    __shared__ uint16_t sList[2][SL];
 
     GSR_TRACE_BEGIN
     // Workgroup b runs on XCD b % 8 and takes the (b >> 3)-th slot of that XCD's band of tiles (the forward's tile -> XCD
@@ -505,7 +510,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     int wmax = max(lastca, lastcb);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
-    for (int i = t; i < GSR_SEG_LEN * GSR_SLOT_FLOATS; i += 128) acc[i] = 0.f;
+    for (int i = t; i < 2 * SL * GSR_SLOT_FLOATS; i += 128) (&acc[0][0])[i] = 0.f;
     uint16_t* mylist = sList[wave];
     const uint32_t qmask = 3u << (2 * wave);  // the two 8x8 quadrants of this strip
     int accfield = -1;  // accumulator field this lane reports after the wave reduction (see gsr_bank_reduce)
@@ -539,7 +544,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
         __syncthreads();
         {
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
-            const int nw = gsr_compact2(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
+            const int nw = gsr_compact2<SL>(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
             __builtin_amdgcn_wave_barrier();
             for (int c0 = 0; c0 < nw; c0 += 64) {
                 const int m = min(64, nw - c0);
@@ -630,7 +635,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                         }
                         x += gsr_dpp<0xB1>(x);
                         x += gsr_dpp<0x4E>(x);
-                        if (accfield >= 0) atomicAdd(&acc[(uint32_t)j * GSR_SLOT_FLOATS + (uint32_t)accfield], x);  // 32-bit index math: no v_mad_u64_u32
+                        if (accfield >= 0) atomicAdd(&acc[wave][(uint32_t)j * GSR_SLOT_FLOATS + (uint32_t)accfield], x);
                     }
                     j = jn; A = An; B = Bn;
                 }
@@ -638,9 +643,14 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
         }
         __syncthreads();
         if (t < cnt) {
-            float4* a4 = reinterpret_cast<float4*>(acc + t * GSR_SLOT_FLOATS);
+            float4* a4 = reinterpret_cast<float4*>(&acc[0][t * GSR_SLOT_FLOATS]);
+            float4* b4 = reinterpret_cast<float4*>(&acc[1][t * GSR_SLOT_FLOATS]);
             float4* dst = slots + (size_t)sSlot[t] * 3;
+            const float4 p0 = b4[0], p1 = b4[1], p2 = b4[2];
             float4 o0 = a4[0], o1 = a4[1], o2 = a4[2];
+            o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;  // strip 0 + strip 1, always in this order
+            o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+            o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
             {
                 // moments -> the reference's per-instance sums (DGR backward.cu:586-601):
                 //   dL/dmean2D = -o (cA Mx + cB My) W/2, -o (cC My + cB Mx) H/2;  dL/dconic = -o/2 (Mxx, Mxy, Myy);
@@ -656,7 +666,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                 o1.y = -op * (cA * Mx + cB * My) * ddelx_dx;
                 o1.z = -op * (cC * My + cB * Mx) * ddely_dy;
                 o1.w = -0.5f * op * Mxx; o2.x = -0.5f * op * Mxy; o2.y = -0.5f * op * Myy;
-                a4[0] = a4[1] = a4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                a4[0] = a4[1] = a4[2] = b4[0] = b4[1] = b4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             dst[0] = o0; dst[1] = o1; dst[2] = o2;
             slot_written[sSlot[t]] = 1;
@@ -689,13 +699,18 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     float4* s4 = reinterpret_cast<float4*>(slots);
     // the grid covers GSR_SEG_MAX segments of every tile; workgroups of segments a tile does not have leave at once
     const dim3 grid(8u * (uint32_t)((T + 7) / 8) * GSR_SEG_MAX);
-    if (dL_ddepth && dL_dfeature)
-        hipLaunchKernelGGL(gsr_blend_bwd_kernel<true>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
-                           gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, dL_ddepth, dL_dfeature,
-                           image.tile_work, T, gsr_seg_len(T), geom.offsets, slot_written, s4);
-    else
-        hipLaunchKernelGGL(gsr_blend_bwd_kernel<false>, grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H,
-                           gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, nullptr, nullptr,
-                           image.tile_work, T, gsr_seg_len(T), geom.offsets, slot_written, s4);
+    const int sl = gsr_seg_len(T);
+#define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
+    hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
+                       gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
+                       geom.offsets, slot_written, s4)
+    if (dL_ddepth && dL_dfeature) {
+        if (sl == 64) GSR_BWD_LAUNCH(true, 64, dL_ddepth, dL_dfeature);
+        else GSR_BWD_LAUNCH(true, GSR_SEG_LEN, dL_ddepth, dL_dfeature);
+    } else {
+        if (sl == 64) GSR_BWD_LAUNCH(false, 64, nullptr, nullptr);
+        else GSR_BWD_LAUNCH(false, GSR_SEG_LEN, nullptr, nullptr);
+    }
+#undef GSR_BWD_LAUNCH
     return hipGetLastError();
 }

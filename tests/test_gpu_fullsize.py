@@ -140,10 +140,8 @@ def test_backward_properties(scene):
     a, radii = _run_bwd(s, dev, rs, g1)
     b, _ = _run_bwd(s, dev, rs, g1)
     for k in a:
-        # no global float atomics; the adds of a tile's <= 16 row leaders into the LDS accumulator are unordered,
-        # so two runs agree to rounding (not bitwise); ill-conditioned dL/dscale, dL/drot amplify that
-        mx, p9999 = _rel_stats(b[k], a[k])
-        assert p9999 < 1e-4 and mx < 5e-2, f"{k}: run-to-run spread max {mx}, p99.99 {p9999}"
+        # no float atomics; per-wavefront LDS accumulators summed in a fixed order: two runs give the same bits, at 1M Gaussians too
+        assert torch.equal(a[k], b[k]), f"{k}: the backward must be bit-reproducible (max diff {(a[k] - b[k]).abs().max().item()})"
     culled = radii <= 0
     assert int(culled.sum()) > 0
     for k in ("means3D", "opacities", "scales", "rotations", "colors", "means2D"):
