@@ -7,4 +7,4 @@ sys.path.insert(0, ".")
 import bench
 from gscream_amd import _native
 _native.load()
-print(bench.pipeline_row(torch.device("cuda", 0), 40))
+print(bench.pipeline_row(torch.device("cuda", 0)))
