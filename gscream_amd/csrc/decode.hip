@@ -97,6 +97,13 @@ __device__ __forceinline__ GsdLds gsd_stage_weights(const GsdMlps& P, int K, flo
     return L;
 }
 
+// The multiply-accumulates run as v_pk_fma_f32 on PAIRS of adjacent weights (a row of W as float2s) against pairs of
+// inputs: one packed FMA = two MACs in 4.2 issue cycles, where the scalar form acc += w * x reads three VGPRs and costs
+// 3.8-4.0 per MAC (tools/microbench/valu_issue.hip) -- the packed form is the only way to the fp32 FMA rate when both
+// factors live in VGPRs.  Dot products therefore come out as (sum over even terms) + (sum over odd terms).
+typedef float gsd_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gsd_f2 gsd_fma2(gsd_f2 a, gsd_f2 b, gsd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // layer 1 of MLP m, fully unrolled into registers (post-ReLU): every index is a compile-time constant.
 __device__ __forceinline__ void gsd_layer1(const float* sw, const GsdLds& L, int m, const float x[GSD_IN], float h[GSD_HID])
 {
@@ -104,19 +111,25 @@ __device__ __forceinline__ void gsd_layer1(const float* sw, const GsdLds& L, int
     const float* b = sw + L.b1[m];
 #pragma unroll
     for (int j = 0; j < GSD_HID; j++) {
-        float s = b[j];
+        gsd_f2 s = {b[j], 0.f};
 #pragma unroll
-        for (int i = 0; i < GSD_IN; i++) s += w[j * GSD_IN + i] * x[i];
-        h[j] = fmaxf(s, 0.0f);
+        for (int i = 0; i < GSD_IN; i += 2) {
+            const gsd_f2 wv = *reinterpret_cast<const gsd_f2*>(w + j * GSD_IN + i), xv = {x[i], x[i + 1]};
+            s = gsd_fma2(wv, xv, s);
+        }
+        h[j] = fmaxf(s.x + s.y, 0.0f);
     }
 }
 __device__ __forceinline__ float gsd_out(const float* sw, const GsdLds& L, int m, int o, const float h[GSD_HID])
 {
     const float* w = sw + L.w2[m] + o * GSD_HID;
-    float s = sw[L.b2[m] + o];
+    gsd_f2 s = {sw[L.b2[m] + o], 0.f};
 #pragma unroll
-    for (int j = 0; j < GSD_HID; j++) s += w[j] * h[j];
-    return s;
+    for (int j = 0; j < GSD_HID; j += 2) {
+        const gsd_f2 wv = *reinterpret_cast<const gsd_f2*>(w + j), hv = {h[j], h[j + 1]};
+        s = gsd_fma2(wv, hv, s);
+    }
+    return s.x + s.y;
 }
 
 // ---- pass A: opacity MLP, mask, count ---------------------------------------------------------------------------
@@ -345,7 +358,11 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
             D2[GSD_AT(12 * K, out_base + o, n)] = dz[c];
             const float* w = sw + L.w2[M] + o * GSD_HID;
 #pragma unroll
-            for (int j = 0; j < GSD_HID; j++) dh[j] += w[j] * dz[c];
+            for (int j = 0; j < GSD_HID; j += 2) {  // two hidden units per packed FMA
+                gsd_f2 d = {dh[j], dh[j + 1]};
+                d = gsd_fma2(*reinterpret_cast<const gsd_f2*>(w + j), (gsd_f2){dz[c], dz[c]}, d);
+                dh[j] = d.x; dh[j + 1] = d.y;
+            }
             if (per > 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -381,7 +398,11 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
         for (int j = 0; j < GSD_HID; j++) {
             const float d1 = D1[GSD_AT(128, m * 32 + j, n)];
 #pragma unroll
-            for (int i = 0; i < GSD_IN; i++) dx[i] += w1[j * GSD_IN + i] * d1;
+            for (int i = 0; i < GSD_IN; i += 2) {  // two inputs per packed FMA
+                gsd_f2 d = {dx[i], dx[i + 1]};
+                d = gsd_fma2(*reinterpret_cast<const gsd_f2*>(w1 + j * GSD_IN + i), (gsd_f2){d1, d1}, d);
+                dx[i] = d.x; dx[i + 1] = d.y;
+            }
         }
     }
 #pragma unroll
