@@ -480,8 +480,8 @@ __global__ void __launch_bounds__(256) gsd_weight_grad_kernel(int N, int K, cons
     constexpr int ROWS = ROLE == 0 ? GSD_WG2_ROWS : GSD_WG1_ROWS, COLS = ROLE == 0 ? GSD_WG2_COLS : GSD_WG1_COLS;
     __shared__ float red[ROWS * COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kg = lane >> 4;
-    const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
-    const int nchunks = (N + 63) >> 6;  // a wave takes whole chunks of 64 anchors: four steps of 16
+    const int npairs = gridDim.x * 2, pair = blockIdx.x * 2 + (wave >> 1), par = wave & 1;
+    const int nchunks = (N + 63) >> 6;
     for (int i = threadIdx.x; i < ROWS * COLS; i += 256) red[i] = 0.f;
     if (ROLE == 0) {
         // delta tiles: MLP m owns rows [base_m, base_m + out_m), ceil(out_m / 16) tiles; tile list for K = 10: 1, 1, 2, 5
@@ -491,7 +491,11 @@ __global__ void __launch_bounds__(256) gsd_weight_grad_kernel(int N, int K, cons
         float bsum[9];
 #pragma unroll
         for (int t = 0; t < 9; t++) { bsum[t] = 0.f; acc[t][0] = acc[t][1] = (gsd_f4){0.f, 0.f, 0.f, 0.f}; }
-        for (int g = gw * 4; g < nchunks * 4; g = (g & 3) == 3 ? g + 4 * nwaves - 3 : g + 1) {
+        // A chunk of 64 anchors is shared by a PAIR of waves of the workgroup: wave parity p takes the 16-anchor steps p and
+        // p + 2, so the two 64-byte halves of every 128-byte line are requested by the two waves at the same time and the
+        // line is fetched from HBM once (one wave walking steps 0..3 fetched every line twice: PMC 373 MB for 198 MB --
+        // the in-flight working set of 2048 waves is larger than the L2s).
+        for (int g = pair * 4 + par; g < nchunks * 4; g = (g & 2) ? g + 4 * npairs - 2 : g + 2) {
             const int n = g * 16 + kg * 4;
             float4 d[9], h[8];
 #pragma unroll
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(256) gsd_weight_grad_kernel(int N, int K, cons
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int c = 0; c < 3; c++) acc[m][a][c] = (gsd_f4){0.f, 0.f, 0.f, 0.f};
-        for (int g = gw * 4; g < nchunks * 4; g = (g & 3) == 3 ? g + 4 * nwaves - 3 : g + 1) {
+        for (int g = pair * 4 + par; g < nchunks * 4; g = (g & 2) ? g + 4 * npairs - 2 : g + 2) {  // wave pairs share chunks, see ROLE 0
             const int n = g * 16 + kg * 4;
             float4 d[8], x[3];
 #pragma unroll
