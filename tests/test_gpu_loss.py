@@ -67,7 +67,7 @@ def test_mirrored_functions_and_upstream_gradient():
     yr, mr = torch.from_numpy(gt).double(), torch.from_numpy(mask).double()
     ref = 0.8 * LO.l1_loss(xr, yr) + 0.2 * (1.0 - LO.ssim(xr, yr)) + 0.5 * (0.8 * LO.l1_loss_masked(xr, yr, mr) + 0.2 * (1.0 - LO.ssim_masked(xr, yr, mr)))
     ref.backward()
-    assert abs(float(total) - float(ref)) < 3e-6
+    assert abs(float(total.detach()) - float(ref.detach())) < 3e-6
     assert (x.grad.cpu().double() - xr.grad).abs().max() <= 1e-4 * xr.grad.abs().max()
     with pytest.raises(NotImplementedError):
         L.ssim(x, y, window_size=7)
