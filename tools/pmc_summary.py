@@ -16,17 +16,22 @@ import os
 import sqlite3
 import sys
 
-STAGE_OF = {
-    "gsr_preprocess_kernel<0>": "preprocess", "gsr_scan_reduce_kernel": "count_scan", "gsr_scan_sums_kernel": "count_scan",
+# kernel-name prefix -> bench.py stage (template arguments vary: matched on the name in front of '<')
+STAGE_PREFIX = {
+    "gsr_preprocess_kernel": "preprocess", "gsr_scan_reduce_kernel": "count_scan", "gsr_scan_sums_kernel": "count_scan",
     "gsr_scan_apply_kernel": "count_scan", "gsr_tile_hist_kernel": "count_scan", "gsr_table_colscan_kernel": "count_scan",
-    "gsr_tile_scan_kernel": "count_scan", "gsr_scatter_kernel": "scatter", "gsr_scatter_kernel<false>": "scatter",
-    "gsr_scatter_kernel<true>": "scatter", "gsr_tile_hist_kernel<false>": "count_scan", "gsr_tile_hist_kernel<true>": "count_scan",
-    "gsr_cursor_init_kernel": "scatter", "gsr_tile_sort_lds_kernel": "tile_sort", "gsr_tile_sort_lds_kernel<256>": "tile_sort",
-    "gsr_tile_sort_lds_kernel<1024>": "tile_sort", "gsr_tile_sort_near_kernel": "tile_sort",
-    "gsr_tile_sort_global_kernel": "tile_sort", "gsr_blend_fwd_kernel": "blend_forward",
-    "gsr_blend_bwd_kernel<false>": "blend_backward", "gsr_blend_bwd_kernel<true>": "blend_backward",
-    "gsr_gauss_bwd_kernel": "gauss_backward",
+    "gsr_tile_scan_kernel": "count_scan", "gsr_scatter_kernel": "scatter", "gsr_cursor_init_kernel": "scatter",
+    "gsr_tile_sort_lds_kernel": "tile_sort", "gsr_tile_sort_near_kernel": "tile_sort", "gsr_tile_sort_global_kernel": "tile_sort",
+    "gsr_blend_fwd_kernel": "blend_forward", "gsr_blend_bwd_kernel": "blend_backward", "gsr_gauss_bwd_kernel": "gauss_backward",
 }
+
+
+class _StageOf:
+    def get(self, kernel, default=None):
+        return STAGE_PREFIX.get(kernel.split("<")[0], default)
+
+
+STAGE_OF = _StageOf()
 
 
 def load(db):
