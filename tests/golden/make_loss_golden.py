@@ -2,8 +2,8 @@
 
     python tests/golden/make_loss_golden.py
 
-The reference module (utils/loss_utils.py) cannot be imported in this image (it imports kornia), so these vectors
-come from the restatement -- "parity unpinned", see the oracle's header."""
+These vectors come from the restatement; the restatement itself is pinned to the reference's utils/loss_utils.py by
+the reference-run vectors of make_reference_vectors2.py (ref_loss.npz), see the oracle's header."""
 import os
 import sys
 
