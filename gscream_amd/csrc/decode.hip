@@ -22,6 +22,7 @@
 //           gsd_backward_input_kernel : W1^T deltas -> gradients of feat / anchor, and the offset / grid-scaling geometry.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gsr_common.h"
 #include "gsr_math.h"
@@ -47,7 +48,13 @@ struct GsdMlps {  // device pointers; m = 0 opacity (K, tanh), 1 uncertainty (K,
     const float* b2[4];  // [out]
 };
 
+#ifdef GSD_EXP_FASTMATH
+__device__ __forceinline__ float gsd_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+#elif defined(GSD_EXP_NOPOST)
+__device__ __forceinline__ float gsd_sigmoid(float x) { return x; }
+#else
 __device__ __forceinline__ float gsd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif
 
 // input vector of one anchor (gaussian_renderer/__init__.py:30-47): [feat(32), ob_view(3), ob_dist]
 __device__ __forceinline__ void gsd_input(const float* __restrict__ feat, const float* __restrict__ anchor,
@@ -132,7 +139,147 @@ __device__ __forceinline__ float gsd_out(const float* sw, const GsdLds& L, int m
     return s.x + s.y;
 }
 
+// ---- the MLPs on the f32 matrix cores ----------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 computes D[16x16] += A[16x4] B[4x16]; lane l = (g = l >> 4, a = l & 15) supplies A[row a][k g] and
+// B[k g][col a] and holds D[row 4g + r][col a] in register r.  The layers are evaluated TRANSPOSED, out[o][anchor] =
+// sum_i W[o][i] in[i][anchor]: the weights are the A operand -- loaded once per wave into registers and kept there for
+// every anchor the wave ever sees --, sixteen anchors are the columns, and the B operand is per-anchor data in lane
+// (g, anchor a).  The sum over k is order-free, so every step may pair k-group g with ANY input index as long as the A
+// operand uses the same map:
+//   layer 1, step s < 4: input 4g + s, step 4 <= s < 8: input 12 + 4g + s (lane g holds feat[4g .. 4g+3] and feat[16+4g .. 16+4g+3]:
+//   two 16-byte loads, each touching one 64-byte line per anchor), step 8: input 32 + g (view, dist);
+//   layer 2, step (jt, r): hidden unit 16 jt + 4g + r -- exactly register r of layer-1 tile jt as the matrix core left it.
+// No LDS, no cross-lane traffic between the layers.  The rows of a second-layer tile are ours to choose as well: row
+// 4g + r carries component r of Gaussian k = 4q + g (tile q), so that after the product lane (g, a) holds, in the four
+// registers of a tile, all components of ONE offset of ITS anchor (opacity / uncertainty: k = 4r + g in one tile).
+// fp32 throughout (the matrix-core fp32 path is an exact fma chain); rounding differs from a sequential dot product only
+// by the order of the sum.
+typedef float gsd_v4 __attribute__((ext_vector_type(4)));
+#ifdef GSD_EXP_NOMFMA
+#define GSD_MFMA(A, B, C) ((C) + (A) * (B))
+#else
+#define GSD_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+#endif
+#define GSD_GROUPS 4  // groups of 16 anchors per 64-anchor unit of a wave
+// The A operands live in LDS as a table of per-lane values, entry e of lane l at sw[e * 64 + l] (a wave reads an entry
+// with one conflict-free ds_read_b32), staged once per workgroup: registers stay free for several waves per SIMD, and a
+// 16-anchor step reads ~200 entries where the thread-per-anchor form needed ~1800 broadcast reads per 64 anchors.
+//   first layer of an MLP : 26 entries = w[jt][s] at 9 jt + s (18), bias (the C operand) at 18 + 4 jt + r
+//   second-layer tile     : 12 entries = w[4 jt + r] (8), bias at 8 + r
+#define GSD_L1_ENTRIES 26
+#define GSD_L2_ENTRIES 12
+__device__ __forceinline__ float gsd_l1_entry(const float* __restrict__ w1, const float* __restrict__ b1, int e, int g, int a)
+{
+    if (e < 18) {
+        const int jt = e / 9, s = e - 9 * jt;
+        return w1[(16 * jt + a) * GSD_IN + (s < 4 ? 4 * g + s : s < 8 ? 12 + 4 * g + s : 32 + g)];
+    }
+    return b1[16 * ((e - 18) >> 2) + 4 * g + ((e - 18) & 3)];
+}
+// head = true: the opacity / uncertainty heads, one tile, row 4g' + r' = offset k = 4r' + g' (r' < 3); otherwise tile q of
+// a head with `comps` components per offset: row 4g' + r' = component r' of offset k = 4q + g', output k * stride + first + r'
+__device__ __forceinline__ float gsd_l2_entry(const float* __restrict__ w2, const float* __restrict__ b2, int K, bool head, int q,
+                                              int comps, int stride, int first, int e, int g, int a)
+{
+    if (e < 8) {
+        const int gp = a >> 2, rp = a & 3;
+        const int k = head ? 4 * rp + gp : 4 * q + gp;
+        const bool used = head ? (rp < 3 && k < K) : (rp < comps && k < K);
+        const int o = head ? k : k * stride + first + rp;
+        return used ? w2[o * GSD_HID + 16 * (e >> 2) + 4 * g + (e & 3)] : 0.0f;
+    }
+    const int r = e - 8;
+    const int k = head ? 4 * r + g : 4 * q + g;
+    const bool used = head ? (r < 3 && k < K) : (r < comps && k < K);
+    return used ? b2[head ? k : k * stride + first + r] : 0.0f;
+}
+// B operands of the first layer for lane (g, a): eight features of its anchor (map above) and component g of (view, dist).  Loading and
+// finishing are separate so that a wave can have the next group's loads in flight without touching their results.
+struct GsdIn {
+    float f[8];
+    float v;
+};
+struct GsdRaw {
+    float4 u, w;
+    float ax, ay, az;
+};
+__device__ __forceinline__ void gsd_load_raw(GsdRaw& R, const float* __restrict__ feat, const float* __restrict__ anchor, int ai, int g)
+{
+    const float4* f4 = reinterpret_cast<const float4*>(feat + (size_t)ai * GSD_F + 4 * g);
+    R.u = f4[0]; R.w = f4[4];  // floats 4g .. 4g+3 and 16 + 4g .. 16 + 4g+3: one 64-byte line per anchor and load
+    R.ax = anchor[3 * (size_t)ai]; R.ay = anchor[3 * (size_t)ai + 1]; R.az = anchor[3 * (size_t)ai + 2];
+}
+__device__ __forceinline__ void gsd_finish_in(GsdIn& X, const GsdRaw& R, float cx, float cy, float cz, int g)
+{
+    X.f[0] = R.u.x; X.f[1] = R.u.y; X.f[2] = R.u.z; X.f[3] = R.u.w; X.f[4] = R.w.x; X.f[5] = R.w.y; X.f[6] = R.w.z; X.f[7] = R.w.w;
+    const float vx = R.ax - cx, vy = R.ay - cy, vz = R.az - cz;
+    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    X.v = g == 0 ? vx / dist : g == 1 ? vy / dist : g == 2 ? vz / dist : dist;
+}
+__device__ __forceinline__ void gsd_load_in(GsdIn& X, const float* __restrict__ feat, const float* __restrict__ anchor, float cx,
+                                            float cy, float cz, int ai, int g)
+{
+    GsdRaw R;
+    gsd_load_raw(R, feat, anchor, ai, g);
+    gsd_finish_in(X, R, cx, cy, cz, g);
+}
+// hidden layer (post-ReLU) of 16 anchors: h[jt][r] = unit 16 jt + 4g + r of the lane's anchor; t = the layer's table (+ lane)
+__device__ __forceinline__ void gsd_mfma_l1(const float* t, const GsdIn& X, gsd_v4 (&h)[2])
+{
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++) {
+        gsd_v4 acc = {t[(18 + 4 * jt) * 64], t[(19 + 4 * jt) * 64], t[(20 + 4 * jt) * 64], t[(21 + 4 * jt) * 64]};
+#pragma unroll
+        for (int s = 0; s < 8; s++) acc = GSD_MFMA(t[(9 * jt + s) * 64], X.f[s], acc);
+        acc = GSD_MFMA(t[(9 * jt + 8) * 64], X.v, acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[jt][r] = fmaxf(acc[r], 0.0f);
+    }
+}
+__device__ __forceinline__ gsd_v4 gsd_mfma_l2(const float* t, const gsd_v4 (&h)[2])
+{
+    gsd_v4 acc = {t[8 * 64], t[9 * 64], t[10 * 64], t[11 * 64]};
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc = GSD_MFMA(t[(4 * jt + r) * 64], h[jt][r], acc);
+    return acc;
+}
+
+// Staging of an operand table: wave W of NW takes entries W, W + NW, ...; W is a template parameter (switch on the wave
+// index) so that every entry index -- and with it every weight pointer and offset -- is a compile-time constant and the
+// wave's loads are all in flight before its first LDS write.  (With a run-time entry index the MLP pointers are fetched
+// from the argument block by dependent loads and the staging alone took ~50 us.)
+template <int W, int NW, int TOTAL, typename Entry>
+__device__ __forceinline__ void gsd_stage_part(float* sw, int lane, Entry entry)
+{
+    constexpr int PER = (TOTAL + NW - 1) / NW;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) v[i] = (W + i * NW < TOTAL) ? entry(W + i * NW) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (W + i * NW < TOTAL) sw[(W + i * NW) * 64 + lane] = v[i];
+}
+template <int NW, int TOTAL, typename Entry>
+__device__ __forceinline__ void gsd_stage(float* sw, int wave, int lane, Entry entry)
+{
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    switch (wave) {
+    case 0: gsd_stage_part<0, NW, TOTAL>(sw, lane, entry); break;
+    case 1: gsd_stage_part<1, NW, TOTAL>(sw, lane, entry); break;
+    case 2: gsd_stage_part<2, NW, TOTAL>(sw, lane, entry); break;
+    case 3: gsd_stage_part<3, NW, TOTAL>(sw, lane, entry); break;
+    case 4: if (NW > 4) gsd_stage_part<4 % NW, NW, TOTAL>(sw, lane, entry); break;
+    case 5: if (NW > 4) gsd_stage_part<5 % NW, NW, TOTAL>(sw, lane, entry); break;
+    case 6: if (NW > 4) gsd_stage_part<6 % NW, NW, TOTAL>(sw, lane, entry); break;
+    default: if (NW > 4) gsd_stage_part<7 % NW, NW, TOTAL>(sw, lane, entry); break;
+    }
+}
+
 // ---- pass A: opacity MLP, mask, count ---------------------------------------------------------------------------
+// Workgroups walk 256-anchor blocks (the unit of the scan); wave w of a block takes its anchors 64 w .. 64 w + 63 as four
+// groups of 16.
 __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, GsdMlps P, const int32_t* __restrict__ vis,
                                                                 const float* __restrict__ feat,
                                                                 const float* __restrict__ anchor,
@@ -142,30 +289,53 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
                                                                 uint32_t* __restrict__ block_sum)
 {
     __shared__ uint32_t bs;
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
-    if (threadIdx.x == 0) bs = 0u;
-    const GsdLds L = gsd_stage_weights(P, K, sw, 0, 0);  // (contains the barrier)
-    int c = 0;
-    if (n < N) {
-        float x[GSD_IN], dist, h[GSD_HID];
-        gsd_input(feat, anchor, campos, vis ? vis[n] : n, x, dist);
-        gsd_layer1(sw, L, 0, x, h);
-#pragma unroll 1
-        for (int k = 0; k < K; k++) {
-            const float op = tanhf(gsd_out(sw, L, 0, k, h));
-            const bool keep = op > 0.0f;  // gaussian_renderer/__init__.py:59
-            neural_opacity[(size_t)n * K + k] = op;
-            mask[(size_t)n * K + k] = keep ? 1 : 0;
-            c += keep ? 1 : 0;
+    __shared__ float sw[(GSD_L1_ENTRIES + GSD_L2_ENTRIES) * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
+    gsd_stage<GSD_THREADS / 64, GSD_L1_ENTRIES + GSD_L2_ENTRIES>(sw, wave, lane, [&](int e) {
+        return e < GSD_L1_ENTRIES ? gsd_l1_entry(P.w1[0], P.b1[0], e, g, a)
+                                  : gsd_l2_entry(P.w2[0], P.b2[0], K, true, 0, 0, 0, 0, e - GSD_L1_ENTRIES, g, a);
+    });
+    const float* t1 = sw + lane;
+    const float* t2 = sw + GSD_L1_ENTRIES * 64 + lane;
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
+    const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
+    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+        if (threadIdx.x == 0) bs = 0u;
+        __syncthreads();  // (also orders the table writes above against the first reads)
+        uint32_t mine = 0;  // survivors among this lane's offsets
+#pragma unroll
+        for (int t = 0; t < GSD_GROUPS; t++) {
+            const int n = blk * GSD_THREADS + wave * 64 + t * 16 + a;
+            const bool live = n < N;
+            const int nn = live ? n : N - 1;
+            GsdIn X;
+            gsd_load_in(X, feat, anchor, cx, cy, cz, vis ? vis[nn] : nn, g);
+            gsd_v4 h[2];
+            gsd_mfma_l1(t1, X, h);
+            const gsd_v4 z = gsd_mfma_l2(t2, h);
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int k = 4 * r + g;
+                if (live && k < K) {
+                    const float op = tanhf(z[r]);
+                    const bool keep = op > 0.0f;  // gaussian_renderer/__init__.py:59
+                    neural_opacity[(size_t)n * K + k] = op;
+                    mask[(size_t)n * K + k] = keep ? 1 : 0;
+                    c += keep ? 1u : 0u;
+                }
+            }
+            mine += c;
+            c += (uint32_t)__shfl_xor((int)c, 16, 64);
+            c += (uint32_t)__shfl_xor((int)c, 32, 64);
+            if (g == 0 && live) count[n] = (uint8_t)c;
         }
-        count[n] = (uint8_t)c;
+        // survivors of this block of 256 anchors: the scan below only has to cover N/256 block totals
+        const uint32_t ws = gsr_wave_scan_add(mine);
+        if (lane == 63 && ws != 0u) atomicAdd(&bs, ws);
+        __syncthreads();
+        if (threadIdx.x == 0) block_sum[blk] = bs;
     }
-    // survivors of this block of 256 anchors: the scan below only has to cover N/256 block totals
-    const uint32_t ws = gsr_wave_scan_add((uint32_t)c);
-    if ((threadIdx.x & 63) == 63 && ws != 0u) atomicAdd(&bs, ws);
-    __syncthreads();
-    if (threadIdx.x == 0) block_sum[blockIdx.x] = bs;
 }
 
 // ---- exclusive scan of the block totals (single block of 1024; thread i owns a contiguous run of them) -------------
@@ -203,68 +373,145 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_first_kernel(int N, const uin
 }
 
 // ---- pass B: full decode, compacted output ------------------------------------------------------------------------
-__global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
+// Uncertainty, colour and covariance MLPs of 16 anchors per step on the matrix cores (layout above); lane (g, a) then owns
+// the offsets k = g, 4 + g, 8 + g of its anchor: activations, geometry and the stores of their output rows.  A wave's
+// unit of work is 64 consecutive anchors (four steps); 8 waves share one operand table.
+#define GSD_EMIT_THREADS 512
+#define GSD_EMIT_ENTRIES (3 * GSD_L1_ENTRIES + 10 * GSD_L2_ENTRIES)  // tiles: uncertainty | colour q = 0..2 | scale q | rotation q
+__global__ void __launch_bounds__(GSD_EMIT_THREADS) gsd_emit_kernel(
     int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
     const float* __restrict__ offsets /*[N,K,3]*/, const float* __restrict__ gscale /*[N,6]*/,
     const float* __restrict__ campos, const float* __restrict__ neural_opacity, const uint8_t* __restrict__ mask,
     const uint32_t* __restrict__ first, float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity, float* __restrict__ uncertainty,
     float* __restrict__ scaling, float* __restrict__ rot)
 {
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    const GsdLds L = gsd_stage_weights(P, K, sw, 1, 3);
-    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
-    if (n >= N) return;
-    const int a = vis ? vis[n] : n;  // visible-anchor gather (gaussian_renderer/__init__.py:25-28) folded in
-    float x[GSD_IN], dist, h[GSD_HID];
-    gsd_input(feat, anchor, campos, a, x, dist);
-    uint32_t keep = 0;
-    for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
-    if (keep == 0u) return;
-    const uint32_t row0 = first[n];
-    const float ax = anchor[3 * (size_t)a], ay = anchor[3 * (size_t)a + 1], az = anchor[3 * (size_t)a + 2];
-    float gs[6];
+    __shared__ float sw[GSD_EMIT_ENTRIES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
+    gsd_stage<GSD_EMIT_THREADS / 64, GSD_EMIT_ENTRIES>(sw, wave, lane, [&](int e) {
+        if (e < 3 * GSD_L1_ENTRIES) {
+            const int m = e / GSD_L1_ENTRIES;
+            return gsd_l1_entry(P.w1[m + 1], P.b1[m + 1], e - m * GSD_L1_ENTRIES, g, a);
+        }
+        const int t = (e - 3 * GSD_L1_ENTRIES) / GSD_L2_ENTRIES, j = (e - 3 * GSD_L1_ENTRIES) - t * GSD_L2_ENTRIES;
+        if (t == 0) return gsd_l2_entry(P.w2[1], P.b2[1], K, true, 0, 0, 0, 0, j, g, a);
+        if (t < 4) return gsd_l2_entry(P.w2[2], P.b2[2], K, false, t - 1, 3, 3, 0, j, g, a);
+        if (t < 7) return gsd_l2_entry(P.w2[3], P.b2[3], K, false, t - 4, 3, 7, 0, j, g, a);
+        return gsd_l2_entry(P.w2[3], P.b2[3], K, false, t - 7, 4, 7, 3, j, g, a);
+    });
+    __syncthreads();
+    const float* tl1 = sw + lane;
+    const float* tl2 = sw + 3 * GSD_L1_ENTRIES * 64 + lane;
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
+    // A wave walks groups of 16 anchors, group index = first + i * stride, with the NEXT group's inputs in flight while the
+    // current one is computed (the gather index two groups ahead): a wave's life is one chain of dependent round trips
+    // otherwise, and there are too few waves per SIMD to hide them behind each other.
+    struct In {  // raw loads only: nothing here is looked at before the group is computed
+        GsdRaw R;
+        float gs[6], nop[3], of[9];
+        uint32_t row0;
+    };
+    const int groups = (N + 15) / 16, stride = gridDim.x * (GSD_EMIT_THREADS / 64);
+    auto anchor_row = [&](int grp) {  // (group index clamped: the loads of a group past the end are issued and never used)
+        const int n = min(grp, groups - 1) * 16 + a;
+        const int nn = n < N ? n : N - 1;
+        return vis ? vis[nn] : nn;  // visible-anchor gather (gaussian_renderer/__init__.py:25-28) folded in
+    };
+    auto load = [&](In& I, int grp, int ai) {
+        const int n = min(grp, groups - 1) * 16 + a;
+        const int nn = n < N ? n : N - 1;
+        gsd_load_raw(I.R, feat, anchor, ai, g);
 #pragma unroll
-    for (int i = 0; i < 6; i++) gs[i] = gscale[6 * (size_t)a + i];
-
-    // opacity = neural_opacity[mask] (:63): copied from pass A, bit for bit; geometry of the offsets
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        if (!((keep >> k) & 1u)) continue;
-        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        opacity[r] = neural_opacity[(size_t)n * K + k];
-        const float* of = offsets + ((size_t)a * K + k) * 3;
-        xyz[3 * (size_t)r] = ax + of[0] * gs[0];       // :94-95
-        xyz[3 * (size_t)r + 1] = ay + of[1] * gs[1];
-        xyz[3 * (size_t)r + 2] = az + of[2] * gs[2];
-    }
-    gsd_layer1(sw, L, 1, x, h);
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        if (!((keep >> k) & 1u)) continue;
-        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        uncertainty[r] = gsd_sigmoid(gsd_out(sw, L, 1, k, h));
-    }
-    gsd_layer1(sw, L, 2, x, h);
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        if (!((keep >> k) & 1u)) continue;
-        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        for (int i = 0; i < 6; i++) I.gs[i] = gscale[6 * (size_t)ai + i];
+        I.row0 = first[nn];
 #pragma unroll
-        for (int c = 0; c < 3; c++) color[3 * (size_t)r + c] = gsd_sigmoid(gsd_out(sw, L, 2, 3 * k + c, h));
-    }
-    gsd_layer1(sw, L, 3, x, h);
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        if (!((keep >> k) & 1u)) continue;
-        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        float sr[7];
+        for (int q = 0; q < 3; q++) {
+            const int k = min(4 * q + g, K - 1);  // (clamped: the duplicate of a lane without a third offset is never used)
+            I.nop[q] = neural_opacity[(size_t)nn * K + k];
+            const float* of = offsets + ((size_t)ai * K + k) * 3;
+            I.of[3 * q] = of[0]; I.of[3 * q + 1] = of[1]; I.of[3 * q + 2] = of[2];
+        }
+    };
+    auto compute = [&](const In& I, int grp) {
+        const bool live = grp * 16 + a < N;
+        GsdIn X;
+        gsd_finish_in(X, I.R, cx, cy, cz, g);
+        uint32_t keep = 0;  // the lane's own offsets, then OR-ed over the anchor's four lanes
 #pragma unroll
-        for (int c = 0; c < 7; c++) sr[c] = gsd_out(sw, L, 3, 7 * k + c, h);
+        for (int q = 0; q < 3; q++)
+            if (live && 4 * q + g < K && I.nop[q] > 0.0f) keep |= 1u << (4 * q + g);  // = mask of pass A (:59)
+        keep |= (uint32_t)__shfl_xor((int)keep, 16, 64);
+        keep |= (uint32_t)__shfl_xor((int)keep, 32, 64);
+        uint32_t row[3];
+        bool on[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) scaling[3 * (size_t)r + c] = gs[3 + c] * gsd_sigmoid(sr[c]);  // :90
-        const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);  // F.normalize
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+#ifdef GSD_EXP_NOSTORE
+            on[q] = k < K - 1000 && ((keep >> k) & 1u);
+#else
+            on[q] = k < K && ((keep >> k) & 1u);
+#endif
+            row[q] = I.row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        }
+        // opacity = neural_opacity[mask] (:63): copied from pass A, bit for bit; geometry of the offsets
 #pragma unroll
-        for (int c = 0; c < 4; c++) rot[4 * (size_t)r + c] = sr[3 + c] / nrm;  // :91
+        for (int q = 0; q < 3; q++) {
+            if (!on[q]) continue;
+            const uint32_t r = row[q];
+            opacity[r] = I.nop[q];
+            xyz[3 * (size_t)r] = I.R.ax + I.of[3 * q] * I.gs[0];       // :94-95
+            xyz[3 * (size_t)r + 1] = I.R.ay + I.of[3 * q + 1] * I.gs[1];
+            xyz[3 * (size_t)r + 2] = I.R.az + I.of[3 * q + 2] * I.gs[2];
+        }
+        gsd_v4 h[2];
+        gsd_mfma_l1(tl1, X, h);
+        {
+            const gsd_v4 z = gsd_mfma_l2(tl2, h);  // register r = offset 4r + g: offset 4q + g sits in register q
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (on[q]) uncertainty[row[q]] = gsd_sigmoid(z[q]);
+        }
+        gsd_mfma_l1(tl1 + GSD_L1_ENTRIES * 64, X, h);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const gsd_v4 z = gsd_mfma_l2(tl2 + (1 + q) * GSD_L2_ENTRIES * 64, h);
+            if (on[q]) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) color[3 * (size_t)row[q] + c] = gsd_sigmoid(z[c]);
+            }
+        }
+        gsd_mfma_l1(tl1 + 2 * GSD_L1_ENTRIES * 64, X, h);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const gsd_v4 zs = gsd_mfma_l2(tl2 + (4 + q) * GSD_L2_ENTRIES * 64, h);
+            const gsd_v4 zr = gsd_mfma_l2(tl2 + (7 + q) * GSD_L2_ENTRIES * 64, h);
+            if (on[q]) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) scaling[3 * (size_t)row[q] + c] = I.gs[3 + c] * gsd_sigmoid(zs[c]);  // :90
+                const float nrm = fmaxf(sqrtf(zr[0] * zr[0] + zr[1] * zr[1] + zr[2] * zr[2] + zr[3] * zr[3]), 1e-12f);  // F.normalize
+                reinterpret_cast<float4*>(rot)[row[q]] = make_float4(zr[0] / nrm, zr[1] / nrm, zr[2] / nrm, zr[3] / nrm);  // :91
+            }
+        }
+    };
+    // Two input buffers in alternation: while a group is computed, the loads of the wave's next group are in flight into
+    // the other buffer (and the gather index of the one after that), untouched until their turn.
+    int gi = blockIdx.x * (GSD_EMIT_THREADS / 64) + wave;
+    if (gi >= groups) return;
+    In A, B;
+    int aiA = anchor_row(gi), aiB = anchor_row(gi + stride);
+    load(A, gi, aiA);
+    aiA = anchor_row(gi + 2 * stride);
+    for (;;) {
+        load(B, gi + stride, aiB);
+        aiB = anchor_row(gi + 3 * stride);
+        compute(A, gi);
+        gi += stride;
+        if (gi >= groups) break;
+        load(A, gi + stride, aiA);
+        aiA = anchor_row(gi + 3 * stride);
+        compute(B, gi);
+        gi += stride;
+        if (gi >= groups) break;
     }
 }
 
@@ -277,8 +524,27 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_emit_kernel(
 // all feature-major, so that the 64 anchors of a wave store 64 consecutive floats
 // One MLP per launch (template M): keeps the live state at input + hidden + d(hidden) registers, so several
 // waves fit per SIMD (the all-in-one version needed 256 VGPRs + 51 AGPRs and spilled SGPRs: one wave per SIMD).
+// On the matrix cores like the forward (layout above): recompute the hidden layer and the head's pre-activations of 16
+// anchors, turn the upstream gradients of the lane's own offsets into deltas dz (register r of a tile, exactly where the
+// forward product left z), and feed those registers straight back as the B operand of W2^T dz -> d(hidden): step (tile t,
+// component r) pairs k-group g with output rho(t, 4g + r), the A operand holds W2[rho(t, 4g + r)][16 jt + a].  d(hidden)
+// comes out in the layout of the hidden layer itself, so the ReLU mask is elementwise.  All four arrays are written
+// feature-major in 64-anchor chunks: a register of a tile is 4 rows x 16 consecutive anchors = four 64-byte runs.
+template <int M> struct GsdBwd {
+    static constexpr int NT = M < 2 ? 1 : (M == 2 ? 3 : 6);      // second-layer tiles
+    static constexpr int NC = M < 2 ? 3 : (M == 2 ? 9 : 21);     // (tile, component) pairs = k-steps of W2^T dz
+    static constexpr int W2T = GSD_L1_ENTRIES + NT * GSD_L2_ENTRIES;
+    static constexpr int ENTRIES = W2T + 2 * NC;
+    // tile t: head (M < 2) | colour q = t | scale q = t (t < 3), rotation q = t - 3
+    __device__ static constexpr int comps(int t) { return M < 2 ? 3 : (M == 2 ? 3 : (t < 3 ? 3 : 4)); }
+    __device__ static constexpr int q(int t) { return M == 3 && t >= 3 ? t - 3 : t; }
+    __device__ static constexpr int stride() { return M < 2 ? 1 : (M == 2 ? 3 : 7); }
+    __device__ static constexpr int first(int t) { return M == 3 && t >= 3 ? 3 : 0; }
+    __device__ static constexpr int pair0(int t) { return M == 3 ? (t < 3 ? 3 * t : 9 + 4 * (t - 3)) : 3 * t; }  // first (tile, component) pair of tile t
+};
+#define GSD_BWD_THREADS 512
 template <int M>
-__global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
+__global__ void __launch_bounds__(GSD_BWD_THREADS) gsd_backward_mlp_kernel(
     int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
     const float* __restrict__ gscale, const float* __restrict__ campos, const uint8_t* __restrict__ mask,
     const uint32_t* __restrict__ first, const float* __restrict__ g_color, const float* __restrict__ g_opacity,
@@ -286,153 +552,272 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_backward_mlp_kernel(
     float* __restrict__ d_gscale, float* __restrict__ D2, float* __restrict__ D1, float* __restrict__ Hout,
     float* __restrict__ Xout)
 {
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    const GsdLds L = gsd_stage_weights(P, K, sw, M, M);
-    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
-    if (n >= N) return;
-    const int a = vis ? vis[n] : n;
-    float x[GSD_IN], dist, h[GSD_HID], dh[GSD_HID];
-    gsd_input(feat, anchor, campos, a, x, dist);
-    if (M == 0) {
-#pragma unroll
-        for (int i = 0; i < GSD_IN; i++) Xout[GSD_AT(GSD_IN, i, n)] = x[i];
-    }
-    uint32_t keep = 0;
-    for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
-    const uint32_t row0 = first[n];
-    float gs3[3] = { 0, 0, 0 }, dgs3[3] = { 0, 0, 0 };
-    if (M == 3) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) gs3[c] = gscale[6 * (size_t)a + 3 + c];
-    }
-    gsd_layer1(sw, L, M, x, h);
-#pragma unroll
-    for (int j = 0; j < GSD_HID; j++) { Hout[GSD_AT(128, M * 32 + j, n)] = h[j]; dh[j] = 0.f; }
-    constexpr int per = M == 0 || M == 1 ? 1 : (M == 2 ? 3 : 7);
+    typedef GsdBwd<M> C;
+    __shared__ float sw[C::ENTRIES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
+    gsd_stage<GSD_BWD_THREADS / 64, C::ENTRIES>(sw, wave, lane, [&](int e) {
+        if (e < GSD_L1_ENTRIES) return gsd_l1_entry(P.w1[M], P.b1[M], e, g, a);
+        if (e < C::W2T) {
+            const int t = (e - GSD_L1_ENTRIES) / GSD_L2_ENTRIES, j = (e - GSD_L1_ENTRIES) - t * GSD_L2_ENTRIES;
+            return gsd_l2_entry(P.w2[M], P.b2[M], K, M < 2, C::q(t), C::comps(t), C::stride(), C::first(t), j, g, a);
+        }
+        // W2^T operand of k-step (tile t, component r), hidden tile jt: W2[rho(t, 4g + r)][16 jt + a]
+        const int pr = (e - C::W2T) >> 1, jt = (e - C::W2T) & 1;
+        int t = 0;
+        for (int u = 1; u < C::NT; u++)
+            if (pr >= C::pair0(u)) t = u;
+        const int r = pr - C::pair0(t);
+        const int k = M < 2 ? 4 * r + g : 4 * C::q(t) + g;
+        const int o = M < 2 ? k : k * C::stride() + C::first(t) + r;
+        return k < K ? P.w2[M][o * GSD_HID + 16 * jt + a] : 0.0f;
+    });
+    __syncthreads();
+    const float* tl1 = sw + lane;
+    const float* tl2 = sw + GSD_L1_ENTRIES * 64 + lane;
+    const float* tw2t = sw + C::W2T * 64 + lane;
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
     const int out_base = M == 0 ? 0 : (M == 1 ? K : (M == 2 ? 2 * K : 5 * K));
+    const int groups = (N + 15) / 16, stride = gridDim.x * (GSD_BWD_THREADS / 64);
 #pragma unroll 1
-    for (int k = 0; k < K; k++) {
-        const bool on = (keep >> k) & 1u;
-        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        float dz[per];  // dL/d(pre-activation) of this offset's outputs
+    for (int grp = blockIdx.x * (GSD_BWD_THREADS / 64) + wave; grp < groups; grp += stride) {
+        const int n = grp * 16 + a;
+        const bool live = n < N;
+        const int nn = live ? n : N - 1;
+        const int ai = vis ? vis[nn] : nn;
+        GsdRaw R;
+        gsd_load_raw(R, feat, anchor, ai, g);
+        uint32_t keep = 0;  // the lane's own offsets, then OR-ed over the anchor's four lanes
 #pragma unroll
-        for (int c = 0; c < per; c++) dz[c] = 0.f;
-        if (on) {
-            if (M == 0) {  // opacity = tanh(z)
-                const float t = tanhf(gsd_out(sw, L, 0, k, h));
-                dz[0] = g_opacity[r] * (1.0f - t * t);
-            } else if (M == 1) {  // sigmoid
-                const float sg = gsd_sigmoid(gsd_out(sw, L, 1, k, h));
-                dz[0] = g_unc[r] * sg * (1.0f - sg);
-            } else if (M == 2) {
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            if (live && k < K && mask[(size_t)nn * K + k]) keep |= 1u << k;
+        }
+        const uint32_t row0 = first[nn];
+        float gs3[3] = { 0.f, 0.f, 0.f };
+        if (M == 3) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) gs3[c] = gscale[6 * (size_t)ai + 3 + c];
+        }
+        keep |= (uint32_t)__shfl_xor((int)keep, 16, 64);
+        keep |= (uint32_t)__shfl_xor((int)keep, 32, 64);
+        uint32_t row[3];
+        bool on[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            on[q] = k < K && ((keep >> k) & 1u);
+            row[q] = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        }
+        // upstream gradients of the lane's rows (requested before the products)
+        float up[3][7];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int c = 0; c < 7; c++) up[q][c] = 0.f;
+            if (on[q]) {
+                const size_t r = row[q];
+                if (M == 0) up[q][0] = g_opacity[r];
+                if (M == 1) up[q][0] = g_unc[r];
+                if (M == 2) { up[q][0] = g_color[3 * r]; up[q][1] = g_color[3 * r + 1]; up[q][2] = g_color[3 * r + 2]; }
+                if (M == 3) {
+                    up[q][0] = g_scaling[3 * r]; up[q][1] = g_scaling[3 * r + 1]; up[q][2] = g_scaling[3 * r + 2];
+                    const float4 gr = reinterpret_cast<const float4*>(g_rot)[r];
+                    up[q][3] = gr.x; up[q][4] = gr.y; up[q][5] = gr.z; up[q][6] = gr.w;
+                }
+            }
+        }
+        GsdIn X;
+        gsd_finish_in(X, R, cx, cy, cz, g);
+        if (M == 0 && live) {  // the MLP input, feature-major (feature map of the first layer)
+#pragma unroll
+            for (int s = 0; s < 8; s++) Xout[GSD_AT(GSD_IN, s < 4 ? 4 * g + s : 12 + 4 * g + s, n)] = X.f[s];
+            Xout[GSD_AT(GSD_IN, 32 + g, n)] = X.v;
+        }
+        gsd_v4 h[2];
+        gsd_mfma_l1(tl1, X, h);
+        if (live) {
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Hout[GSD_AT(128, M * 32 + 16 * jt + 4 * g + r, n)] = h[jt][r];
+        }
+        // deltas of the second layer, tile by tile
+        gsd_v4 dz[C::NT];
+        float dgs3[3] = { 0.f, 0.f, 0.f };
+        if (M < 2) {
+            const gsd_v4 z = gsd_mfma_l2(tl2, h);  // register r = offset 4r + g
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                float d = 0.f;
+                if (on[q]) {
+                    if (M == 0) { const float t = tanhf(z[q]); d = up[q][0] * (1.0f - t * t); }       // opacity = tanh(z)
+                    else { const float sg = gsd_sigmoid(z[q]); d = up[q][0] * sg * (1.0f - sg); }   // sigmoid
+                }
+                dz[0][q] = d;
+            }
+            dz[0][3] = 0.f;
+        } else if (M == 2) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const gsd_v4 z = gsd_mfma_l2(tl2 + q * GSD_L2_ENTRIES * 64, h);
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const float sg = gsd_sigmoid(gsd_out(sw, L, 2, 3 * k + c, h));
-                    dz[c % per] = g_color[3 * (size_t)r + c] * sg * (1.0f - sg);
+                    const float sg = gsd_sigmoid(z[c]);
+                    dz[q][c] = on[q] ? up[q][c] * sg * (1.0f - sg) : 0.f;
                 }
-            } else {
-                float sr[7];
+                dz[q][3] = 0.f;
+            }
+        } else {
 #pragma unroll
-                for (int c = 0; c < 7; c++) {
-                    sr[c] = gsd_out(sw, L, 3, 7 * k + c, h);
-                    __builtin_amdgcn_sched_barrier(0);  // one weight row in flight at a time: 7 x 32 live scalars do not fit
+            for (int q = 0; q < 3; q++) {
+                const gsd_v4 zs = gsd_mfma_l2(tl2 + q * GSD_L2_ENTRIES * 64, h);
+                const gsd_v4 zr = gsd_mfma_l2(tl2 + (3 + q) * GSD_L2_ENTRIES * 64, h);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {  // scaling = gs[3+c] * sigmoid(z)
+                    const float sg = gsd_sigmoid(zs[c]);
+                    dz[q][c] = on[q] ? up[q][c] * gs3[c] * sg * (1.0f - sg) : 0.f;
+                    dgs3[c] += on[q] ? up[q][c] * sg : 0.f;
                 }
+                dz[q][3] = 0.f;
+                // rot = v / max(|v|, eps): d v = (g - rot (rot . g)) / |v|
+                const float nrm = fmaxf(sqrtf(zr[0] * zr[0] + zr[1] * zr[1] + zr[2] * zr[2] + zr[3] * zr[3]), 1e-12f);
+                float rt[4], dot = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {  // scaling = gs[3+c] * sigmoid(sr[c])
-                    const float sg = gsd_sigmoid(sr[c]), g = g_scaling[3 * (size_t)r + c];
-                    dz[c % per] = g * gs3[c] * sg * (1.0f - sg);
-                    dgs3[c] += g * sg;
-                }
-                // rot = q / max(|q|, eps): d q = (g - rot (rot . g)) / |q|
-                const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);
-                float gq[4], dot = 0.f;
+                for (int c = 0; c < 4; c++) { rt[c] = zr[c] / nrm; dot += up[q][3 + c] * rt[c]; }
 #pragma unroll
-                for (int c = 0; c < 4; c++) { gq[c] = g_rot[4 * (size_t)r + c]; dot += gq[c] * (sr[3 + c] / nrm); }
-#pragma unroll
-                for (int c = 0; c < 4; c++) dz[(3 + c) % per] = (gq[c] - (sr[3 + c] / nrm) * dot) / nrm;
+                for (int c = 0; c < 4; c++) dz[3 + q][c] = on[q] ? (up[q][3 + c] - rt[c] * dot) / nrm : 0.f;
             }
         }
+        // D2 rows and d(hidden) = W2^T dz
+        gsd_v4 dh[2] = { {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f} };
 #pragma unroll
-        for (int c = 0; c < per; c++) {
-            const int o = per * k + c;
-            D2[GSD_AT(12 * K, out_base + o, n)] = dz[c];
-            const float* w = sw + L.w2[M] + o * GSD_HID;
+        for (int t = 0; t < C::NT; t++) {
 #pragma unroll
-            for (int j = 0; j < GSD_HID; j += 2) {  // two hidden units per packed FMA
-                gsd_f2 d = {dh[j], dh[j + 1]};
-                d = gsd_fma2(*reinterpret_cast<const gsd_f2*>(w + j), (gsd_f2){dz[c], dz[c]}, d);
-                dh[j] = d.x; dh[j + 1] = d.y;
+            for (int r = 0; r < C::comps(t); r++) {
+                const int k = M < 2 ? 4 * r + g : 4 * C::q(t) + g;
+                const int o = M < 2 ? k : k * C::stride() + C::first(t) + r;
+                if (live && k < K) D2[GSD_AT(12 * K, out_base + o, n)] = dz[t][r];
+                const int pr = C::pair0(t) + r;
+                dh[0] = GSD_MFMA(tw2t[(2 * pr) * 64], dz[t][r], dh[0]);
+                dh[1] = GSD_MFMA(tw2t[(2 * pr + 1) * 64], dz[t][r], dh[1]);
             }
-            if (per > 1) __builtin_amdgcn_sched_barrier(0);
         }
-    }
+        if (live) {
 #pragma unroll
-    for (int j = 0; j < GSD_HID; j++) D1[GSD_AT(128, M * 32 + j, n)] = h[j] > 0.0f ? dh[j] : 0.0f;  // through the ReLU
-    if (M == 3) {
+            for (int jt = 0; jt < 2; jt++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) d_gscale[6 * (size_t)a + 3 + c] = dgs3[c];
+                for (int r = 0; r < 4; r++)
+                    D1[GSD_AT(128, M * 32 + 16 * jt + 4 * g + r, n)] = h[jt][r] > 0.0f ? dh[jt][r] : 0.0f;  // through the ReLU
+        }
+        if (M == 3) {  // d grid_scaling[3:6]: over the anchor's offsets = over its four lanes
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dgs3[c] += __shfl_xor(dgs3[c], 16, 64);
+                dgs3[c] += __shfl_xor(dgs3[c], 32, 64);
+            }
+            if (live && g == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) d_gscale[6 * (size_t)ai + 3 + c] = dgs3[c];
+            }
+        }
     }
 }
 
-// dL/d(input) = sum over the four MLPs of W1^T d(pre1) (read back feature-major, coalesced), then feature / anchor
-// gradients; also the geometry part: xyz = anchor + offset * gs[0:3].
-__global__ void __launch_bounds__(GSD_THREADS) gsd_backward_input_kernel(
+// dL/d(input) = sum over the four MLPs of W1^T d(pre1), then feature / anchor gradients; also the geometry part:
+// xyz = anchor + offset * gs[0:3].  On the matrix cores: rows = the 36 inputs (three tiles), columns = 16 anchors, K = the
+// 4 x 32 first-layer deltas, read back from D1 (step s of MLP m: lane (g, a) takes row 32 m + 4 s + g of its anchor:
+// four 64-byte runs per load).  Lane (g, a) ends up with d(input) 4g .. 4g+3, 16 + 4g .. 16 + 4g+3 of its anchor (two
+// 16-byte stores into d_feat) and lane (0, a) with the view / distance gradients; the offsets k = g, 4 + g, 8 + g of
+// the anchor are the lane's share of the geometry part.
+#define GSD_INK_ENTRIES (4 * 3 * 8)
+__global__ void __launch_bounds__(GSD_BWD_THREADS) gsd_backward_input_kernel(
     int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
     const uint8_t* __restrict__ mask, const uint32_t* __restrict__ first, const float* __restrict__ g_xyz,
     const float* __restrict__ D1, float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_offsets,
     float* __restrict__ d_gscale)
 {
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    const GsdLds L = gsd_stage_weights(P, K, sw, 0, 3, true);
-    const int n = blockIdx.x * GSD_THREADS + threadIdx.x;
-    if (n >= N) return;
-    const int a = vis ? vis[n] : n;
-    float dx[GSD_IN];
-#pragma unroll
-    for (int i = 0; i < GSD_IN; i++) dx[i] = 0.f;
+    __shared__ float sw[GSD_INK_ENTRIES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
+    gsd_stage<GSD_BWD_THREADS / 64, GSD_INK_ENTRIES>(sw, wave, lane, [&](int e) {
+        // entry (m, it, s): W1_m[4 s + g][16 it + a] (input rows beyond 35: zero)
+        const int m = e / 24, it = (e - 24 * m) >> 3, st = e & 7, i = 16 * it + a;
+        return i < GSD_IN ? P.w1[m][(4 * st + g) * GSD_IN + i] : 0.0f;
+    });
+    __syncthreads();
+    const float* tw = sw + lane;
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
+    const int groups = (N + 15) / 16, stride = gridDim.x * (GSD_BWD_THREADS / 64);
 #pragma unroll 1
-    for (int m = 0; m < 4; m++) {
-        const float* w1 = sw + L.w1[m];
-#pragma unroll 4
-        for (int j = 0; j < GSD_HID; j++) {
-            const float d1 = D1[GSD_AT(128, m * 32 + j, n)];
+    for (int grp = blockIdx.x * (GSD_BWD_THREADS / 64) + wave; grp < groups; grp += stride) {
+        const int n = grp * 16 + a;
+        const bool live = n < N;
+        const int nn = live ? n : N - 1;
+        const int ai = vis ? vis[nn] : nn;
+        float d1[32];
 #pragma unroll
-            for (int i = 0; i < GSD_IN; i += 2) {  // two inputs per packed FMA
-                gsd_f2 d = {dx[i], dx[i + 1]};
-                d = gsd_fma2(*reinterpret_cast<const gsd_f2*>(w1 + j * GSD_IN + i), (gsd_f2){d1, d1}, d);
-                dx[i] = d.x; dx[i + 1] = d.y;
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int st = 0; st < 8; st++) d1[8 * m + st] = D1[GSD_AT(128, 32 * m + 4 * st + g, nn)];
+        uint32_t keep = 0;  // the lane's own offsets, then OR-ed over the anchor's four lanes
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            if (live && k < K && mask[(size_t)nn * K + k]) keep |= 1u << k;
+        }
+        const uint32_t row0 = first[nn];
+        const float ax = anchor[3 * (size_t)ai], ay = anchor[3 * (size_t)ai + 1], az = anchor[3 * (size_t)ai + 2];
+        float gs[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) gs[c] = gscale[6 * (size_t)ai + c];
+        keep |= (uint32_t)__shfl_xor((int)keep, 16, 64);
+        keep |= (uint32_t)__shfl_xor((int)keep, 32, 64);
+        // geometry of the lane's offsets
+        float da[3] = { 0.f, 0.f, 0.f }, dgs[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            if (!live || k >= K) continue;
+            float* dof = d_offsets + ((size_t)ai * K + k) * 3;
+            if (!((keep >> k) & 1u)) { dof[0] = 0.f; dof[1] = 0.f; dof[2] = 0.f; continue; }
+            const size_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+            const float* of = offsets + ((size_t)ai * K + k) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float gu = g_xyz[3 * r + c];
+                da[c] += gu; dof[c] = gu * gs[c]; dgs[c] += gu * of[c];
+            }
+        }
+        gsd_v4 dx[3] = { {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f} };
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int st = 0; st < 8; st++)
+#pragma unroll
+                for (int it = 0; it < 3; it++) dx[it] = GSD_MFMA(tw[(24 * m + 8 * it + st) * 64], d1[8 * m + st], dx[it]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            da[c] += __shfl_xor(da[c], 16, 64); da[c] += __shfl_xor(da[c], 32, 64);
+            dgs[c] += __shfl_xor(dgs[c], 16, 64); dgs[c] += __shfl_xor(dgs[c], 32, 64);
+        }
+        if (live) {
+            float4* df = reinterpret_cast<float4*>(d_feat + (size_t)ai * GSD_F + 4 * g);
+            df[0] = make_float4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
+            df[4] = make_float4(dx[1][0], dx[1][1], dx[1][2], dx[1][3]);
+            if (g == 0) {
+                // view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist); dx[2] = d(view, dist)
+                const float vx = ax - cx, vy = ay - cy, vz = az - cz;
+                const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+                const float ux = vx / dist, uy = vy / dist, uz = vz / dist;
+                const float gdot = dx[2][0] * ux + dx[2][1] * uy + dx[2][2] * uz;
+                d_anchor[3 * (size_t)ai] = da[0] + (dx[2][0] - ux * gdot) / dist + dx[2][3] * ux;
+                d_anchor[3 * (size_t)ai + 1] = da[1] + (dx[2][1] - uy * gdot) / dist + dx[2][3] * uy;
+                d_anchor[3 * (size_t)ai + 2] = da[2] + (dx[2][2] - uz * gdot) / dist + dx[2][3] * uz;
+#pragma unroll
+                for (int c = 0; c < 3; c++) d_gscale[6 * (size_t)ai + c] = dgs[c];
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < GSD_F; i++) d_feat[(size_t)a * GSD_F + i] = dx[i];
-    // view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist)
-    const float vx = anchor[3 * (size_t)a] - campos[0], vy = anchor[3 * (size_t)a + 1] - campos[1], vz = anchor[3 * (size_t)a + 2] - campos[2];
-    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-    const float ux = vx / dist, uy = vy / dist, uz = vz / dist;
-    const float gdot = dx[32] * ux + dx[33] * uy + dx[34] * uz;
-    float da[3] = { (dx[32] - ux * gdot) / dist + dx[35] * ux, (dx[33] - uy * gdot) / dist + dx[35] * uy,
-                    (dx[34] - uz * gdot) / dist + dx[35] * uz };
-    uint32_t keep = 0;
-    for (int k = 0; k < K; k++) keep |= mask[(size_t)n * K + k] ? (1u << k) : 0u;
-    const uint32_t row0 = first[n];
-    float gs[3], dgs[3] = { 0, 0, 0 };
-#pragma unroll
-    for (int c = 0; c < 3; c++) gs[c] = gscale[6 * (size_t)a + c];
-    for (int k = 0; k < K; k++) {
-        float* dof = d_offsets + ((size_t)a * K + k) * 3;
-        if (!((keep >> k) & 1u)) { dof[0] = dof[1] = dof[2] = 0.f; continue; }
-        const uint32_t r = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
-        const float* of = offsets + ((size_t)a * K + k) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float g = g_xyz[3 * (size_t)r + c];
-            da[c] += g; dof[c] = g * gs[c]; dgs[c] += g * of[c];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) { d_anchor[3 * (size_t)a + c] = da[c]; d_gscale[6 * (size_t)a + c] = dgs[c]; }
 }
 
 // ---- weight gradients: D @ A^T over the anchors, on the f32 matrix cores ------------------------------------------------
@@ -640,6 +1025,7 @@ __global__ void __launch_bounds__(256) gsd_weight_grad_finish_kernel(int K, int 
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
+#define GSD_MLP_GRID 256  // CUs: the matrix-core MLP kernels launch a few workgroups per CU, each with its operand table in LDS
 static GsdMlps gsd_pack(const float* const* w)  // w[16] = {w1[4], b1[4], w2[4], b2[4]}
 {
     GsdMlps P;
@@ -653,7 +1039,7 @@ hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int
 {
     if (N <= 0) return hipSuccess;
     const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
-    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb), dim3(GSD_THREADS), GSD_LDS_FLOATS(K) * sizeof(float), stream, N, K, gsd_pack(weights), vis, feat, anchor, campos,
+    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb < 8 * GSD_MLP_GRID ? nb : 8 * GSD_MLP_GRID), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), vis, feat, anchor, campos,
                        neural_opacity, mask, count, block_scratch);
     hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, block_scratch, total);
     hipLaunchKernelGGL(gsd_first_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, count, block_scratch, first);
@@ -666,7 +1052,10 @@ hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int3
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsd_emit_kernel, dim3((N + GSD_THREADS - 1) / GSD_THREADS), dim3(GSD_THREADS), GSD_LDS_FLOATS(K) * sizeof(float), stream, N, K,
+    // persistent waves: 2 per SIMD (one workgroup of 8 per CU), each walks ~6 groups of 16 anchors at 200k anchors
+    static const int emit_grid = getenv("GSD_EMIT_GRID") ? atoi(getenv("GSD_EMIT_GRID")) : GSD_MLP_GRID;
+    const int nb = ((N + 15) / 16 + GSD_EMIT_THREADS / 64 - 1) / (GSD_EMIT_THREADS / 64);
+    hipLaunchKernelGGL(gsd_emit_kernel, dim3(nb < emit_grid ? nb : emit_grid), dim3(GSD_EMIT_THREADS), 0, stream, N, K,
                        gsd_pack(weights), vis, feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
                        opacity, uncertainty, scaling, rot);
     return hipGetLastError();
@@ -680,14 +1069,15 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
                                hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
-    const dim3 grid((N + GSD_THREADS - 1) / GSD_THREADS), block(GSD_THREADS);
     const GsdMlps P = gsd_pack(weights);
+    static const int bwd_grid = getenv("GSD_BWD_GRID") ? atoi(getenv("GSD_BWD_GRID")) : 2 * GSD_MLP_GRID;
+    const int ngrp = ((N + 15) / 16 + GSD_BWD_THREADS / 64 - 1) / (GSD_BWD_THREADS / 64);
 #define GSD_BWD(M)                                                                                                          \
-    hipLaunchKernelGGL(gsd_backward_mlp_kernel<M>, grid, block, GSD_LDS_FLOATS(K) * sizeof(float), stream, N, K, P, vis, feat, anchor, gscale, campos, mask,  \
+    hipLaunchKernelGGL(gsd_backward_mlp_kernel<M>, dim3(ngrp < bwd_grid ? ngrp : bwd_grid), dim3(GSD_BWD_THREADS), 0, stream, N, K, P, vis, feat, anchor, gscale, campos, mask,  \
                        first, g_color, g_opacity, g_unc, g_scaling, g_rot, d_gscale, D2, D1, H, X)
     GSD_BWD(0); GSD_BWD(1); GSD_BWD(2); GSD_BWD(3);
 #undef GSD_BWD
-    hipLaunchKernelGGL(gsd_backward_input_kernel, grid, block, 4 * GSD_HID * GSD_IN * sizeof(float), stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
+    hipLaunchKernelGGL(gsd_backward_input_kernel, dim3(ngrp < bwd_grid ? ngrp : bwd_grid), dim3(GSD_BWD_THREADS), 0, stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
                        first, g_xyz, D1, d_feat, d_anchor, d_offsets, d_gscale);
     return hipGetLastError();
 }
