@@ -580,6 +580,28 @@ extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, co
     return GSR_OK;
 }
 
+extern "C" int gsr_decode_backward_fused(int N, int K, const float* const* weights, const int32_t* visible, const float* feat,
+                                         const float* anchor, const float* offsets, const float* grid_scaling, const float* campos,
+                                         const uint8_t* mask, const uint32_t* first, const float* g_xyz, const float* g_color,
+                                         const float* g_opacity, const float* g_uncertainty, const float* g_scaling,
+                                         const float* g_rot, float* d_feat, float* d_anchor, float* d_offsets,
+                                         float* d_grid_scaling, void* workspace, float* const* grads16, void* stream)
+{
+    int rc = gsr_check_decode(N, K, weights);
+    if (rc) return rc;
+    if (!workspace || !grads16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: workspace / grads16 is NULL");
+    for (int i = 0; i < 16; i++)
+        if (!grads16[i]) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: grads16[%d] is NULL", i);
+    if (N > 0 && (!feat || !anchor || !offsets || !grid_scaling || !campos || !mask || !first || !d_feat || !d_anchor || !d_offsets ||
+                  !d_grid_scaling))
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    if (!campos) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: campos is NULL");
+    GSR_HIP(gsd_launch_backward_fused(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
+                                      g_opacity, g_uncertainty, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_grid_scaling,
+                                      workspace, grads16, (hipStream_t)stream), "decode backward");
+    return GSR_OK;
+}
+
 extern "C" int gsr_decode_ld(int N) { return gsd_leading_dim(N > 0 ? N : 0); }
 extern "C" size_t gsr_decode_weight_grad_workspace_bytes(void) { return gsd_weight_grad_workspace_bytes(); }
 

@@ -453,50 +453,56 @@ __global__ void __launch_bounds__(GSD_EMIT_THREADS) gsd_emit_kernel(
 #endif
             row[q] = I.row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
         }
-        // opacity = neural_opacity[mask] (:63): copied from pass A, bit for bit; geometry of the offsets
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if (!on[q]) continue;
-            const uint32_t r = row[q];
-            opacity[r] = I.nop[q];
-            xyz[3 * (size_t)r] = I.R.ax + I.of[3 * q] * I.gs[0];       // :94-95
-            xyz[3 * (size_t)r + 1] = I.R.ay + I.of[3 * q + 1] * I.gs[1];
-            xyz[3 * (size_t)r + 2] = I.R.az + I.of[3 * q + 2] * I.gs[2];
-        }
+        // The products and the activations of all three heads run branch-free (one basic block: the scheduler can put the
+        // activations of one tile into the shadow of the next tile's matrix-core steps); the stores of the lane's up to
+        // three surviving rows follow at the end.
         gsd_v4 h[2];
+        float unc[3], col[3][3], scl[3][3];
+        float4 rt[3];
         gsd_mfma_l1(tl1, X, h);
         {
             const gsd_v4 z = gsd_mfma_l2(tl2, h);  // register r = offset 4r + g: offset 4q + g sits in register q
 #pragma unroll
-            for (int q = 0; q < 3; q++)
-                if (on[q]) uncertainty[row[q]] = gsd_sigmoid(z[q]);
+            for (int q = 0; q < 3; q++) unc[q] = gsd_sigmoid(z[q]);
         }
         gsd_mfma_l1(tl1 + GSD_L1_ENTRIES * 64, X, h);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const gsd_v4 z = gsd_mfma_l2(tl2 + (1 + q) * GSD_L2_ENTRIES * 64, h);
-            if (on[q]) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) color[3 * (size_t)row[q] + c] = gsd_sigmoid(z[c]);
-            }
+            for (int c = 0; c < 3; c++) col[q][c] = gsd_sigmoid(z[c]);
         }
         gsd_mfma_l1(tl1 + 2 * GSD_L1_ENTRIES * 64, X, h);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const gsd_v4 zs = gsd_mfma_l2(tl2 + (4 + q) * GSD_L2_ENTRIES * 64, h);
             const gsd_v4 zr = gsd_mfma_l2(tl2 + (7 + q) * GSD_L2_ENTRIES * 64, h);
-            if (on[q]) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) scaling[3 * (size_t)row[q] + c] = I.gs[3 + c] * gsd_sigmoid(zs[c]);  // :90
-                const float nrm = fmaxf(sqrtf(zr[0] * zr[0] + zr[1] * zr[1] + zr[2] * zr[2] + zr[3] * zr[3]), 1e-12f);  // F.normalize
-                reinterpret_cast<float4*>(rot)[row[q]] = make_float4(zr[0] / nrm, zr[1] / nrm, zr[2] / nrm, zr[3] / nrm);  // :91
-            }
+            for (int c = 0; c < 3; c++) scl[q][c] = I.gs[3 + c] * gsd_sigmoid(zs[c]);  // :90
+            const float nrm = fmaxf(sqrtf(zr[0] * zr[0] + zr[1] * zr[1] + zr[2] * zr[2] + zr[3] * zr[3]), 1e-12f);  // F.normalize
+            rt[q] = make_float4(zr[0] / nrm, zr[1] / nrm, zr[2] / nrm, zr[3] / nrm);  // :91
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (!on[q]) continue;
+            const size_t r = row[q];
+            opacity[r] = I.nop[q];  // = neural_opacity[mask] (:63), bit for bit
+            xyz[3 * r] = I.R.ax + I.of[3 * q] * I.gs[0];       // :94-95
+            xyz[3 * r + 1] = I.R.ay + I.of[3 * q + 1] * I.gs[1];
+            xyz[3 * r + 2] = I.R.az + I.of[3 * q + 2] * I.gs[2];
+            uncertainty[r] = unc[q];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { color[3 * r + c] = col[q][c]; scaling[3 * r + c] = scl[q][c]; }
+            reinterpret_cast<float4*>(rot)[r] = rt[q];
         }
     };
     // Two input buffers in alternation: while a group is computed, the loads of the wave's next group are in flight into
     // the other buffer (and the gather index of the one after that), untouched until their turn.
     int gi = blockIdx.x * (GSD_EMIT_THREADS / 64) + wave;
     if (gi >= groups) return;
+#ifdef GSD_EXP_DESYNC
+    if (wave >= 4) for (int i = 0; i < GSD_EXP_DESYNC; i++) __builtin_amdgcn_s_sleep(127);
+#endif
     In A, B;
     int aiA = anchor_row(gi), aiB = anchor_row(gi + stride);
     load(A, gi, aiA);
@@ -1024,6 +1030,375 @@ __global__ void __launch_bounds__(256) gsd_weight_grad_finish_kernel(int K, int 
     }
 }
 
+// ---- the whole backward in one persistent kernel ---------------------------------------------------------------------------
+// One wave per SIMD walks groups of 16 anchors through all four MLPs and keeps EVERYTHING it accumulates in registers:
+// the input gradients of the group (W1^T d(pre1) over the four MLPs) and, over all of its groups, the 16 weight / bias
+// gradients.  Nothing per-anchor goes to HBM but the outputs themselves (no delta / activation arrays, no second pass).
+// The weight gradients need the ANCHORS as the reduction dimension of the matrix-core product, gW[o][j] = sum_a dz[o][a]
+// h[j][a], while the layer products leave anchors along the columns: a 16 x 16 tile is turned through a per-wave LDS
+// buffer (row stride 20 floats; written as four rows per lane group, read back as 16 bytes = 4 anchors per lane, one
+// register per k-step) -- for the deltas as the A operand, for the hidden layer / the input as the B operand.
+//   table (entries of 64 lane values): first layers 4 x 26 | second-layer tiles 11 x 12 (opacity, uncertainty, colour q,
+//   scale q, rotation q) | W2^T operands 36 (tile, component) pairs x 2 hidden tiles | W1^T operands 4 x 3 input tiles x 8
+#define GSD_FB_THREADS 256
+#define GSD_FB_L2 (4 * GSD_L1_ENTRIES)
+#define GSD_FB_W2T (GSD_FB_L2 + 11 * GSD_L2_ENTRIES)
+#define GSD_FB_W1T (GSD_FB_W2T + 2 * 36)
+#define GSD_FB_ENTRIES (GSD_FB_W1T + 4 * 24)
+#define GSD_TS 20                                   // row stride of the transposition buffers
+#define GSD_FB_WAVEBUF ((48 + 32 + 16) * GSD_TS)    // per wave: input rows | hidden rows | one 16-row scratch tile
+#define GSD_FB_LDS_FLOATS (GSD_FB_ENTRIES * 64 + (GSD_FB_THREADS / 64) * GSD_FB_WAVEBUF)
+struct GsdTile { int mlp, head, q, comps, stride, first, pair0; };
+__host__ __device__ constexpr GsdTile gsd_tile(int t)
+{
+    return t == 0 ? GsdTile{0, 1, 0, 3, 1, 0, 0}
+         : t == 1 ? GsdTile{1, 1, 0, 3, 1, 0, 3}
+         : t < 5  ? GsdTile{2, 0, t - 2, 3, 3, 0, 6 + 3 * (t - 2)}
+         : t < 8  ? GsdTile{3, 0, t - 5, 3, 7, 0, 15 + 3 * (t - 5)}
+                  : GsdTile{3, 0, t - 8, 4, 7, 3, 24 + 4 * (t - 8)};
+}
+__host__ __device__ constexpr int gsd_tile0(int m) { return m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 2 : 5; }   // first tile of MLP m
+__host__ __device__ constexpr int gsd_ntiles(int m) { return m < 2 ? 1 : m == 2 ? 3 : 6; }
+// row of the D2 numbering (opacity K | uncertainty K | colour 3K | cov 7K) that tile t carries in row 4g + r, -1 if none
+__device__ __forceinline__ int gsd_tile_row(int t, int g, int r, int K)
+{
+    const GsdTile T = gsd_tile(t);
+    const int base = T.mlp == 0 ? 0 : T.mlp == 1 ? K : T.mlp == 2 ? 2 * K : 5 * K;
+    const int k = T.head ? 4 * r + g : 4 * T.q + g;
+    if (r >= T.comps || k >= K) return -1;
+    return base + (T.head ? k : k * T.stride + T.first + r);
+}
+__device__ __forceinline__ float gsd_comp4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+__global__ void __launch_bounds__(GSD_FB_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) gsd_backward_fused_kernel(
+    int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
+    const float* __restrict__ offsets, const float* __restrict__ gscale, const float* __restrict__ campos,
+    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ first, const float* __restrict__ g_xyz,
+    const float* __restrict__ g_color, const float* __restrict__ g_opacity, const float* __restrict__ g_unc,
+    const float* __restrict__ g_scaling, const float* __restrict__ g_rot, float* __restrict__ d_feat,
+    float* __restrict__ d_anchor, float* __restrict__ d_offsets, float* __restrict__ d_gscale, float* __restrict__ partial2,
+    float* __restrict__ partial1)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sw = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
+    float* const xT = smem + GSD_FB_ENTRIES * 64 + wave * GSD_FB_WAVEBUF;
+    float* const hT = xT + 48 * GSD_TS;
+    float* const sT = hT + 32 * GSD_TS;
+    gsd_stage<GSD_FB_THREADS / 64, GSD_FB_ENTRIES>(sw, wave, lane, [&](int e) {
+        if (e < GSD_FB_L2) {
+            const int m = e / GSD_L1_ENTRIES;
+            return gsd_l1_entry(P.w1[m], P.b1[m], e - m * GSD_L1_ENTRIES, g, a);
+        }
+        if (e < GSD_FB_W2T) {
+            const int t = (e - GSD_FB_L2) / GSD_L2_ENTRIES, j = (e - GSD_FB_L2) - t * GSD_L2_ENTRIES;
+            const GsdTile T = gsd_tile(t);
+            return gsd_l2_entry(P.w2[T.mlp], P.b2[T.mlp], K, T.head, T.q, T.comps, T.stride, T.first, j, g, a);
+        }
+        if (e < GSD_FB_W1T) {
+            // W2^T operand of k-step (tile t, component r), hidden tile jt: W2[rho(t, 4g + r)][16 jt + a]
+            const int pr = (e - GSD_FB_W2T) >> 1, jt = (e - GSD_FB_W2T) & 1;
+            int t = 0;
+            for (int u = 1; u < 11; u++)
+                if (pr >= gsd_tile(u).pair0) t = u;
+            const GsdTile T = gsd_tile(t);
+            const int r = pr - T.pair0;
+            const int k = T.head ? 4 * r + g : 4 * T.q + g;
+            const int o = T.head ? k : k * T.stride + T.first + r;
+            return k < K ? P.w2[T.mlp][o * GSD_HID + 16 * jt + a] : 0.0f;
+        }
+        // W1^T operand of MLP m, input tile it, k-step (jt, r): W1_m[16 jt + 4g + r][16 it + a]
+        const int m = (e - GSD_FB_W1T) / 24, it = ((e - GSD_FB_W1T) - 24 * m) >> 3, ks = (e - GSD_FB_W1T) & 7, i = 16 * it + a;
+        return i < GSD_IN ? P.w1[m][(16 * (ks >> 2) + 4 * g + (ks & 3)) * GSD_IN + i] : 0.0f;
+    });
+    for (int i = lane; i < 48 * GSD_TS; i += 64) xT[i] = 0.f;  // rows 36..47 of the input tile stay zero
+    __syncthreads();
+    const float* const tl = sw + lane;
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
+
+    gsd_v4 gW2[11][2], gW1[4][2][3];
+    float bs2[11][4], bs1[4][2][4];
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+        gW2[t][0] = gW2[t][1] = (gsd_v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) bs2[t][r] = 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+#pragma unroll
+            for (int it = 0; it < 3; it++) gW1[m][jt][it] = (gsd_v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; r++) bs1[m][jt][r] = 0.f;
+        }
+
+    const int groups = (N + 15) / 16, stride = gridDim.x * (GSD_FB_THREADS / 64);
+#pragma unroll 1
+    for (int grp = blockIdx.x * (GSD_FB_THREADS / 64) + wave; grp < groups; grp += stride) {
+        const int n = grp * 16 + a;
+        const bool live = n < N;
+        const int nn = live ? n : N - 1;
+        const int ai = vis ? vis[nn] : nn;
+        GsdRaw R;
+        gsd_load_raw(R, feat, anchor, ai, g);
+        uint32_t keep = 0;  // the lane's own offsets, then OR-ed over the anchor's four lanes
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            if (live && k < K && mask[(size_t)nn * K + k]) keep |= 1u << k;
+        }
+        const uint32_t row0 = first[nn];
+        float gs[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) gs[c] = gscale[6 * (size_t)ai + c];
+        keep |= (uint32_t)__shfl_xor((int)keep, 16, 64);
+        keep |= (uint32_t)__shfl_xor((int)keep, 32, 64);
+        size_t row[3];
+        bool on[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            on[q] = k < K && ((keep >> k) & 1u);
+            row[q] = row0 + (uint32_t)__popc(keep & ((1u << k) - 1u));
+        }
+        // geometry of the lane's offsets: xyz = anchor + offset * gs[0:3]
+        float da[3] = { 0.f, 0.f, 0.f }, dgs[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + g;
+            if (!live || k >= K) continue;
+            float* dof = d_offsets + ((size_t)ai * K + k) * 3;
+            if (!on[q]) { dof[0] = 0.f; dof[1] = 0.f; dof[2] = 0.f; continue; }
+            const float* of = offsets + ((size_t)ai * K + k) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float gu = g_xyz[3 * row[q] + c];
+                da[c] += gu; dof[c] = gu * gs[c]; dgs[c] += gu * of[c];
+            }
+        }
+        GsdIn X;
+        gsd_finish_in(X, R, cx, cy, cz, g);
+        // the input tile, turned: row = input index, 16 anchors along the row
+#pragma unroll
+        for (int s = 0; s < 8; s++) xT[(s < 4 ? 4 * g + s : 12 + 4 * g + s) * GSD_TS + a] = X.f[s];
+        xT[(32 + g) * GSD_TS + a] = X.v;
+        float4 XB[3];
+#pragma unroll
+        for (int it = 0; it < 3; it++) XB[it] = *reinterpret_cast<const float4*>(xT + (16 * it + a) * GSD_TS + 4 * g);
+
+        gsd_v4 dx[3] = { {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f} };
+        float dgs3[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            // upstream gradients of the lane's rows for this head
+            float up[3][7];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) up[q][c] = 0.f;
+                if (on[q]) {
+                    const size_t r = row[q];
+                    if (m == 0) up[q][0] = g_opacity[r];
+                    if (m == 1) up[q][0] = g_unc[r];
+                    if (m == 2) { up[q][0] = g_color[3 * r]; up[q][1] = g_color[3 * r + 1]; up[q][2] = g_color[3 * r + 2]; }
+                    if (m == 3) {
+                        up[q][0] = g_scaling[3 * r]; up[q][1] = g_scaling[3 * r + 1]; up[q][2] = g_scaling[3 * r + 2];
+                        const float4 gr = reinterpret_cast<const float4*>(g_rot)[r];
+                        up[q][3] = gr.x; up[q][4] = gr.y; up[q][5] = gr.z; up[q][6] = gr.w;
+                    }
+                }
+            }
+            gsd_v4 h[2];
+            gsd_mfma_l1(tl + m * GSD_L1_ENTRIES * 64, X, h);
+            float4 HB[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) hT[(16 * jt + 4 * g + r) * GSD_TS + a] = h[jt][r];
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) HB[jt] = *reinterpret_cast<const float4*>(hT + (16 * jt + a) * GSD_TS + 4 * g);
+
+            gsd_v4 dh[2] = { {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f} };
+            // one second-layer tile: deltas dz -> weight gradients (turned through sT), d(hidden), bias sums
+            auto tile_back = [&](const int t, const gsd_v4 dz) {
+                const GsdTile T = gsd_tile(t);
+#pragma unroll
+                for (int r = 0; r < 4; r++) sT[(4 * g + r) * GSD_TS + a] = dz[r];
+                const float4 A4 = *reinterpret_cast<const float4*>(sT + a * GSD_TS + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    gW2[t][0] = GSD_MFMA(gsd_comp4(A4, e), gsd_comp4(HB[0], e), gW2[t][0]);
+                    gW2[t][1] = GSD_MFMA(gsd_comp4(A4, e), gsd_comp4(HB[1], e), gW2[t][1]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r < T.comps) {
+                        dh[0] = GSD_MFMA(tl[(GSD_FB_W2T + 2 * (T.pair0 + r)) * 64], dz[r], dh[0]);
+                        dh[1] = GSD_MFMA(tl[(GSD_FB_W2T + 2 * (T.pair0 + r) + 1) * 64], dz[r], dh[1]);
+                        bs2[t][r] += dz[r];
+                    }
+                }
+            };
+            const float* tl2 = tl + GSD_FB_L2 * 64;
+            if (m < 2) {
+                const gsd_v4 z = gsd_mfma_l2(tl2 + m * GSD_L2_ENTRIES * 64, h);  // register r = offset 4r + g
+                gsd_v4 dz;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    float d = 0.f;
+                    if (m == 0) { const float t = tanhf(z[q]); d = up[q][0] * (1.0f - t * t); }       // opacity = tanh(z)
+                    else { const float sg = gsd_sigmoid(z[q]); d = up[q][0] * sg * (1.0f - sg); }   // sigmoid
+                    dz[q] = on[q] ? d : 0.f;
+                }
+                dz[3] = 0.f;
+                tile_back(m, dz);
+            } else if (m == 2) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const gsd_v4 z = gsd_mfma_l2(tl2 + (2 + q) * GSD_L2_ENTRIES * 64, h);
+                    gsd_v4 dz;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float sg = gsd_sigmoid(z[c]);
+                        dz[c] = on[q] ? up[q][c] * sg * (1.0f - sg) : 0.f;
+                    }
+                    dz[3] = 0.f;
+                    tile_back(2 + q, dz);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const gsd_v4 zs = gsd_mfma_l2(tl2 + (5 + q) * GSD_L2_ENTRIES * 64, h);
+                    const gsd_v4 zr = gsd_mfma_l2(tl2 + (8 + q) * GSD_L2_ENTRIES * 64, h);
+                    gsd_v4 dzs, dzr;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {  // scaling = gs[3+c] * sigmoid(z)
+                        const float sg = gsd_sigmoid(zs[c]);
+                        dzs[c] = on[q] ? up[q][c] * gs[3 + c] * sg * (1.0f - sg) : 0.f;
+                        dgs3[c] += on[q] ? up[q][c] * sg : 0.f;
+                    }
+                    dzs[3] = 0.f;
+                    // rot = v / max(|v|, eps): d v = (g - rot (rot . g)) / |v|
+                    const float nrm = fmaxf(sqrtf(zr[0] * zr[0] + zr[1] * zr[1] + zr[2] * zr[2] + zr[3] * zr[3]), 1e-12f);
+                    float rt[4], dot = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { rt[c] = zr[c] / nrm; dot += up[q][3 + c] * rt[c]; }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) dzr[c] = on[q] ? (up[q][3 + c] - rt[c] * dot) / nrm : 0.f;
+                    tile_back(5 + q, dzs);
+                    tile_back(8 + q, dzr);
+                }
+            }
+            // through the ReLU; first-layer weight gradients, input gradients, bias sums
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                gsd_v4 d1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) d1[r] = h[jt][r] > 0.0f ? dh[jt][r] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) sT[(4 * g + r) * GSD_TS + a] = d1[r];
+                const float4 A4 = *reinterpret_cast<const float4*>(sT + a * GSD_TS + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int it = 0; it < 3; it++) gW1[m][jt][it] = GSD_MFMA(gsd_comp4(A4, e), gsd_comp4(XB[it], e), gW1[m][jt][it]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+#pragma unroll
+                    for (int it = 0; it < 3; it++)
+                        dx[it] = GSD_MFMA(tl[(GSD_FB_W1T + 24 * m + 8 * it + 4 * jt + r) * 64], d1[r], dx[it]);
+                    bs1[m][jt][r] += d1[r];
+                }
+            }
+        }
+        // per-anchor outputs
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            da[c] += __shfl_xor(da[c], 16, 64); da[c] += __shfl_xor(da[c], 32, 64);
+            dgs[c] += __shfl_xor(dgs[c], 16, 64); dgs[c] += __shfl_xor(dgs[c], 32, 64);
+            dgs3[c] += __shfl_xor(dgs3[c], 16, 64); dgs3[c] += __shfl_xor(dgs3[c], 32, 64);
+        }
+        if (live) {
+            float4* df = reinterpret_cast<float4*>(d_feat + (size_t)ai * GSD_F + 4 * g);
+            df[0] = make_float4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
+            df[4] = make_float4(dx[1][0], dx[1][1], dx[1][2], dx[1][3]);
+            if (g == 0) {
+                // view vector / distance back to the anchor (v = a - c, dist = |v|, view = v / dist); dx[2] = d(view, dist)
+                const float vx = R.ax - cx, vy = R.ay - cy, vz = R.az - cz;
+                const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+                const float ux = vx / dist, uy = vy / dist, uz = vz / dist;
+                const float gdot = dx[2][0] * ux + dx[2][1] * uy + dx[2][2] * uz;
+                d_anchor[3 * (size_t)ai] = da[0] + (dx[2][0] - ux * gdot) / dist + dx[2][3] * ux;
+                d_anchor[3 * (size_t)ai + 1] = da[1] + (dx[2][1] - uy * gdot) / dist + dx[2][3] * uy;
+                d_anchor[3 * (size_t)ai + 2] = da[2] + (dx[2][2] - uz * gdot) / dist + dx[2][3] * uz;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { d_gscale[6 * (size_t)ai + c] = dgs[c]; d_gscale[6 * (size_t)ai + 3 + c] = dgs3[c]; }
+            }
+        }
+    }
+
+    // ---- the wave's weight gradients -> workgroup partial (LDS, in wave order: bit-reproducible) -> workspace ----
+    // bias sums over the 16 anchors of a lane group (the lanes of one DPP row)
+#pragma unroll
+    for (int t = 0; t < 11; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) bs2[t][r] += __shfl_xor(bs2[t][r], d, 64);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) bs1[m][jt][r] += __shfl_xor(bs1[m][jt][r], d, 64);
+    __syncthreads();  // every wave is done with the operand table: the partials take its place
+    float* const red2 = smem;
+    float* const red1 = smem + GSD_WG2_ROWS * GSD_WG2_COLS;
+    for (int i = threadIdx.x; i < GSD_WG2_ROWS * GSD_WG2_COLS + GSD_WG1_ROWS * GSD_WG1_COLS; i += GSD_FB_THREADS) smem[i] = 0.f;
+    for (int w = 0; w < GSD_FB_THREADS / 64; w++) {
+        __syncthreads();
+        if (wave != w) continue;
+#pragma unroll
+        for (int t = 0; t < 11; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = gsd_tile_row(t, g, r, K);
+                if (o < 0) continue;
+                red2[o * GSD_WG2_COLS + a] += gW2[t][0][r];
+                red2[o * GSD_WG2_COLS + 16 + a] += gW2[t][1][r];
+                if (a == 0) red2[o * GSD_WG2_COLS + 32] += bs2[t][r];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = 32 * m + 16 * jt + 4 * g + r;
+#pragma unroll
+                    for (int it = 0; it < 3; it++) red1[j * GSD_WG1_COLS + 16 * it + a] += gW1[m][jt][it][r];
+                }
+        __builtin_amdgcn_s_waitcnt(0);  // (the tile sums above land before the bias column, which shares words with input row 36)
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (a == 0) red1[(32 * m + 16 * jt + 4 * g + r) * GSD_WG1_COLS + 36] += bs1[m][jt][r];
+    }
+    __syncthreads();
+    float* dst2 = partial2 + (size_t)blockIdx.x * GSD_WG2_ROWS * GSD_WG2_COLS;
+    float* dst1 = partial1 + (size_t)blockIdx.x * GSD_WG1_ROWS * GSD_WG1_COLS;
+    for (int i = threadIdx.x; i < GSD_WG2_ROWS * GSD_WG2_COLS; i += GSD_FB_THREADS) dst2[i] = red2[i];
+    for (int i = threadIdx.x; i < GSD_WG1_ROWS * GSD_WG1_COLS; i += GSD_FB_THREADS) dst1[i] = red1[i];
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 #define GSD_MLP_GRID 256  // CUs: the matrix-core MLP kernels launch a few workgroups per CU, each with its operand table in LDS
 static GsdMlps gsd_pack(const float* const* w)  // w[16] = {w1[4], b1[4], w2[4], b2[4]}
@@ -1079,6 +1454,41 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
 #undef GSD_BWD
     hipLaunchKernelGGL(gsd_backward_input_kernel, dim3(ngrp < bwd_grid ? ngrp : bwd_grid), dim3(GSD_BWD_THREADS), 0, stream, N, K, P, vis, anchor, offsets, gscale, campos, mask,
                        first, g_xyz, D1, d_feat, d_anchor, d_offsets, d_gscale);
+    return hipGetLastError();
+}
+
+hipError_t gsd_launch_backward_fused(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
+                                     const float* offsets, const float* gscale, const float* campos, const uint8_t* mask,
+                                     const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
+                                     const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
+                                     float* d_anchor, float* d_offsets, float* d_gscale, void* workspace, float* const* grads16,
+                                     hipStream_t stream)
+{
+    GsdGrads G;
+    for (int i = 0; i < 16; i++) G.g[i] = grads16[i];
+    float* p2 = (float*)workspace;
+    float* p1 = p2 + (size_t)GSD_WG_BLOCKS * GSD_WG2_ROWS * GSD_WG2_COLS;
+    // dynamic LDS beyond 64 KiB: one-time opt-in per device
+    static thread_local uint64_t done_mask = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)GSD_FB_LDS_FLOATS * sizeof(float);
+    if (!(dev >= 0 && dev < 64 && ((done_mask >> dev) & 1))) {
+        e = hipFuncSetAttribute((const void*)gsd_backward_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+    }
+    static const int fused_grid = getenv("GSD_FUSED_GRID") ? atoi(getenv("GSD_FUSED_GRID")) : GSD_MLP_GRID;
+    const int want = ((N > 0 ? (N + 15) / 16 : 1) + GSD_FB_THREADS / 64 - 1) / (GSD_FB_THREADS / 64);
+    int grid = want < fused_grid ? want : fused_grid;
+    if (grid > GSD_WG_BLOCKS) grid = GSD_WG_BLOCKS;
+    // N == 0: the partials are zeros (nothing to add up) -- the kernels still run so that every output is written
+    hipLaunchKernelGGL(gsd_backward_fused_kernel, dim3(grid), dim3(GSD_FB_THREADS), lds, stream, N, K, gsd_pack(weights), vis, feat, anchor,
+                       offsets, gscale, campos, mask, first, g_xyz, g_color, g_opacity, g_unc, g_scaling, g_rot, d_feat, d_anchor,
+                       d_offsets, d_gscale, p2, p1);
+    const int total = GSD_WG2_ROWS * GSD_WG2_COLS + GSD_WG1_ROWS * GSD_WG1_COLS;
+    hipLaunchKernelGGL(gsd_weight_grad_finish_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, K, grid, p2, p1, G);
     return hipGetLastError();
 }
 
