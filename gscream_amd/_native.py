@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = (
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
     "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward", "gsr_training_stats",
-    "gsr_decode_ld", "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_weight_grads", "gsr_decode_backward_fused",
+    "gsr_decode_weight_grad_workspace_bytes",
 )
 NUM_STAGES = 7
 
@@ -101,15 +101,9 @@ def load():
     lib.gsr_decode_emit.restype = _c_int
     lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 17
     lib.gsr_decode_backward.restype = _c_int
-    lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 24
-    lib.gsr_decode_backward_fused.restype = _c_int
-    lib.gsr_decode_backward_fused.argtypes = [_c_int, _c_int] + [_vp] * 22
-    lib.gsr_decode_ld.restype = _c_int
-    lib.gsr_decode_ld.argtypes = [_c_int]
+    lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 22
     lib.gsr_decode_weight_grad_workspace_bytes.restype = ctypes.c_size_t
     lib.gsr_decode_weight_grad_workspace_bytes.argtypes = []
-    lib.gsr_decode_weight_grads.restype = _c_int
-    lib.gsr_decode_weight_grads.argtypes = [_c_int, _c_int] + [_vp] * 7
     lib.gsr_depth_loss_workspace_bytes.restype = ctypes.c_size_t
     lib.gsr_depth_loss_workspace_bytes.argtypes = [_c_int, _c_int]
     lib.gsr_depth_loss_forward.restype = _c_int

@@ -561,27 +561,8 @@ extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const 
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
-                                   const float* offsets, const float* grid_scaling, const float* campos,
-                                   const uint8_t* mask, const uint32_t* first, const float* g_xyz, const float* g_color,
-                                   const float* g_opacity, const float* g_uncertainty, const float* g_scaling,
-                                   const float* g_rot, float* d_feat, float* d_anchor, float* d_offsets,
-                                   float* d_grid_scaling, float* D2, float* D1, float* H, float* X, void* stream)
-{
-    int rc = gsr_check_decode(N, K, weights);
-    if (rc) return rc;
-    if (N == 0) return GSR_OK;
-    if (!feat || !anchor || !offsets || !grid_scaling || !campos || !mask || !first || !d_feat || !d_anchor || !d_offsets ||
-        !d_grid_scaling || !D2 || !D1 || !H || !X)
-        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_backward(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
-                                g_opacity, g_uncertainty, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_grid_scaling, D2,
-                                D1, H, X, (hipStream_t)stream), "decode backward");
-    return GSR_OK;
-}
-
-extern "C" int gsr_decode_backward_fused(int N, int K, const float* const* weights, const int32_t* visible, const float* feat,
-                                         const float* anchor, const float* offsets, const float* grid_scaling, const float* campos,
+extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t* visible, const float* feat,
+                                   const float* anchor, const float* offsets, const float* grid_scaling, const float* campos,
                                          const uint8_t* mask, const uint32_t* first, const float* g_xyz, const float* g_color,
                                          const float* g_opacity, const float* g_uncertainty, const float* g_scaling,
                                          const float* g_rot, float* d_feat, float* d_anchor, float* d_offsets,
@@ -596,27 +577,13 @@ extern "C" int gsr_decode_backward_fused(int N, int K, const float* const* weigh
                   !d_grid_scaling))
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
     if (!campos) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: campos is NULL");
-    GSR_HIP(gsd_launch_backward_fused(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
+    GSR_HIP(gsd_launch_backward(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, mask, first, g_xyz, g_color,
                                       g_opacity, g_uncertainty, g_scaling, g_rot, d_feat, d_anchor, d_offsets, d_grid_scaling,
                                       workspace, grads16, (hipStream_t)stream), "decode backward");
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_ld(int N) { return gsd_leading_dim(N > 0 ? N : 0); }
 extern "C" size_t gsr_decode_weight_grad_workspace_bytes(void) { return gsd_weight_grad_workspace_bytes(); }
-
-extern "C" int gsr_decode_weight_grads(int N, int K, const float* D2, const float* D1, const float* H, const float* X, void* workspace,
-                                       float* const* grads16, void* stream)
-{
-    if (N < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: N must be >= 0 (got %d)", N);
-    if (K < 1 || K > 10) return gsr_fail(GSR_ERR_UNSUPPORTED, "decode: n_offsets must be in 1..10 (got %d)", K);
-    if (!workspace || !grads16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: workspace / grads16 is NULL");
-    for (int i = 0; i < 16; i++)
-        if (!grads16[i]) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: grads16[%d] is NULL", i);
-    if (N > 0 && (!D2 || !D1 || !H || !X)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_weight_grads(N, K, D2, D1, H, X, workspace, grads16, (hipStream_t)stream), "decode weight gradients");
-    return GSR_OK;
-}
 
 // ---- depth loss (depth_loss.hip) ----
 extern "C" size_t gsr_depth_loss_workspace_bytes(int H, int W) { return gdl_workspace_bytes(H, W); }

@@ -221,21 +221,12 @@ hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int3
                            const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream);
 hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
-                               const float* offsets, const float* gscale, const float* campos, const uint8_t* mask,
-                               const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
-                               const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
-                               float* d_anchor, float* d_offsets, float* d_gscale, float* D2, float* D1, float* H, float* X,
-                               hipStream_t stream);
-hipError_t gsd_launch_backward_fused(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
                                      const float* offsets, const float* gscale, const float* campos, const uint8_t* mask,
                                      const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
                                      const float* g_unc, const float* g_scaling, const float* g_rot, float* d_feat,
                                      float* d_anchor, float* d_offsets, float* d_gscale, void* workspace, float* const* grads16,
                                      hipStream_t stream);
 size_t gsd_weight_grad_workspace_bytes();
-int gsd_leading_dim(int N);
-hipError_t gsd_launch_weight_grads(int N, int K, const float* D2, const float* D1, const float* H, const float* X, void* workspace,
-                                   float* const* grads16, hipStream_t stream);
 
 // ---- depth_loss.hip (depth terms) ----
 size_t gdl_workspace_bytes(int H, int W);

@@ -8,12 +8,11 @@ the reference's GaussianModel does: `_anchor_feat`, `get_anchor`, `_offset`, `ge
 
 The visible-anchor gather (:25-28) is folded into the kernels (the mask becomes a row list once); view vector, four
 MLPs, opacity mask, boolean-mask compaction, post-processing run in `gsr_decode_count` / `gsr_decode_emit`
-(include/gsraster.h), the backward in `gsr_decode_backward` and `gsr_decode_weight_grads` (all 16 weight / bias
+(include/gsraster.h), the backward in `gsr_decode_backward` (input gradients and all 16 weight / bias
 gradients in one native call on the f32 matrix cores; no library GEMM on the path).
 `use_feat_bank=True` (off in every GScream config, arguments/__init__.py:57) runs the bank MLP + blend as a torch pre-step.
 No CPU fallback."""
 import ctypes
-import os
 
 import torch
 
@@ -90,33 +89,8 @@ class _Decode(torch.autograd.Function):
             full = feat_c.shape[0]  # model-sized gradients; rows outside `vis` stay zero
             mk = (lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)) if vis is not None else e
             d_feat, d_anchor, d_off, d_gs = mk(full, 32), mk(full, 3), mk(full, K, 3), mk(full, 6)
-            if os.environ.get("GSD_FUSED", "1") != "0":
-                outs = (K, K, 3 * K, 7 * K)
-                gw1 = [e(32, 36) for _ in range(4)]
-                gb1 = [e(32) for _ in range(4)]
-                gw2 = [e(outs[m], 32) for m in range(4)]
-                gb2 = [e(outs[m]) for m in range(4)]
-                garr = (ctypes.c_void_p * 16)(*[g.data_ptr() for g in gw1 + gb1 + gw2 + gb2])
-                wsp = _workspace(dev, lib.gsr_decode_weight_grad_workspace_bytes())
-                _native.check(lib.gsr_decode_backward_fused(
-                    N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c),
-                    _native.ptr(cam_c), _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
-                    _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
-                    _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(wsp), garr, _stream()), "gsr_decode_backward_fused")
-                grads_w = gw1 + gb1 + gw2 + gb2
-                sh = ctx.in_shapes
-                return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None, None,
-                        *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
-            ld = lib.gsr_decode_ld(N)  # row stride of the feature-major per-anchor arrays (N rounded up to 16)
-            D2, D1, H, X = e(12 * K, ld), e(128, ld), e(128, ld), e(36, ld)
-            _native.check(lib.gsr_decode_backward(
-                N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c),
-                _native.ptr(cam_c), _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
-                _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
-                _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(D2), _native.ptr(D1), _native.ptr(H), _native.ptr(X),
-                _stream()), "gsr_decode_backward")
-            # weight / bias gradients: D @ A^T with the anchors as the reduction dimension, one native call on the f32
-            # matrix cores (gsr_decode_weight_grads) straight into the 16 gradient tensors
+            # one native call: input / geometry gradients and all 16 weight / bias gradients (accumulated in registers on the
+            # f32 matrix cores, workgroup partials added in a fixed order) straight into the gradient tensors
             outs = (K, K, 3 * K, 7 * K)
             gw1 = [e(32, 36) for _ in range(4)]
             gb1 = [e(32) for _ in range(4)]
@@ -124,8 +98,11 @@ class _Decode(torch.autograd.Function):
             gb2 = [e(outs[m]) for m in range(4)]
             garr = (ctypes.c_void_p * 16)(*[g.data_ptr() for g in gw1 + gb1 + gw2 + gb2])
             wsp = _workspace(dev, lib.gsr_decode_weight_grad_workspace_bytes())
-            _native.check(lib.gsr_decode_weight_grads(N, K, _native.ptr(D2), _native.ptr(D1), _native.ptr(H), _native.ptr(X),
-                                                      _native.ptr(wsp), garr, _stream()), "gsr_decode_weight_grads")
+            _native.check(lib.gsr_decode_backward(
+                N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c), _native.ptr(gs_c),
+                _native.ptr(cam_c), _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
+                _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
+                _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(wsp), garr, _stream()), "gsr_decode_backward")
         grads_w = gw1 + gb1 + gw2 + gb2
         sh = ctx.in_shapes
         return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None, None,

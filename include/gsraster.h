@@ -199,14 +199,11 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
  *                      scaling[M,3], rot[M,4]
  *   gsr_decode_backward : upstream gradients of those rows -> d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3],
- *                      d_grid_scaling[N,6], plus the per-anchor layer deltas D2 (12K rows) / D1 (128 rows) and activations
- *                      H (128 rows), X (36 rows), each of rows * gsr_decode_ld(N) floats (ld = N rounded up to 64), laid
- *                      out in chunks of 64 anchors, feature-major inside a chunk: element (row, n) at
- *                      ((n / 64) * rows + row) * 64 + n % 64.  Opaque to the caller: feed them to gsr_decode_weight_grads.
- *   gsr_decode_weight_grads : the 16 weight / bias gradients from those four arrays (D @ A^T over the anchors, on the
- *                      f32 matrix cores; bit-reproducible): grads16 = { gw1[4] [32,36], gb1[4] [32], gw2[4] [out,32],
- *                      gb2[4] [out] } in the order of `weights`; workspace of gsr_decode_weight_grad_workspace_bytes().
- *                      Replaces the autograd backward of the reference's nn.Linear layers (scene/gaussian_model.py:118-144).
+ *                      d_grid_scaling[N,6] AND the 16 weight / bias gradients grads16 = { gw1[4] [32,36], gb1[4] [32],
+ *                      gw2[4] [out,32], gb2[4] [out] } in the order of `weights` (every element written; bit-reproducible),
+ *                      in one pass on the f32 matrix cores; workspace of gsr_decode_weight_grad_workspace_bytes() bytes
+ *                      (workgroup partials, nothing to initialise).  Replaces the autograd backward of
+ *                      generate_neural_gaussians including the reference's nn.Linear layers (scene/gaussian_model.py:118-144).
  */
 int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor, const float* campos,
                      float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first, uint32_t* total,
@@ -219,11 +216,8 @@ int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t
                         const float* offsets, const float* grid_scaling, const float* campos, const uint8_t* mask,
                         const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,
                         const float* g_uncertainty, const float* g_scaling, const float* g_rot, float* d_feat, float* d_anchor,
-                        float* d_offsets, float* d_grid_scaling, float* D2, float* D1, float* H, float* X, void* stream);
-int gsr_decode_ld(int N);
+                        float* d_offsets, float* d_grid_scaling, void* workspace, float* const* grads16, void* stream);
 size_t gsr_decode_weight_grad_workspace_bytes(void);
-int gsr_decode_weight_grads(int N, int K, const float* D2, const float* D1, const float* H, const float* X, void* workspace,
-                            float* const* grads16, void* stream);
 
 /*
  * Densification statistics of one training iteration: replaces the body of
