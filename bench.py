@@ -20,6 +20,7 @@ Extra objects on the JSON line:
                   bounded sample of the same workload; rank 0, N=1 only.  Reported, not a target.
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -108,6 +109,18 @@ def cpu_torch_naive():
 NEXT_ROW_WARMUP, NEXT_ROW_ITERS = 10, 30  # fixed: independent of --steps (allocator growth, library heuristics settle in the warm-up)
 
 
+def gpu_spin_up(dev, ms=120.0):
+    """Keeps the GPU busy for ~`ms` before a timed section.  The rows' CPU legs (seconds of host-only work) let the GPU drop to
+    its idle clocks, and ten warm-up iterations of a 0.05-0.5 ms step are over before the clocks are back: the decode row read
+    0.85 ms right after a CPU leg and 0.55 ms otherwise."""
+    a = torch.empty((2048, 2048), dtype=torch.float32, device=dev).normal_()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            a = (a @ a).clamp_(-1.0, 1.0)
+        torch.cuda.synchronize()
+
+
 def loss_row(dev, H, W, with_cpu):
     """SURVEY 8(f) rank 2 (the step after the rasterizer): fused weighted L1 + SSIM loss, forward + backward at the
     bench resolution.  Timed with HIP events on torch's current stream (the stream the kernels are launched on).
@@ -128,6 +141,7 @@ def loss_row(dev, H, W, with_cpu):
         return torch.autograd.grad(loss, img)[0]
 
     def timed(fn, n):
+        gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -203,6 +217,62 @@ def knn_row(dev, with_cpu, P=1_000_000):
     return row
 
 
+def decode_native_ms(dev, model, cam, N, K):
+    """count -> emit -> backward through the C ABI alone, preallocated buffers, CUDA events around NEXT_ROW_ITERS iterations."""
+    from gscream_amd import _native
+    from gscream_amd.neural_gaussians import _mlp_tensors
+    lib = _native.load()
+    f32 = lambda t: t.detach().contiguous().float()
+    feat, anchor, off = f32(model._anchor_feat), f32(model.get_anchor), f32(model._offset)
+    gs, campos = f32(model.get_scaling), f32(cam.camera_center)
+    t = [_mlp_tensors(m) for m in (model.get_opacity_mlp, model.get_uncertainty_mlp, model.get_color_mlp, model.get_cov_mlp)]
+    ws = [f32(t[m][i]) for i in range(4) for m in range(4)]
+    warr = (ctypes.c_void_p * 16)(*[w.data_ptr() for w in ws])
+    e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=dev)
+    nop, mask, count = e(N * K), e(N * K, dt=torch.uint8), e(N, dt=torch.uint8)
+    first, total, scratch = e(N, dt=torch.int32), torch.zeros(1, dtype=torch.int32, device=dev), e(N // 256 + 2, dt=torch.int32)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = _native.ptr
+
+    def fwd_count():
+        _native.check(lib.gsr_decode_count(N, K, warr, None, P(feat), P(anchor), P(campos), P(nop), P(mask), P(count), P(first), P(total),
+                                           P(scratch), stream), "gsr_decode_count")
+    fwd_count()
+    M = int(total.item())
+    xyz, color, opacity, unc, scaling, rot = e(M, 3), e(M, 3), e(M), e(M), e(M, 3), e(M, 4)
+    g = [torch.randn_like(o) for o in (xyz, color, opacity, unc, scaling, rot)]
+    d_feat, d_anchor, d_off, d_gs = e(N, 32), e(N, 3), e(N, K, 3), e(N, 6)
+    outs = (K, K, 3 * K, 7 * K)
+    grads = [e(32, 36) for _ in range(4)] + [e(32) for _ in range(4)] + [e(outs[m], 32) for m in range(4)] + [e(outs[m]) for m in range(4)]
+    garr = (ctypes.c_void_p * 16)(*[x.data_ptr() for x in grads])
+    wsp = e(lib.gsr_decode_weight_grad_workspace_bytes(), dt=torch.uint8)
+
+    def fwd():
+        fwd_count()
+        _native.check(lib.gsr_decode_emit(N, K, warr, None, P(feat), P(anchor), P(off), P(gs), P(campos), P(nop), P(mask), P(first), P(xyz),
+                                          P(color), P(opacity), P(unc), P(scaling), P(rot), stream), "gsr_decode_emit")
+
+    def fwdbwd():
+        fwd()
+        _native.check(lib.gsr_decode_backward(N, K, warr, None, P(feat), P(anchor), P(off), P(gs), P(campos), P(mask), P(first), P(g[0]),
+                                              P(g[1]), P(g[2]), P(g[3]), P(g[4]), P(g[5]), P(d_feat), P(d_anchor), P(d_off), P(d_gs), P(wsp),
+                                              garr, stream), "gsr_decode_backward")
+
+    def timed(fn):
+        gpu_spin_up(dev)
+        for _ in range(NEXT_ROW_WARMUP):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(NEXT_ROW_ITERS):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / NEXT_ROW_ITERS
+    return timed(fwd), timed(fwdbwd)
+
+
 def decode_row(dev, with_cpu, N=200_000, K=10):
     """SURVEY 8(f) rank 1 (the step before the rasterizer): fused neural-Gaussian decode + compaction,
     200k anchors x 10 offsets (-> ~1M Gaussians), forward and forward+backward."""
@@ -221,6 +291,7 @@ def decode_row(dev, with_cpu, N=200_000, K=10):
         return out
 
     def timed(fn, backward, n):
+        gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             run(fn, backward)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -237,8 +308,14 @@ def decode_row(dev, with_cpu, N=200_000, K=10):
     fb_ms, _ = timed(generate_neural_gaussians, True, n)
     ef_ms, _ = timed(DO.generate_neural_gaussians, False, n)
     efb_ms, _ = timed(DO.generate_neural_gaussians, True, n)
+    nat_f, nat_fb = decode_native_ms(dev, model, cam, N, K)
     row = {"what": f"generate_neural_gaussians: {N} anchors x {K} offsets -> {M} Gaussians (gsr_decode_*), through the autograd API",
            "forward_ms": round(f_ms, 3), "forward_backward_ms": round(fb_ms, 3),
+           "native": {"forward_ms": round(nat_f, 3), "forward_backward_ms": round(nat_fb, 3),
+                      "note": "the same three C-ABI calls (gsr_decode_count / emit / backward) on preallocated buffers, no Python "
+                              "autograd around them: the GPU time of the row; the autograd figures above add ~40 small host-side "
+                              "torch operations per iteration (the summed test loss, its backward, allocations, the row-count read-back) "
+                              "and move with the host's load"},
            "torch_eager_same_gpu": {"forward_ms": round(ef_ms, 3), "forward_backward_ms": round(efb_ms, 3)},
            "speedup_vs_torch_eager": {"forward": round(ef_ms / f_ms, 1), "forward_backward": round(efb_ms / fb_ms, 1)},
            "MFLOP_forward": round(N * 2 * (4 * 36 * 32 + 32 * 12 * K) / 1e6, 1)}
@@ -287,6 +364,7 @@ def pipeline_row(dev, W=1008, H=567, N=200_000, K=10):
         torch.autograd.grad(loss, params, allow_unused=True)
         return int(xyz.shape[0])
 
+    gpu_spin_up(dev)
     for _ in range(NEXT_ROW_WARMUP):
         M = step()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -346,6 +424,7 @@ def depth_loss_row(dev, H, W):
         return torch.autograd.grad(loss, d)[0]
 
     def timed(fn, n):
+        gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

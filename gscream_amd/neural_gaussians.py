@@ -92,10 +92,14 @@ class _Decode(torch.autograd.Function):
             # one native call: input / geometry gradients and all 16 weight / bias gradients (accumulated in registers on the
             # f32 matrix cores, workgroup partials added in a fixed order) straight into the gradient tensors
             outs = (K, K, 3 * K, 7 * K)
-            gw1 = [e(32, 36) for _ in range(4)]
-            gb1 = [e(32) for _ in range(4)]
-            gw2 = [e(outs[m], 32) for m in range(4)]
-            gb2 = [e(outs[m]) for m in range(4)]
+            shapes = [(32, 36)] * 4 + [(32,)] * 4 + [(outs[m], 32) for m in range(4)] + [(outs[m],) for m in range(4)]
+            sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+            flat = e(sum(sizes))  # one allocation for the 16 gradients (every element is written by the kernel)
+            views, at = [], 0
+            for sh, n in zip(shapes, sizes):
+                views.append(flat[at:at + n].view(sh))
+                at += n
+            gw1, gb1, gw2, gb2 = views[0:4], views[4:8], views[8:12], views[12:16]
             garr = (ctypes.c_void_p * 16)(*[g.data_ptr() for g in gw1 + gb1 + gw2 + gb2])
             wsp = _workspace(dev, lib.gsr_decode_weight_grad_workspace_bytes())
             _native.check(lib.gsr_decode_backward(
