@@ -175,19 +175,20 @@ __device__ __forceinline__ gsd_v4 gsd_mfma_l2(const float* t, const gsd_v4 (&h)[
 }
 
 // Staging of an operand table: wave W of NW takes entries W, W + NW, ...; W is a template parameter (switch on the wave
-// index) so that every entry index -- and with it every weight pointer and offset -- is a compile-time constant and the
-// wave's loads are all in flight before its first LDS write.  (With a run-time entry index the MLP pointers are fetched
-// from the argument block by dependent loads and the staging alone took ~50 us.)
+// index) and the entry index reaches the callee as a type (std::integral_constant), so that every weight pointer and
+// offset is a constant expression and the wave's loads are all in flight before its first LDS write.  (With a run-time
+// entry index the MLP pointers are fetched from the argument block by dependent loads: the staging alone took tens of us.)
+template <int W, int NW, int TOTAL, typename Entry, int... I>
+__device__ __forceinline__ void gsd_stage_part_impl(float* sw, int lane, Entry entry, std::integer_sequence<int, I...>)
+{
+    // entry(std::integral_constant<int, e>) -> the lane's value of entry e; e is a constant expression inside the callee
+    const float v[sizeof...(I)] = { entry(std::integral_constant<int, (W + I * NW < TOTAL ? W + I * NW : W)>{})... };
+    ((W + I * NW < TOTAL ? (void)(sw[(W + I * NW) * 64 + lane] = v[I]) : (void)0), ...);
+}
 template <int W, int NW, int TOTAL, typename Entry>
 __device__ __forceinline__ void gsd_stage_part(float* sw, int lane, Entry entry)
 {
-    constexpr int PER = (TOTAL + NW - 1) / NW;
-    float v[PER];
-#pragma unroll
-    for (int i = 0; i < PER; i++) v[i] = (W + i * NW < TOTAL) ? entry(W + i * NW) : 0.0f;
-#pragma unroll
-    for (int i = 0; i < PER; i++)
-        if (W + i * NW < TOTAL) sw[(W + i * NW) * 64 + lane] = v[i];
+    gsd_stage_part_impl<W, NW, TOTAL>(sw, lane, entry, std::make_integer_sequence<int, (TOTAL + NW - 1) / NW>{});
 }
 template <int NW, int TOTAL, typename Entry>
 __device__ __forceinline__ void gsd_stage(float* sw, int wave, int lane, Entry entry)
@@ -219,9 +220,10 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
     __shared__ uint32_t bs;
     __shared__ float sw[(GSD_L1_ENTRIES + GSD_L2_ENTRIES) * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
-    gsd_stage<GSD_THREADS / 64, GSD_L1_ENTRIES + GSD_L2_ENTRIES>(sw, wave, lane, [&](int e) {
-        return e < GSD_L1_ENTRIES ? gsd_l1_entry(P.w1[0], P.b1[0], e, g, a)
-                                  : gsd_l2_entry(P.w2[0], P.b2[0], K, true, 0, 0, 0, 0, e - GSD_L1_ENTRIES, g, a);
+    gsd_stage<GSD_THREADS / 64, GSD_L1_ENTRIES + GSD_L2_ENTRIES>(sw, wave, lane, [&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (e < GSD_L1_ENTRIES) return gsd_l1_entry(P.w1[0], P.b1[0], e, g, a);
+        else return gsd_l2_entry(P.w2[0], P.b2[0], K, true, 0, 0, 0, 0, e - GSD_L1_ENTRIES, g, a);
     });
     const float* t1 = sw + lane;
     const float* t2 = sw + GSD_L1_ENTRIES * 64 + lane;
@@ -315,16 +317,18 @@ __global__ void __launch_bounds__(GSD_EMIT_THREADS) gsd_emit_kernel(
 {
     __shared__ float sw[GSD_EMIT_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
-    gsd_stage<GSD_EMIT_THREADS / 64, GSD_EMIT_ENTRIES>(sw, wave, lane, [&](int e) {
-        if (e < 3 * GSD_L1_ENTRIES) {
-            const int m = e / GSD_L1_ENTRIES;
+    gsd_stage<GSD_EMIT_THREADS / 64, GSD_EMIT_ENTRIES>(sw, wave, lane, [&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (e < 3 * GSD_L1_ENTRIES) {
+            constexpr int m = e / GSD_L1_ENTRIES;
             return gsd_l1_entry(P.w1[m + 1], P.b1[m + 1], e - m * GSD_L1_ENTRIES, g, a);
+        } else {
+            constexpr int t = (e - 3 * GSD_L1_ENTRIES) / GSD_L2_ENTRIES, j = (e - 3 * GSD_L1_ENTRIES) - t * GSD_L2_ENTRIES;
+            if constexpr (t == 0) return gsd_l2_entry(P.w2[1], P.b2[1], K, true, 0, 0, 0, 0, j, g, a);
+            else if constexpr (t < 4) return gsd_l2_entry(P.w2[2], P.b2[2], K, false, t - 1, 3, 3, 0, j, g, a);
+            else if constexpr (t < 7) return gsd_l2_entry(P.w2[3], P.b2[3], K, false, t - 4, 3, 7, 0, j, g, a);
+            else return gsd_l2_entry(P.w2[3], P.b2[3], K, false, t - 7, 4, 7, 3, j, g, a);
         }
-        const int t = (e - 3 * GSD_L1_ENTRIES) / GSD_L2_ENTRIES, j = (e - 3 * GSD_L1_ENTRIES) - t * GSD_L2_ENTRIES;
-        if (t == 0) return gsd_l2_entry(P.w2[1], P.b2[1], K, true, 0, 0, 0, 0, j, g, a);
-        if (t < 4) return gsd_l2_entry(P.w2[2], P.b2[2], K, false, t - 1, 3, 3, 0, j, g, a);
-        if (t < 7) return gsd_l2_entry(P.w2[3], P.b2[3], K, false, t - 4, 3, 7, 0, j, g, a);
-        return gsd_l2_entry(P.w2[3], P.b2[3], K, false, t - 7, 4, 7, 3, j, g, a);
     });
     __syncthreads();
     const float* tl1 = sw + lane;
@@ -531,6 +535,13 @@ __host__ __device__ constexpr GsdTile gsd_tile(int t)
          : t < 8  ? GsdTile{3, 0, t - 5, 3, 7, 0, 15 + 3 * (t - 5)}
                   : GsdTile{3, 0, t - 8, 4, 7, 3, 24 + 4 * (t - 8)};
 }
+__host__ __device__ constexpr int gsd_pair_tile(int pr)  // tile of (tile, component) pair pr
+{
+    int t = 0;
+    for (int u = 1; u < 11; u++)
+        if (pr >= gsd_tile(u).pair0) t = u;
+    return t;
+}
 __host__ __device__ constexpr int gsd_tile0(int m) { return m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 2 : 5; }   // first tile of MLP m
 __host__ __device__ constexpr int gsd_ntiles(int m) { return m < 2 ? 1 : m == 2 ? 3 : 6; }
 // row of the D2 numbering (opacity K | uncertainty K | colour 3K | cov 7K) that tile t carries in row 4g + r, -1 if none
@@ -559,31 +570,30 @@ __global__ void __launch_bounds__(GSD_FB_THREADS) __attribute__((amdgpu_waves_pe
     float* const xT = smem + GSD_FB_ENTRIES * 64 + wave * GSD_FB_WAVEBUF;
     float* const hT = xT + 48 * GSD_TS;
     float* const sT = hT + 32 * GSD_TS;
-    gsd_stage<GSD_FB_THREADS / 64, GSD_FB_ENTRIES>(sw, wave, lane, [&](int e) {
-        if (e < GSD_FB_L2) {
-            const int m = e / GSD_L1_ENTRIES;
+    gsd_stage<GSD_FB_THREADS / 64, GSD_FB_ENTRIES>(sw, wave, lane, [&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (e < GSD_FB_L2) {
+            constexpr int m = e / GSD_L1_ENTRIES;
             return gsd_l1_entry(P.w1[m], P.b1[m], e - m * GSD_L1_ENTRIES, g, a);
-        }
-        if (e < GSD_FB_W2T) {
-            const int t = (e - GSD_FB_L2) / GSD_L2_ENTRIES, j = (e - GSD_FB_L2) - t * GSD_L2_ENTRIES;
-            const GsdTile T = gsd_tile(t);
+        } else if constexpr (e < GSD_FB_W2T) {
+            constexpr int t = (e - GSD_FB_L2) / GSD_L2_ENTRIES, j = (e - GSD_FB_L2) - t * GSD_L2_ENTRIES;
+            constexpr GsdTile T = gsd_tile(t);
             return gsd_l2_entry(P.w2[T.mlp], P.b2[T.mlp], K, T.head, T.q, T.comps, T.stride, T.first, j, g, a);
-        }
-        if (e < GSD_FB_W1T) {
+        } else if constexpr (e < GSD_FB_W1T) {
             // W2^T operand of k-step (tile t, component r), hidden tile jt: W2[rho(t, 4g + r)][16 jt + a]
-            const int pr = (e - GSD_FB_W2T) >> 1, jt = (e - GSD_FB_W2T) & 1;
-            int t = 0;
-            for (int u = 1; u < 11; u++)
-                if (pr >= gsd_tile(u).pair0) t = u;
-            const GsdTile T = gsd_tile(t);
-            const int r = pr - T.pair0;
+            constexpr int pr = (e - GSD_FB_W2T) >> 1, jt = (e - GSD_FB_W2T) & 1;
+            constexpr int t = gsd_pair_tile(pr);
+            constexpr GsdTile T = gsd_tile(t);
+            constexpr int r = pr - T.pair0;
             const int k = T.head ? 4 * r + g : 4 * T.q + g;
             const int o = T.head ? k : k * T.stride + T.first + r;
             return k < K ? P.w2[T.mlp][o * GSD_HID + 16 * jt + a] : 0.0f;
+        } else {
+            // W1^T operand of MLP m, input tile it, k-step (jt, r): W1_m[16 jt + 4g + r][16 it + a]
+            constexpr int m = (e - GSD_FB_W1T) / 24, it = ((e - GSD_FB_W1T) - 24 * m) >> 3, ks = (e - GSD_FB_W1T) & 7;
+            const int i = 16 * it + a;
+            return i < GSD_IN ? P.w1[m][(16 * (ks >> 2) + 4 * g + (ks & 3)) * GSD_IN + i] : 0.0f;
         }
-        // W1^T operand of MLP m, input tile it, k-step (jt, r): W1_m[16 jt + 4g + r][16 it + a]
-        const int m = (e - GSD_FB_W1T) / 24, it = ((e - GSD_FB_W1T) - 24 * m) >> 3, ks = (e - GSD_FB_W1T) & 7, i = 16 * it + a;
-        return i < GSD_IN ? P.w1[m][(16 * (ks >> 2) + 4 * g + (ks & 3)) * GSD_IN + i] : 0.0f;
     });
     for (int i = lane; i < 48 * GSD_TS; i += 64) xT[i] = i / GSD_TS == 36 ? 1.f : 0.f;  // input rows 37..47 stay zero; row 36 = ones: the bias column of the first-layer gradients
     __syncthreads();
