@@ -121,6 +121,9 @@ def test_eval_path_empty_and_errors():
     assert torch.allclose(out[5].norm(dim=1), torch.ones_like(out[5][:, 0]), atol=1e-5)
     none = generate_neural_gaussians(cam_d, dut, torch.zeros(500, dtype=torch.bool, device="cuda"), True)
     assert none[0].shape == (0, 3) and none[6].shape == (0, 1) and none[7].shape == (0,)
+    # backward through an empty selection: every parameter gradient exists and is exactly zero
+    grads = torch.autograd.grad(sum(o.sum() for o in none[:6]), list(dut.parameters()), allow_unused=True)
+    assert all(g is not None and g.abs().sum().item() == 0.0 for g in grads)
     with pytest.raises(RuntimeError):
         generate_neural_gaussians(DO.Camera(torch.tensor(CAM)), copy.deepcopy(ref).float(), None, False)
 
