@@ -534,7 +534,8 @@ def run_config5(args, dist, dev, rank, world):
                                       "queue (TCPStore counter), no collective in the raster path",
                           "parallelism": f"{world} process(es), work queue over 10 scenes",
                           "collective_backend": None if dist is None else dist.get_backend(),
-                          "collective_world_size": 1 if dist is None else dist.get_world_size()},
+                          "collective_world_size": 1 if dist is None else dist.get_world_size(),
+                          "oversubscribed_test_mode": bool(args.oversubscribe)},
                "sum_of_scene_rates": round(sum(r["iters_per_s"] for r in report), 1),
                "slowest_rank_busy_s": round(slowest, 4), "scenes": report}
         print(json.dumps(out), flush=True)
