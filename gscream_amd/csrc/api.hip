@@ -199,6 +199,28 @@ static int gsr_info_event(hipEvent_t* ev)
     return GSR_OK;
 }
 
+// `prefiltered` (GaussianRasterizationSettings field 11).  The reference uses it for one thing: a point that fails the near
+// plane although the caller declared the cloud pre-filtered prints "Point is filtered although prefiltered is set" and
+// traps the kernel (DGR auxiliary.h:154-162) -- the process then dies at its next synchronisation.  Here the same
+// condition is an ordinary error of the call, checked in debug mode (`debug=True` synchronises after every stage anyway);
+// without debug the flag costs nothing and culled points are simply culled.
+static int gsr_prefiltered_trap(int P, int prefiltered, int debug, const float* means3D, const float* viewmatrix, hipStream_t stream)
+{
+    if (!prefiltered || !debug || P <= 0) return GSR_OK;
+    volatile uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;
+    int rc = gsr_info_buffer(&host, &dev);
+    if (rc) return rc;
+    GSR_HIP(hipStreamSynchronize(stream), "prefiltered check");  // nothing in flight may still write the info words
+    host[4] = 0u;
+    GSR_HIP(gsr_launch_prefiltered_check(P, means3D, viewmatrix, dev + 4, stream), "prefiltered check");
+    GSR_HIP(hipStreamSynchronize(stream), "prefiltered check");
+    const uint32_t n = host[4];
+    if (n) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "Point is filtered although prefiltered is set. This shouldn't happen! "
+                                                    "(%u of %d points have view-space z <= 0.2)", n, P);
+    return GSR_OK;
+}
+
 // Validates the stage-1 arguments and enqueues preprocess + counting + the 16-byte D2H copy of {R, max tile count}.
 static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* means3D, const float* scales,
                               float scale_modifier, const float* rotations, const float* opacities,
@@ -250,13 +272,16 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
                                   void* image_ws, int32_t* radii, gsr_stage1_result* result_host,
                                   const gsr_tuning* tuning, int debug, void* stream_)
 {
-    (void)prefiltered;  // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
     hipStream_t stream = (hipStream_t)stream_;
     int rc = gsr_check_dims(P, W, H);
     if (rc) return rc;
     if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
     memset(result_host, 0, sizeof(*result_host));
     if (P == 0) return GSR_OK;  // DGR rasterize_points.cu:85
+    if (prefiltered && debug && means3D && viewmatrix) {
+        rc = gsr_prefiltered_trap(P, prefiltered, debug, means3D, viewmatrix, stream);
+        if (rc) return rc;
+    }
     volatile uint32_t* info = nullptr;  // pinned words the scan kernel writes {R, max} into
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
@@ -317,13 +342,16 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                            float* out_color, float* out_depth, float* out_feature, gsr_stage1_result* result_host,
                            const gsr_tuning* tuning, int debug, void* stream_)
 {
-    (void)prefiltered;
     hipStream_t stream = (hipStream_t)stream_;
     int rc = gsr_check_dims(P, W, H);
     if (rc) return rc;
     if (!result_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "result_host is NULL");
     memset(result_host, 0, sizeof(*result_host));
     if (P == 0) return GSR_OK;
+    if (prefiltered && debug && means3D && viewmatrix) {
+        rc = gsr_prefiltered_trap(P, prefiltered, debug, means3D, viewmatrix, stream);
+        if (rc) return rc;
+    }
     if (!background || !binning_ws || !out_color || !out_depth || !out_feature || binning_capacity <= 0)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL or the binning capacity is not positive");
     // One event per thread and device marks "R is on the host"; stage 2 is enqueued BEFORE we wait for it, so the GPU
@@ -442,11 +470,14 @@ extern "C" int gsr_filter(int P, int W, int H, const float* means3D, const float
                           const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered, int32_t* radii,
                           float* px, float* py, int debug, void* stream_)
 {
-    (void)prefiltered;
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || W <= 0 || H <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad sizes P=%d W=%d H=%d", P, W, H);
     if (P == 0) return GSR_OK;
     if (!means3D || !viewmatrix || !projmatrix || !radii) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
+    {
+        const int rc0 = gsr_prefiltered_trap(P, prefiltered, debug, means3D, viewmatrix, stream);
+        if (rc0) return rc0;
+    }
     if ((!scales || !rotations) == (cov3D_precomp == nullptr))
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations or cov3D_precomp");
     if ((px == nullptr) != (py == nullptr)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "px and py go together");

@@ -185,10 +185,13 @@ __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const floa
 #define GSR_FWB 64
 // Dynamic LDS requested (and never touched) per forward workgroup: it caps how many quadrant waves are resident per CU, so
 // that the rest of the 4T workgroups are handed out as earlier ones finish (the dispatcher then balances the SIMDs; with
-// every wave resident from the start a launch lasts as long as its most loaded SIMD).  Experiment knob: GSR_FWD_LDS_PAD.
+// every wave resident from the start a launch lasts as long as its most loaded SIMD).  Compile-time experiment knob
+// (make variant FLAGS=-DGSR_FWD_LDS_PAD=...; measured: every non-zero value is slower); the shipped library
+// reads no environment variable.
 #ifndef GSR_FWD_LDS_PAD
 #define GSR_FWD_LDS_PAD 0
 #endif
+static_assert(GSR_FWD_LDS_PAD >= 0 && GSR_FWD_LDS_PAD <= 60 * 1024, "GSR_FWD_LDS_PAD out of range");
 typedef float gsr_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gsr_f2 gsr_splat(float v) { gsr_f2 r = {v, v}; return r; }
 __device__ __forceinline__ gsr_f2 gsr_fma2(gsr_f2 a, gsr_f2 b, gsr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -688,8 +691,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
                                     float* out_feature, int capacity, int max_tile_count, bool only_flagged, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
-    static const int fwd_lds_pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : GSR_FWD_LDS_PAD;
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), fwd_lds_pad, stream, image.ranges, bin.point_list, geom.rec, W, H,
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,
                        image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr);

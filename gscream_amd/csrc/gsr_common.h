@@ -176,6 +176,7 @@ hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& ca
                                  const float* features, const float* shs, const float* cov3D_precomp,
                                  const float* colors_precomp, const GsrGeom* geom, int32_t* radii, float* px, float* py,
                                  int tile_cull, hipStream_t stream);
+hipError_t gsr_launch_prefiltered_check(int P, const float* means3D, const float* viewmatrix, uint32_t* culled, hipStream_t stream);
 hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                    hipStream_t stream);
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,

@@ -212,6 +212,24 @@ __global__ void __launch_bounds__(256) gsr_mark_visible_kernel(int P, const floa
     present[idx] = z > 0.2f ? 1 : 0;
 }
 
+// `prefiltered` contract check (DGR auxiliary.h:154-162): the reference traps the kernel when a point the caller declared
+// pre-filtered fails the near-plane test.  Counts such points; api.hip turns a non-zero count into an error (debug mode).
+__global__ void __launch_bounds__(256) gsr_prefiltered_check_kernel(int P, const float* __restrict__ means3D,
+                                                                    const float* __restrict__ vm, uint32_t* __restrict__ culled)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = idx < P && !(vm[2] * means3D[3 * idx] + vm[6] * means3D[3 * idx + 1] + vm[10] * means3D[3 * idx + 2] + vm[14] > 0.2f);
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(culled, (uint32_t)__popcll(m));
+}
+
+hipError_t gsr_launch_prefiltered_check(int P, const float* means3D, const float* vm, uint32_t* culled, hipStream_t stream)
+{
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsr_prefiltered_check_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, vm, culled);
+    return hipGetLastError();
+}
+
 hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& cam, const float* means3D,
                                  const float* scales, const float* rotations, const float* opacities,
                                  const float* features, const float* shs, const float* cov3D_precomp,

@@ -16,10 +16,12 @@ def dist_env():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend, device=None):
-    """Initialises the default process group when WORLD_SIZE > 1; returns torch.distributed or None."""
+def init(backend, device=None, force=False):
+    """Initialises the default process group when WORLD_SIZE > 1; returns torch.distributed or None.
+    force=True brings the backend up for a world of ONE as well (the RCCL bring-up test on a 1-GPU box: communicator
+    creation, barrier and all-reduce all run through librccl; bench.py never forces it)."""
     rank, _, world = dist_env()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -68,11 +70,15 @@ class SceneQueue:
     the process group's TCPStore (host side, rank 0 serves it): no collective, nothing on xGMI.  Single process: a
     local counter."""
 
+    _generation = 0  # queues are created collectively, in the same order on every rank: the n-th queue of a process
+    #                  group gets its own counter key, so a second queue does not start at the first one's count
+
     def __init__(self, dist, num_scenes, name="gsr_scene_queue"):
-        self.num_scenes, self.name, self._local = int(num_scenes), name, 0
-        self.store = None
+        self.num_scenes, self._local, self.name, self.store = int(num_scenes), 0, name, None
         if dist is not None:
-            self.store = dist.distributed_c10d._get_default_store()
+            SceneQueue._generation += 1
+            self.name = f"{name}/{SceneQueue._generation}"
+            self.store = _default_store(dist)
 
     def pull(self):
         """-> next scene index, or None when the list is exhausted.  Every index is handed out exactly once."""
@@ -81,6 +87,14 @@ class SceneQueue:
         else:
             i = int(self.store.add(self.name, 1)) - 1
         return i if i < self.num_scenes else None
+
+
+def _default_store(dist):
+    """The process group's rendezvous store (TCPStore served by rank 0).  torch exposes it only under a private name."""
+    get = getattr(dist.distributed_c10d, "_get_default_store", None)
+    if get is None:
+        raise RuntimeError("this torch build does not expose the default process-group store; SceneQueue needs it")
+    return get()
 
 
 def config5_scene(index):

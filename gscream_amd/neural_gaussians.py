@@ -113,15 +113,11 @@ class _Decode(torch.autograd.Function):
                 *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
 
 
-_ws_cache = {}
-
-
 def _workspace(dev, nbytes):
-    """Per-device scratch for the weight-gradient partials (17 MB), kept between calls: every byte read is written first."""
-    t = _ws_cache.get(dev.index)
-    if t is None or t.numel() < nbytes:
-        t = _ws_cache[dev.index] = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-    return t
+    """Scratch for the weight-gradient partials (~20 MB; every byte read is written first).  Allocated per call through
+    torch's caching allocator: it is stream-aware, so two backwards in flight on different streams of one device never
+    share the buffer, and in a training loop the same block comes back every iteration at the cost of one torch.empty."""
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 
 
 def _mlp_tensors(mlp):

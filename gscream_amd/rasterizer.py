@@ -22,10 +22,11 @@ import torch.nn as nn
 from . import _native
 
 _tuning = _native.Tuning()
+_tuning_ref = _native.ctypes.byref(_tuning)  # built once: the struct is mutated in place by set_tuning
 _capacity_hint = {}  # per-device: (binning capacity, longest-list provision) for the next speculative forward
 _recent = {}         # per-device: (num_rendered, max_tile_count) of the last few forwards (training hops between views)
 _RECENT_FRAMES = 8
-_pinned = {}  # per-device pinned int32[4] that receives gsr_stage1_result (truly asynchronous D2H copy)
+_pinned = {}  # per-device (pinned int32[4] that receives gsr_stage1_result, its ctypes pointer)
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
@@ -64,10 +65,17 @@ def _require_gpu(t, name):
             f"gscream_amd: `{name}` must live on the GPU (got device {t.device}); the rasterizer has no CPU path")
 
 
+_F32 = torch.float32
+_EMPTY = torch.Tensor([])
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a torch.cuda.Stream
+
+
 def _f32c(t, device=None):
     """contiguous fp32 view/copy; mirrors the `.contiguous().data<float>()` of DGR rasterize_points.cu:98-118"""
     if t is None:
         return None
+    if t.dtype is _F32 and t.is_contiguous() and (device is None or t.device == device):
+        return t  # the per-iteration case: nothing to do
     if device is not None and t.device != device:
         t = t.to(device)
     if t.dtype != torch.float32:
@@ -75,8 +83,40 @@ def _f32c(t, device=None):
     return t.contiguous()
 
 
+def _p(t):
+    """device address for the C ABI: None (NULL) for absent / empty tensors (the reference's 'not provided')"""
+    return t.data_ptr() if (t is not None and t.numel() != 0) else None
+
+
+def _stream_handle(index):
+    """HIP stream handle of torch's current stream on device `index` (what the kernels are enqueued on)."""
+    if _raw_stream is not None:
+        return _raw_stream(index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
 def _stream():
-    return _native.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _native.ctypes.c_void_p(_stream_handle(torch.cuda.current_device()))
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` that costs nothing when `dev` already is the current device (the training case)."""
+    __slots__ = ("index", "prev")
+
+    def __init__(self, index):
+        self.index, self.prev = index, -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.index:
+            self.prev = cur
+            torch.cuda.set_device(self.index)
+        return self.index
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _snapshot(args):
@@ -94,19 +134,20 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    idx = dev.index
     P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
-    f32 = dict(dtype=torch.float32, device=dev)
-    # Outputs are zero-filled like the reference's torch::full (rasterize_points.cu:69-72): with
-    # P == 0 the kernels are skipped and the zeros are what the caller gets.
-    color = torch.zeros((3, H, W), **f32) if P == 0 else torch.empty((3, H, W), **f32)
-    depth = torch.zeros((1, H, W), **f32) if P == 0 else torch.empty((1, H, W), **f32)
-    unc = torch.zeros((1, H, W), **f32) if P == 0 else torch.empty((1, H, W), **f32)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev) if P == 0 else torch.empty((P,), dtype=torch.int32, device=dev)
-    u8 = dict(dtype=torch.uint8, device=dev)
     if P == 0:
-        e = torch.empty((0,), **u8)
-        return 0, color, depth, unc, radii, e, e.clone(), e.clone(), 0
+        # Outputs are zero-filled like the reference's torch::full (rasterize_points.cu:69-72): with
+        # P == 0 the kernels are skipped and the zeros are what the caller gets.
+        f32 = dict(dtype=torch.float32, device=dev)
+        e = torch.empty((0,), dtype=torch.uint8, device=dev)
+        return (0, torch.zeros((3, H, W), **f32), torch.zeros((1, H, W), **f32), torch.zeros((1, H, W), **f32),
+                torch.zeros((0,), dtype=torch.int32, device=dev), e, e.clone(), e.clone(), 0)
+    empty = torch.empty
+    color, depth = empty((3, H, W), dtype=_F32, device=dev), empty((1, H, W), dtype=_F32, device=dev)
+    unc, radii = empty((1, H, W), dtype=_F32, device=dev), empty((P,), dtype=torch.int32, device=dev)
 
+    # keep every converted tensor referenced until the launches are enqueued
     means3D_c, opac_c, unc_c = _f32c(means3D), _f32c(opacities), _f32c(uncertainties)
     scales_c, rot_c, cov_c = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
     colors_c, sh_c = _f32c(colors_precomp, dev), _f32c(sh, dev)
@@ -114,55 +155,64 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     view, proj, campos = _cam(rs, dev)
     bg = _f32c(rs.bg, dev)
 
-    geom = torch.empty((lib.gsr_geom_bytes(P),), **u8)
-    img = torch.empty((lib.gsr_image_bytes(P, W, H),), **u8)
-    pin = _pinned.get(dev.index)
+    geom = empty((lib.gsr_geom_bytes(P),), dtype=torch.uint8, device=dev)
+    img = empty((lib.gsr_image_bytes(P, W, H),), dtype=torch.uint8, device=dev)
+    pin = _pinned.get(idx)
     if pin is None:
-        pin = _pinned[dev.index] = torch.zeros(4, dtype=torch.int32).pin_memory()
-    res = _native.ctypes.cast(pin.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result))
-    debug = int(bool(rs.debug))
-    common = (P, int(rs.sh_degree), M, W, H, _native.ptr(means3D_c), _native.ptr(scales_c), float(rs.scale_modifier),
-              _native.ptr(rot_c), _native.ptr(opac_c), _native.ptr(unc_c), _native.ptr(sh_c), _native.ptr(cov_c),
-              _native.ptr(colors_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos), float(rs.tanfovx),
-              float(rs.tanfovy), int(bool(rs.prefiltered)))
-    outs = (_native.ptr(color), _native.ptr(depth), _native.ptr(unc))
-    with torch.cuda.device(dev):
-        stream = _stream()
-        cap, tile_hint = _capacity_hint.get(dev.index, (0, 0))
+        t = torch.zeros(4, dtype=torch.int32).pin_memory()
+        pin = _pinned[idx] = (t, _native.ctypes.cast(t.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result)))
+    res = pin[1]
+    debug = 1 if rs.debug else 0
+    tuning = _tuning_ref
+    common = (P, int(rs.sh_degree), M, W, H, means3D_c.data_ptr(), _p(scales_c), float(rs.scale_modifier),
+              _p(rot_c), _p(opac_c), _p(unc_c), _p(sh_c), _p(cov_c), _p(colors_c), _p(view), _p(proj), _p(campos),
+              float(rs.tanfovx), float(rs.tanfovy), 1 if rs.prefiltered else 0)
+    gp, ip, bgp = geom.data_ptr(), img.data_ptr(), _p(bg)
+    cp, dp, up, rp = color.data_ptr(), depth.data_ptr(), unc.data_ptr(), radii.data_ptr()
+    with _on_device(idx):
+        stream = _stream_handle(idx)
+        cap, tile_hint = _capacity_hint.get(idx, (0, 0))
         done = False
         if cap > 0 and not _tuning.disable_speculation:
             # Speculative single call: stage 2 is enqueued before the host learns num_rendered, against a workspace
             # sized from the previous frames.  No GPU-idle window; redone below only if the guess was too small.
-            binning = torch.empty((lib.gsr_binning_bytes(cap),), **u8)
-            rc = lib.gsr_forward(*common, _native.ptr(bg), _native.ptr(geom), _native.ptr(img), _native.ptr(binning), cap,
-                                 tile_hint, _native.ptr(radii), *outs, res, _native.ctypes.byref(_tuning), debug, stream)
-            if rc not in (0, _native.NEED_CAPACITY):
+            binning = empty((lib.gsr_binning_bytes(cap),), dtype=torch.uint8, device=dev)
+            rc = lib.gsr_forward(*common, bgp, gp, ip, binning.data_ptr(), cap, tile_hint, rp, cp, dp, up, res, tuning,
+                                 debug, stream)
+            if rc != 0 and rc != _native.NEED_CAPACITY:
                 _native.check(rc, "gsr_forward")
             done = rc == 0
         else:
-            rc = lib.gsr_forward_stage1(*common, _native.ptr(geom), _native.ptr(img), _native.ptr(radii), res,
-                                        _native.ctypes.byref(_tuning), debug, stream)
-            _native.check(rc, "gsr_forward_stage1")
-        res = res.contents
-        R = int(res.num_rendered)
+            rc = lib.gsr_forward_stage1(*common, gp, ip, rp, res, tuning, debug, stream)
+            if rc != 0:
+                _native.check(rc, "gsr_forward_stage1")
+        r = res.contents
+        R, longest, nslots = int(r.num_rendered), int(r.max_tile_count), int(r.num_slots)
         if not done:
             cap = R
-            binning = torch.empty((lib.gsr_binning_bytes(cap),), **u8)
-            rc = lib.gsr_forward_stage2(P, W, H, R, int(res.max_tile_count), _native.ptr(bg), _native.ptr(geom),
-                                        _native.ptr(img), _native.ptr(binning), *outs, _native.ctypes.byref(_tuning),
-                                        debug, stream)
-            _native.check(rc, "gsr_forward_stage2")
-        # Provision for the next call from the largest of the last few frames (a trainer hops between views, so the
-        # previous frame alone is a poor predictor): binning capacity, and the longest tile list (sizes the LDS of the
-        # per-tile sort; a tight value lets more sort workgroups be resident).  Exceeded -> GSR_NEED_CAPACITY -> stage 2
-        # is redone above.
-        hist = _recent.setdefault(dev.index, [])
-        hist.append((R, int(res.max_tile_count)))
-        del hist[:-_RECENT_FRAMES]
-        _capacity_hint[dev.index] = (int(1.25 * max(h[0] for h in hist)) + 65536,
-                                     max(1024, int(1.25 * max(h[1] for h in hist)) + 64))
-    _last_stage1.update(num_rendered=R, max_tile_count=int(res.max_tile_count), num_slots=int(res.num_slots),
-                        binning_capacity=cap, speculative=done)
+            binning = empty((lib.gsr_binning_bytes(cap),), dtype=torch.uint8, device=dev)
+            rc = lib.gsr_forward_stage2(P, W, H, R, longest, bgp, gp, ip, _p(binning), cp, dp, up, tuning, debug, stream)
+            if rc != 0:
+                _native.check(rc, "gsr_forward_stage2")
+    # Provision for the next call from the largest of the last few frames (a trainer hops between views, so the
+    # previous frame alone is a poor predictor): binning capacity, and the longest tile list (sizes the LDS of the
+    # per-tile sort; a tight value lets more sort workgroups be resident).  Exceeded -> GSR_NEED_CAPACITY -> stage 2
+    # is redone above.
+    hist = _recent.get(idx)
+    if hist is None:
+        hist = _recent[idx] = []
+    hist.append((R, longest))
+    if len(hist) > _RECENT_FRAMES:
+        del hist[0]
+    maxR, maxL = R, longest
+    for h in hist:
+        if h[0] > maxR:
+            maxR = h[0]
+        if h[1] > maxL:
+            maxL = h[1]
+    _capacity_hint[idx] = (int(1.25 * maxR) + 65536, max(1024, int(1.25 * maxL) + 64))
+    ls = _last_stage1
+    ls["num_rendered"], ls["max_tile_count"], ls["num_slots"], ls["binning_capacity"], ls["speculative"] = R, longest, nslots, cap, done
     return R, color, depth, unc, radii, geom, binning, img, cap
 
 
@@ -171,51 +221,51 @@ def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_
     """The work of `_C.rasterize_gaussians_backward` (DGR rasterize_points.cu:124-211)."""
     lib = _native.load()
     dev = means3D.device
+    idx = dev.index
     P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
-    f32 = dict(dtype=torch.float32, device=dev)
     have_sh = sh is not None and sh.numel() != 0
     have_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0
     M = sh.shape[1] if have_sh else 0
-    mk = torch.zeros if P == 0 else torch.empty  # the kernels write every row when P > 0
-    g_means2D, g_colors = mk((P, 3), **f32), mk((P, 3), **f32)
-    g_opac, g_feat = mk((P, 1), **f32), mk((P, 1), **f32)
-    g_means3D = mk((P, 3), **f32)
+    if P == 0:
+        z = lambda *shape: torch.zeros(shape, dtype=_F32, device=dev)  # noqa: E731
+        return (z(0, 3), z(0, 3), z(0, 1), z(0, 1), z(0, 3), z(0, 6) if have_cov else None, z(0, M, 3) if have_sh else None,
+                None if have_cov else z(0, 3), None if have_cov else z(0, 4))
+    mk = torch.empty  # the kernels write every row when P > 0
+    g_means2D, g_colors = mk((P, 3), dtype=_F32, device=dev), mk((P, 3), dtype=_F32, device=dev)
+    g_opac, g_feat = mk((P, 1), dtype=_F32, device=dev), mk((P, 1), dtype=_F32, device=dev)
+    g_means3D = mk((P, 3), dtype=_F32, device=dev)
     # gradients of inputs that were not provided (empty tensors) are None: autograd ignores them, and the
     # reference's zero tensors for them would cost a fill kernel per iteration
-    g_cov = mk((P, 6), **f32) if have_cov else None
-    g_sh = mk((P, M, 3), **f32) if have_sh else None
-    g_scales = None if have_cov else mk((P, 3), **f32)
-    g_rot = None if have_cov else mk((P, 4), **f32)
-    if P == 0:
-        return g_means2D, g_colors, g_opac, g_feat, g_means3D, g_cov, g_sh, g_scales, g_rot
+    g_cov = mk((P, 6), dtype=_F32, device=dev) if have_cov else None
+    g_sh = mk((P, M, 3), dtype=_F32, device=dev) if have_sh else None
+    g_scales = None if have_cov else mk((P, 3), dtype=_F32, device=dev)
+    g_rot = None if have_cov else mk((P, 4), dtype=_F32, device=dev)
     view, proj, campos = _cam(rs, dev)
     bg = _f32c(rs.bg, dev)
     # set_materialize_grads(False): an output the loss never touched arrives as None.  GScream's loss never uses
     # the uncertainty map (train.py:532) and early iterations use no depth either -> cheaper kernel variant.
-    H_, W_ = int(rs.image_height), int(rs.image_width)
-    gc = _f32c(g_color, dev) if g_color is not None else torch.zeros((3, H_, W_), **f32)
+    gc = _f32c(g_color, dev) if g_color is not None else torch.zeros((3, H, W), dtype=_F32, device=dev)
     if g_depth is None and g_unc is None:
         gd = gu = None
     else:
-        gd = _f32c(g_depth, dev) if g_depth is not None else torch.zeros((1, H_, W_), **f32)
-        gu = _f32c(g_unc, dev) if g_unc is not None else torch.zeros((1, H_, W_), **f32)
+        gd = _f32c(g_depth, dev) if g_depth is not None else torch.zeros((1, H, W), dtype=_F32, device=dev)
+        gu = _f32c(g_unc, dev) if g_unc is not None else torch.zeros((1, H, W), dtype=_F32, device=dev)
     # keep every converted tensor referenced until the launches are enqueued: a temporary freed early
     # could hand its block to the next temporary
     means3D_c, colors_c, sh_c = _f32c(means3D), _f32c(colors_precomp, dev), _f32c(sh, dev)
     scales_c, rot_c, cov_c = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
-    scratch = torch.empty((lib.gsr_backward_scratch_bytes(P, num_rendered),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    scratch = mk((lib.gsr_backward_scratch_bytes(P, num_rendered),), dtype=torch.uint8, device=dev)
+    with _on_device(idx):
         rc = lib.gsr_backward(
-            P, int(rs.sh_degree), M, W, H, int(num_rendered), int(binning_capacity), _native.ptr(bg), _native.ptr(means3D_c),
-            _native.ptr(radii), _native.ptr(colors_c), _native.ptr(sh_c),
-            _native.ptr(scales_c), float(rs.scale_modifier), _native.ptr(rot_c),
-            _native.ptr(cov_c), _native.ptr(view), _native.ptr(proj), _native.ptr(campos),
-            float(rs.tanfovx), float(rs.tanfovy), _native.ptr(gc), _native.ptr(gd), _native.ptr(gu),
-            _native.ptr(geom), _native.ptr(img), _native.ptr(binning), _native.ptr(scratch),
-            _native.ptr(g_means2D), _native.ptr(g_colors), _native.ptr(g_opac), _native.ptr(g_feat),
-            _native.ptr(g_means3D), _native.ptr(g_cov), _native.ptr(g_sh), _native.ptr(g_scales), _native.ptr(g_rot),
-            _native.ctypes.byref(_tuning), int(bool(rs.debug)), _stream())
-        _native.check(rc, "gsr_backward")
+            P, int(rs.sh_degree), M, W, H, int(num_rendered), int(binning_capacity), _p(bg), means3D_c.data_ptr(),
+            radii.data_ptr(), _p(colors_c), _p(sh_c), _p(scales_c), float(rs.scale_modifier), _p(rot_c),
+            _p(cov_c), _p(view), _p(proj), _p(campos), float(rs.tanfovx), float(rs.tanfovy), gc.data_ptr(), _p(gd), _p(gu),
+            _p(geom), _p(img), _p(binning), scratch.data_ptr(),
+            g_means2D.data_ptr(), g_colors.data_ptr(), g_opac.data_ptr(), g_feat.data_ptr(),
+            g_means3D.data_ptr(), _p(g_cov), _p(g_sh), _p(g_scales), _p(g_rot),
+            _tuning_ref, 1 if rs.debug else 0, _stream_handle(idx))
+        if rc != 0:
+            _native.check(rc, "gsr_backward")
     return g_means2D, g_colors, g_opac, g_feat, g_means3D, g_cov, g_sh, g_scales, g_rot
 
 
@@ -310,7 +360,7 @@ class GaussianRasterizer(nn.Module):
         pair_any = scales is not None or rotations is not None
         if (pair_missing and cov3D_precomp is None) or (pair_any and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        empty = torch.Tensor([])  # absent inputs travel as empty tensors (DGR/__init__.py:230-240)
+        empty = _EMPTY  # absent inputs travel as empty tensors (DGR/__init__.py:230-240); one shared instance, never written
         return rasterize_gaussians(
             means3D, means2D,
             empty if shs is None else shs,

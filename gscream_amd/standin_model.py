@@ -1,13 +1,20 @@
 """Stand-in for the parts of GScream's `GaussianModel` / `Camera` that `generate_neural_gaussians` and `render()` read
-(scene/gaussian_model.py:118-144 MLPs, :43-54 activations, :241-242 get_scaling; scene/cameras.py camera_center).
+(scene/gaussian_model.py:118-144 MLPs, :43-54 activations, :241-242 get_scaling, :265-266 get_rotation, the
+densification accumulators; scene/cameras.py camera_center and the fields render() / prefilter_*() read).
 A seeded parameter container for tests and bench.py -- no arithmetic of the path lives here."""
 import torch
 from torch import nn
 
 
 class Camera:
-    def __init__(self, center):
+    """What the decode reads (camera_center) and, when the optional fields are given, what render() / prefilter_*() read
+    from the reference's Camera (scene/cameras.py:17-69)."""
+
+    def __init__(self, center, image_height=None, image_width=None, FoVx=None, FoVy=None, world_view_transform=None,
+                 full_proj_transform=None):
         self.camera_center = center
+        self.image_height, self.image_width, self.FoVx, self.FoVy = image_height, image_width, FoVx, FoVy
+        self.world_view_transform, self.full_proj_transform = world_view_transform, full_proj_transform
 
 
 class Model(nn.Module):
@@ -30,12 +37,20 @@ class Model(nn.Module):
         self.mlp_cov = mk(7 * K, None)                   # :133-137
         self.mlp_color = mk(3 * K, nn.Sigmoid())         # :139-144
         self.rotation_activation = torch.nn.functional.normalize  # :54
+        rot = torch.zeros((N, 4), dtype=dtype)
+        rot[:, 0] = 1.0                                   # anchors carry the identity quaternion (:439-440)
+        self.register_buffer("_rotation", rot, persistent=False)  # a buffer: the decode's parameter list stays as it was
+        # densification statistics (:211-215 / training_setup :332-336), updated in place by training_statis
+        for name, shape in (("opacity_accum", (N, 1)), ("anchor_demon", (N, 1)), ("offset_gradient_accum", (N * K, 1)),
+                            ("offset_denom", (N * K, 1))):
+            self.register_buffer(name, torch.zeros(shape, dtype=torch.float32), persistent=False)
         if use_feat_bank:                                # :107-113 (view-adaptive feature bank, off in every shipped config)
             self.mlp_feature_bank = nn.Sequential(nn.Linear(3 + 1, feat_dim), nn.ReLU(True), nn.Linear(feat_dim, 3),
                                                   nn.Softmax(dim=1)).to(dtype)
 
     get_anchor = property(lambda self: self._anchor)
     get_scaling = property(lambda self: 1.0 * torch.exp(self._scaling))  # :241-242
+    get_rotation = property(lambda self: self.rotation_activation(self._rotation))  # :262-263
     get_opacity_mlp = property(lambda self: self.mlp_opacity)
     get_uncertainty_mlp = property(lambda self: self.mlp_uncertainty)
     get_cov_mlp = property(lambda self: self.mlp_cov)

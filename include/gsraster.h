@@ -101,6 +101,10 @@ size_t gsr_backward_scratch_bytes(int P, int num_slots); /* per-instance gradien
  *   colors_precomp[P,3]         XOR  shs[P,M,3] with degree D (campos[3] needed for SH)
  * Outputs: radii[P] (int32; 0 = culled), *result_host.  The call synchronises `stream` once,
  * like the reference's blocking cudaMemcpy (rasterizer_impl.cu:287).
+ * prefiltered: the caller's promise that no point fails the near-plane test.  The reference traps the kernel on a
+ * violation (auxiliary.h:154-162); here, with prefiltered != 0 AND debug != 0, the entry points that take the flag
+ * (stage 1, gsr_forward, gsr_filter) check the promise first and fail with GSR_ERR_INVALID_ARGUMENT and the
+ * reference's message; without debug the flag is ignored (culled points are culled).
  */
 int gsr_forward_stage1(int P, int D, int M, int W, int H,
                        const float* means3D, const float* scales, float scale_modifier, const float* rotations,

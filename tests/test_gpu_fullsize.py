@@ -23,6 +23,13 @@ from gscream_amd import synthetic as S  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+# What the parity build leaves at full size.  Its arithmetic is the reference's expression evaluated with a correctly rounded
+# expf on BOTH sides (libm in the oracle, ocml on the GPU), but the two expf differ in the last ulp on a small fraction of
+# arguments, so among the ~1e8 (pixel, Gaussian) pairs of a 1M-Gaussian frame a few still land on opposite sides of
+# alpha = 1/255.  Bounds = measured counts on the GPU box with head-room (DESIGN 6 has the measured numbers).
+PRECISE_MAX_PIXELS = 4
+PRECISE_MAX_GRAD_ELEMS = 12
+
 CONFIGS = {"config2_1M_1008x567": (1, 1_000_000, 1008, 567), "config4_2M_1920x1080": (3, 2_000_000, 1920, 1080)}
 
 
@@ -243,27 +250,44 @@ def test_rgb_only_variant_matches_full_kernel(scene):
         assert p9999 < 1e-4 and mx < 1e-2, (k, mx, p9999)
 
 
+def _full_size_report(lib, seed, P, W, H, use):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GSR_LIB", None)
+    if lib:
+        env["GSR_LIB"] = os.path.join(root, "gscream_amd", lib)
+    cmd = [sys.executable, os.path.join(root, "tools", "full_size_oracle_check.py"), str(seed), str(P), str(W), str(H)] + [str(int(u)) for u in use]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("build", ["shipped", "precise"])
 @pytest.mark.parametrize("seed,P,W,H,use", [(1, 1_000_000, 1008, 567, (True, False, False)),   # config 2: RGB-only gradients
                                             (2, 1_000_000, 1008, 567, (True, True, True)),     # config 3: all three maps
                                             (3, 2_000_000, 1920, 1080, (True, True, True))])   # config 4: 2M @1080p
-def test_full_size_element_wise_parity(seed, P, W, H, use):
+def test_full_size_element_wise_parity(seed, P, W, H, use, build):
     """Direct element-wise parity at BASELINE's size: the OpenMP oracle does 1M Gaussians @1008x567 in about a second
-    per pass on the GPU box's host cores.  Radii bit-exact for every Gaussian; images within 1e-4 except threshold
-    flips (a pair at alpha = 1/255 or T = 1e-4 to the ulp), bounded at 1e-4 of the pixels; gradients: 99.9th
-    percentile inside 1e-3 and at most 1e-4 of the elements outside it (measured: p99.9 ~ 6e-6, ~3e-6 of the elements)."""
-    from oracle import oracle as O
-    s = S.scene_slab(seed, P, W, H)
-    grads = S.upstream_grads(seed, W, H, *use)
-    nt = max(1, min(O.max_threads(), os.cpu_count() or 1, 64))
-    st = Hh.oracle_forward(s, nthreads=nt)
-    ref = Hh.oracle_backward(s, st, grads, nthreads=nt)
-    set_tuning()
-    got = Hh.hip_run(s, grads)
-    assert (got["radii"] == st["radii"]).all()
-    for k in ("out_color", "out_depth", "out_unc"):
-        d = np.abs(got[k] - st[k])
-        assert (d > 1e-4).mean() <= 1e-4 and d.max() < 0.05, (k, float(d.max()), float((d > 1e-4).mean()))
-    for k in Hh.GRAD_KEYS:
-        if k in ref and k in got:
-            r = Hh.grad_report(got[k], ref[k], 1e-3)
-            assert r["p999"] <= 1e-3 and r["n_bad"] <= 1e-4 * r["n"], (k, r)
+    per pass on the GPU box's host cores.  Radii bit-exact for every Gaussian.
+    shipped build (v_exp_f32 / v_rcp_f32 / pre-scaled quadratic form): images within 1e-4 except threshold flips (a pair at
+      alpha = 1/255 or T = 1e-4 to the ulp), bounded at 1e-4 of the pixels and 5e-3 in size; gradients: 99.9th percentile
+      inside 1e-3 and at most 1e-4 of the elements outside it (measured: p99.9 ~ 6e-6, ~3e-6 of the elements).
+    parity build (libgsraster_precise.so: the reference's own expression, libm expf, IEEE division, no contraction): the
+      north-star's bar on EVERY element -- see the assertion below for what is left at this size."""
+    r = _full_size_report("libgsraster_precise.so" if build == "precise" else None, seed, P, W, H, use)
+    assert r["lib"] == ("libgsraster_precise.so" if build == "precise" else "libgsraster.so")
+    assert r["radii_equal"]
+    print(f"\n[{build}] P={P} {W}x{H}: " + ", ".join(f"{k}: {v['gt_1e-4']} px > 1e-4 (max {v['max']:.2e})" for k, v in r["images"].items()))
+    print(f"[{build}] gradients: " + ", ".join(f"{k}: {v['n_bad']} > 1e-3 (max {v['max']:.2e})" for k, v in r["grads"].items()))
+    if build == "precise":
+        for k, v in r["images"].items():
+            assert v["gt_1e-4"] <= PRECISE_MAX_PIXELS and v["max"] < 5e-3, (k, v)
+        for k, v in r["grads"].items():
+            assert v["n_bad"] <= PRECISE_MAX_GRAD_ELEMS and v["p999"] <= 1e-4, (k, v)
+        return
+    for k, v in r["images"].items():
+        assert v["gt_1e-4"] <= 1e-4 * v["n"] and v["max"] < 5e-3, (k, v)
+    for k, v in r["grads"].items():
+        assert v["p999"] <= 1e-3 and v["n_bad"] <= 1e-4 * v["n"], (k, v)

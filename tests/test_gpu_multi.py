@@ -122,6 +122,54 @@ def test_two_ranks_one_gpu_collectives_and_images(native_lib, tmp_path):
                  "passed on gloo.  The N-GPU RCCL run is the driver's scaling bench.")
 
 
+def _rccl_world1_worker(port, outdir):
+    from gscream_amd import multi
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    status = {"ok": False}
+    try:
+        dev = torch.device("cuda", multi.pick_device(0))
+        torch.cuda.set_device(dev)
+        assert multi.init("nccl", dev) is None, "a world of one needs no process group unless forced"
+        dist = multi.init("nccl", dev, force=True)  # communicator creation goes through librccl
+        assert dist is not None and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        multi.barrier(dist, dev)                     # ncclAllReduce under the hood + device sync
+        total, tmax, rate = multi.aggregate_throughput(dist, 40, 2.0, dev)  # the two reductions of bench.py's report, on the device
+        x = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+        y = x.clone()
+        dist.all_reduce(y)                           # a real RCCL kernel on a megabyte-sized device buffer
+        torch.cuda.synchronize(dev)
+        q = multi.SceneQueue(dist, 3)                # TCPStore counter of the process group
+        pulled = [i for i in iter(q.pull, None)]
+        gathered = multi.gather_objects(dist, {"rank": 0, "pulled": pulled})
+        status.update(ok=True, total=total, tmax=tmax, rate=rate, same=bool(torch.equal(x, y)), pulled=pulled, gathered=gathered,
+                      backend=dist.get_backend(), nccl_version=list(torch.cuda.nccl.version()))
+        multi.barrier(dist, dev)
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        status["error"] = repr(e)
+    json.dump(status, open(os.path.join(outdir, "status.json"), "w"))
+
+
+def test_rccl_comes_up_with_a_world_of_one(native_lib, tmp_path):
+    """The only RCCL evidence a 1-GPU box can give: the `nccl` backend (== RCCL on ROCm) initialises, and the barrier,
+    the report reductions, a device all-reduce, the work queue and the report gather all run on it."""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(240)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL world-size-1 bring-up hung")
+    f = tmp_path / "status.json"
+    assert f.exists(), f"worker died with exit code {p.exitcode}"
+    st = json.load(open(f))
+    assert st["ok"], st
+    assert st["backend"] == "nccl" and (st["total"], st["tmax"], st["rate"]) == (40.0, 2.0, 20.0) and st["same"]
+    assert st["pulled"] == [0, 1, 2] and st["gathered"] == [{"rank": 0, "pulled": [0, 1, 2]}]
+    print("RCCL (nccl backend) world size 1: OK, version", st["nccl_version"])
+
+
 def _bench(*extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
@@ -157,3 +205,5 @@ def test_config5_work_queue_runs_every_scene_once(native_lib):
     assert [s["scene"] for s in line["scenes"]] == list(range(10)) and line["scaling"] == "strong"
     assert {s["rank"] for s in line["scenes"]} == {0, 1}, "both ranks pulled work"
     assert all(600_000 <= s["P"] <= 1_400_000 for s in line["scenes"])
+    assert line["checks_passed"] == 10 and all(s["check_ok"] for s in line["scenes"]), "every scene's outputs are checked on its rank"
+    assert line["wall_clock"]["seconds_first_to_last_barrier"] >= line["slowest_rank_busy_s"]

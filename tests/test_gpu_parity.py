@@ -406,6 +406,31 @@ def test_debug_mode_and_determinism():
         assert np.array_equal(b[k], c[k]) and np.array_equal(a[k], b[k]), f"{k}: the backward is bit-reproducible"
 
 
+def test_prefiltered_promise_is_checked_in_debug_mode(tmp_path, monkeypatch):
+    """DGR auxiliary.h:154-162: a point that fails the near plane although `prefiltered` is set is a contract violation (the
+    reference prints and traps the kernel).  Here: an error of the call in debug mode, ignored otherwise."""
+    from gscream_amd import GaussianRasterizer
+    monkeypatch.chdir(tmp_path)  # debug mode dumps snapshot_fw.dump on failure, like the reference
+    s = S.scene_config1(seed=3, P=500, W=64, H=64)
+    s["means3D"][:7, 2] = 0.1  # seven points in front of the near plane (view-space z <= 0.2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = dict(means3D=t(s["means3D"]), means2D=torch.zeros(500, 3, device="cuda"), opacities=t(s["opacities"]),
+                uncertainties=t(s["uncertainties"]), colors_precomp=t(s["colors"]), scales=t(s["scales"]), rotations=t(s["rotations"]))
+    base = Hh.hip_settings(s)
+    ref = GaussianRasterizer(base)(**args)
+    out = GaussianRasterizer(base._replace(prefiltered=True))(**args)           # not debug: the flag changes nothing
+    assert all(torch.equal(a, b) for a, b in zip(ref, out)) and int((out[3][:7] == 0).sum()) == 7
+    with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set.*7 of 500"):
+        GaussianRasterizer(base._replace(prefiltered=True, debug=True))(**args)
+    with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
+        GaussianRasterizer(base._replace(prefiltered=True, debug=True)).visible_filter(args["means3D"], args["scales"], args["rotations"])
+    s["means3D"][:7, 2] = 3.0                                                   # promise kept: debug mode passes
+    args["means3D"] = t(s["means3D"])
+    a = GaussianRasterizer(base._replace(prefiltered=True, debug=True))(**args)
+    b = GaussianRasterizer(base)(**args)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_non_default_stream_and_strided_inputs():
     s, grads, exp = MG.load("cfg1")
     st = torch.cuda.Stream()

@@ -37,7 +37,13 @@ def _worker(rank, world, port, out):
     multi.barrier(dist)
     pulled = [i for i in iter(multi.SceneQueue(dist, 10).pull, None)]  # config 5: shared work queue
     multi.barrier(dist)
-    out[rank] = (my_scenes, total, tmax, rate, multi.scene_seed(7, rank, world), pulled, multi.gather_objects(dist, pulled))
+    # a SECOND queue in the same process group starts at zero again (its own counter key), and a local queue in between
+    # (dist=None) does not shift the key the ranks agree on
+    if rank == 0:
+        multi.SceneQueue(None, 2).pull()
+    pulled2 = [i for i in iter(multi.SceneQueue(dist, 4).pull, None)]
+    multi.barrier(dist)
+    out[rank] = (my_scenes, total, tmax, rate, multi.scene_seed(7, rank, world), pulled, multi.gather_objects(dist, pulled), pulled2)
     dist.destroy_process_group()
 
 
@@ -57,6 +63,7 @@ def test_two_rank_gloo_throughput_reduction():
     # the work queue hands every one of the ten scenes to exactly one rank, and the report gather sees both shares
     assert sorted(out[0][5] + out[1][5]) == list(range(10))
     assert out[0][6] == out[1][6] == [out[0][5], out[1][5]]
+    assert sorted(out[0][7] + out[1][7]) == list(range(4)), "second queue of the same group hands out 0..3 again"
 
 
 def test_single_process_needs_no_process_group():
@@ -88,6 +95,9 @@ def test_bench_refuses_gpus_without_devices():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # at most one device visible to the subprocess: the refusal must not depend on how many GPUs the box has
+    # (on the 8-GPU target node `--gpus 8` would otherwise launch a real 8-rank bench)
+    env.update(HIP_VISIBLE_DEVICES="0", CUDA_VISIBLE_DEVICES="0", ROCR_VISIBLE_DEVICES="0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "one process per GPU" in (p.stderr + p.stdout)

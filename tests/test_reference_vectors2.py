@@ -250,18 +250,40 @@ def test_hip_decode_matches_reference_generate_neural_gaussians(name):
     sure = np.abs(nop_ref.reshape(-1)) > 1e-5                       # an opacity within rounding of 0 may flip the mask
     mask = res[7].cpu().numpy()
     assert np.array_equal(mask[sure], mask_ref[sure])
-    if not np.array_equal(mask, mask_ref):
-        pytest.skip("an opacity within fp32 rounding of zero flipped the mask on this case; rows are not comparable one to one")
-    for k, v in zip(MR.DECODE_OUT, res[:6]):
-        ref = DEC[f"{name}_{k}"]
-        assert np.abs(v.detach().cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
-    loss = MR.decode_loss([r.double() for r in res[:6]], c["seed"])
+    flipped = int((mask != mask_ref).sum())
     params = dict(dut.named_parameters())
-    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    if flipped == 0:
+        for k, v in zip(MR.DECODE_OUT, res[:6]):
+            ref = DEC[f"{name}_{k}"]
+            assert np.abs(v.detach().cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+        loss = MR.decode_loss([r.double() for r in res[:6]], c["seed"])
+        grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+        gtol = 2e-4
+    else:
+        # An opacity within fp32 rounding of zero flipped the mask: the outputs are boolean-mask compacted, so the rows are
+        # compared ALIGNED -- row of offset i in ours vs. row of offset i in the reference, for every offset both kept.  The
+        # upstream weights of the reference's loss are carried over the same way (zero for a row only we kept), so the parameter
+        # gradients differ by the handful of rows only the reference kept: bounded, looser tolerance, count printed.
+        print(f"[mask flips] {name}: {flipped} offsets with |opacity| <= 1e-5 flipped; comparing row-aligned")
+        both = mask & mask_ref
+        mine = (np.cumsum(mask) - 1)[both]        # our row of every offset both kept
+        theirs = (np.cumsum(mask_ref) - 1)[both]  # the reference's row of the same offset
+        gen = torch.Generator().manual_seed(c["seed"] + 99)
+        ups = []
+        for k, v in zip(MR.DECODE_OUT, res[:6]):
+            ref = DEC[f"{name}_{k}"]
+            got = v.detach().cpu().numpy()
+            assert np.abs(got[mine] - ref[theirs]).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+            w_ref = torch.randn(ref.shape, generator=gen, dtype=torch.float64)   # MR.decode_loss's weights, in its order
+            w = torch.zeros(got.shape, dtype=torch.float64)
+            w[torch.from_numpy(mine)] = w_ref[torch.from_numpy(theirs)]
+            ups.append(w.to(v.device, v.dtype))
+        grads = torch.autograd.grad(list(res[:6]), list(params.values()), ups, allow_unused=True)
+        gtol = 2e-4 + 2e-3 * flipped
     for k, g in zip(params, grads):
         ref = DEC[f"{name}_grad_{k}"]
         got = np.zeros_like(ref) if g is None else g.cpu().numpy()
-        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12), k
+        assert np.abs(got - ref).max() <= gtol * max(np.abs(ref).max(), 1e-12), k
 
 
 @pytest.mark.gpu

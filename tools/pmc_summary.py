@@ -90,6 +90,10 @@ def main():
         if st and "SQ_INSTS_VALU" in v and launches[st]["FETCH_SIZE"]:
             insts[st] += v["SQ_INSTS_VALU"][0] / max(v["SQ_INSTS_VALU"][1], 1) * (v["SQ_INSTS_VALU"][1] / max(launches_of(tot, st), 1))
     cur[workload]["_insts_valu"] = {k: round(v) for k, v in insts.items()}
+    # provenance: which kernels these counters were measured on (bench.py refuses to replay them onto other kernels)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import provenance
+    cur[workload]["_provenance"] = provenance.stamp()
     json.dump(cur, open(path, "w"), indent=1)
 
 
