@@ -501,7 +501,8 @@ def host_floor_row(dev, W, H):
     """Host cost of one fwd+bwd step through the public API: the step loop on a 1k-Gaussian scene, where the kernels are
     negligible and the wall time is Python + ctypes + allocator + autograd engine + HIP launches + the num_rendered wait."""
     sb = SceneBench(dev, 1000, W, H, 1, 1, (True, False, False))
-    for _ in range(50):
+    gpu_spin_up(dev)  # the step waits for the GPU once (num_rendered): idle clocks would show up as host time
+    for _ in range(200):
         sb.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

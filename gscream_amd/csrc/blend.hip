@@ -83,6 +83,21 @@ extern "C" int gsr_debug_trace(void* host_dst, size_t bytes)
 #define GSR_TRACE_END_AT(NW, BASE)
 #endif
 
+// -DGSR_COUNT (diagnostic build, `make variant SRC=blend NAME=count FLAGS=-DGSR_COUNT`; tools/blend_counts.py): how many
+// (instance, strip) iterations the backward runs, how many of them blend at least one pixel, and how many pixels blend.
+#ifdef GSR_COUNT
+__device__ unsigned long long gsr_cnt[8];
+#define GSR_COUNT_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gsr_cnt[i], (unsigned long long)(v)); } while (0)
+extern "C" int gsr_debug_counters(void* host_dst, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gsr_cnt), sizeof(gsr_cnt));
+    if (e == hipSuccess && reset) { unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(gsr_cnt), z, sizeof(z)); }
+    return (int)e;
+}
+#else
+#define GSR_COUNT_ADD(i, v)
+#endif
+
 // Lane selects on wave-uniform 64-bit masks (compares write SGPR pairs, the logic between them is scalar).
 __device__ __forceinline__ float gsr_sel(unsigned long long m, float if_set, float if_clear) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : if_clear; }
 __device__ __forceinline__ float gsr_sel0(unsigned long long m, float if_set) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : 0.0f; }
@@ -350,6 +365,9 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 #endif
             };
             const unsigned long long okma = cma & ~donem;
+            GSR_COUNT_ADD(4, 1);                                 // forward: pair iterations
+            GSR_COUNT_ADD(5, (okma != 0ull) + ((cmb & ~donem) != 0ull));  // ... instances of them that blend a pixel
+            GSR_COUNT_ADD(6, __popcll(okma) + __popcll(cmb & ~donem));
             if (okma != 0ull) blend(okma, al.x, __builtin_amdgcn_readfirstlane(__float_as_int(P3.x)), P3.z);
             const unsigned long long okmb = cmb & ~donem;  // after a: pixels it finished no longer blend b
             if (okmb != 0ull) blend(okmb, al.y, __builtin_amdgcn_readfirstlane(__float_as_int(P3.y)), P3.w);
@@ -583,7 +601,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                                                     __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
                     const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
                                                     __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
+                    GSR_COUNT_ADD(0, 1);
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
+                        GSR_COUNT_ADD(1, 1);
+                        GSR_COUNT_ADD(2, __popcll(okma) + __popcll(okmb));
+                        GSR_COUNT_ADD(3, (okma != 0ull) != (okmb != 0ull));  // only one 8x8 half of the strip blends
                         const gsr_f2 ae = {gsr_sel0(okma, alpha.x), gsr_sel0(okmb, alpha.y)};
                         const gsr_f2 Ge = {gsr_sel0(okma, G.x), gsr_sel0(okmb, G.y)};
                         const float4 C = sC[j];

@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 from gscream_amd import GaussianRasterizationSettings, _native, _layout, rasterizer
 from gscream_amd import synthetic as S
 from gscream_amd.neural_gaussians import generate_neural_gaussians
-from oracle import decode_oracle as DO
+from gscream_amd import standin_model as DO
 
 W, H, N, K = 1008, 567, 200_000, 10
 dev = torch.device("cuda", 0)
@@ -40,3 +40,6 @@ print("opacity pct", q, np.round(np.percentile(opacity.detach().cpu().numpy(), q
 print("scaling pct", q, np.round(np.percentile(scaling.detach().cpu().numpy(), q), 4))
 print("list length pct", q, np.percentile(n, q).astype(int), "mean", n.mean())
 print("traversed   pct", q, np.percentile(work, q).astype(int), "mean", work.mean(), "sum/sumlist", work.sum() / max(n.sum(), 1))
+per_wave = np.add.reduceat(tiles.astype(np.int64), np.arange(0, P, 64))
+print("tiles per Gaussian pct", q, np.percentile(tiles[r > 0], q).astype(int))
+print("slots per 64-Gaussian wave pct", q, np.percentile(per_wave, q).astype(int), "mean", per_wave.mean(), "top5", np.sort(per_wave)[-5:])
