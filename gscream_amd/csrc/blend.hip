@@ -155,6 +155,41 @@ __device__ __forceinline__ void gsr_bank_reduce(const float (&s)[11], float& q0,
     }
 }
 
+// Variant of the row-level reduction for the lane map  pixel row = 2 (lane >> 4) + (lane & 1), column = (lane >> 1) & 7
+// (GSR_BWD_DYF): the four lanes a DPP row's bank steps add up (l, l+4, l+8, l+12) then share their pixel row, i.e. dy, so
+// the three dy-weighted moments need not be reduced at all -- they are dy and dy^2 times the bank-level sums of (sum g,
+// sum g dx), formed between the two steps: 6 (8) values enter the butterfly instead of 9 (11).
+//   non-AUX: q0 = {c0, c1, c2, Mxx}  q1 = {M0, Mx, My, Mxy}  q2 = {Myy, -, -, -}
+//   AUX:     q0 = {c0, c1, c2, d}    q1 = {u, Mxx, M0, Mx}   q2 = {My, Mxy, Myy, -}
+template <bool AUX>
+__device__ __forceinline__ void gsr_bank_reduce_dyf(float c0, float c1, float c2, float d, float u, float sx, float mxx, float gs,
+                                                    float dy, float& q0, float& q1, float& q2)
+{
+    float r0, r1, r2, r3, r4, r5;
+    if (AUX) {
+        asm volatile("s_nop 1\n\t" GSR_PAIR4("%0", "%4", "%5") GSR_PAIR4("%1", "%6", "%7") GSR_PAIR4("%2", "%8", "%9")
+                     GSR_PAIR4("%3", "%10", "%11") "s_nop 1"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                     : "v"(c0), "v"(c1), "v"(c2), "v"(d), "v"(u), "v"(mxx), "v"(gs), "v"(sx));
+        r4 = r3 * dy;   // even banks: dy sum g (My), odd banks: dy sum g dx (Mxy)
+        r5 = r4 * dy;   // even banks: dy^2 sum g (Myy)
+        asm volatile("s_nop 1\n\t" GSR_PAIR8("%0", "%3", "%4") GSR_PAIR8("%1", "%5", "%6") GSR_PAIR8("%2", "%7", "%8") "s_nop 1"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2)
+                     : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5));
+    } else {
+        asm volatile("s_nop 1\n\t" GSR_PAIR4("%0", "%3", "%4") GSR_PAIR4("%1", "%5", "%6") GSR_PAIR4("%2", "%7", "%8") "s_nop 1"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                     : "v"(c0), "v"(c1), "v"(c2), "v"(mxx), "v"(gs), "v"(sx));
+        r3 = r2 * dy;
+        r4 = r3 * dy;
+        asm volatile("s_nop 1\n\t" GSR_PAIR8("%0", "%3", "%4") GSR_PAIR8("%1", "%5", "%6")
+                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2)
+                     : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4));
+    }
+}
+
 // The instance loops are software-pipelined: the wave's list indices sit one per lane (v_readlane instead of a
 // dependent LDS read) and the operands of instance k+1 are in flight while instance k is computed (measured winner
 // against the plain loop, profiles/).
@@ -475,8 +510,14 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + seg_len);
     if (seg_hi <= seg_lo) return;
 
+#ifdef GSR_BWD_DYF
+    // lanes l, l+4, l+8, l+12 of a DPP row share their pixel row (see gsr_bank_reduce_dyf)
+    const int pxa = tx * 16 + ((lane >> 1) & 7), pxb = pxa + 8;
+    const int py = ty * 16 + wave * 8 + 2 * (lane >> 4) + (lane & 1);
+#else
     const int pxa = tx * 16 + (lane & 7), pxb = pxa + 8;
     const int py = ty * 16 + wave * 8 + (lane >> 3);
+#endif
     const gsr_f2 pxf = {(float)pxa, (float)pxb};
     const float pyf = (float)py;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
@@ -546,8 +587,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     {
         const int row = lane >> 4, bank = (lane >> 2) & 3;
         if ((lane & 3) == 0) {
+#ifdef GSR_BWD_DYF
+            // slot fields: 0-2 colour, 3 depth, 4 feature, 5 Mx, 6 My, 7 Mxx, 8 Mxy, 9 Myy, 10 M0
+            const int f0a[4] = {0, 1, 2, 3}, f1a[4] = {4, 7, 10, 5}, f2a[4] = {6, 8, 9, -1};
+            const int f0n[4] = {0, 1, 2, 7}, f1n[4] = {10, 5, 6, 8}, f2n[4] = {9, -1, -1, -1};
+            if (AUX) accfield = row == 0 ? f0a[bank] : row == 2 ? f1a[bank] : row == 1 ? f2a[bank] : -1;
+            else accfield = row == 0 ? f0n[bank] : row == 2 ? f1n[bank] : row == 1 ? f2n[bank] : -1;
+#else
             if (AUX) accfield = row == 0 ? bank : row == 2 ? 4 + bank : (row == 1 && bank < 3) ? 8 + bank : -1;
             else accfield = row == 0 ? (bank < 3 ? bank : 5) : row == 2 ? 6 + bank : (row == 1 && bank == 0) ? 10 : -1;
+#endif
         }
     }
 
@@ -555,6 +604,28 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     // the backmost instance of the batch
     for (int hi = seg_hi; hi > seg_lo; hi -= seg_len) {
         const int lo = max(seg_lo, hi - seg_len), cnt = hi - lo;
+#ifdef GSR_BWD_SPLIT_STAGE
+        if (SL == 64) {
+            // both wavefronts stage: wave 0 fetches {a, b} of instance `lane`, wave 1 {c, d} + the slot offset; the strip
+            // test below then runs on both (one box test per wave and instance instead of four quadrant tests on wave 0)
+            if (lane < cnt) {
+                const uint32_t id = point_list[rg.x + (hi - 1 - lane)];
+                const GsrRec* r = rec + id;
+                if (wave == 0) {
+                    sA[lane] = r->a; sB[lane] = r->b;
+                } else {
+                    const uint32_t slot0 = offsets[id];
+                    const uint4 d = r->d;
+                    const float4 c = r->c;
+                    const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)__float_as_uint(c.w);
+                    const int pos = (ty - y0) * wd + (tx - x0);
+                    const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
+                    sSlot[lane] = slot0 + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
+                    sC[lane] = c;
+                }
+            }
+        } else
+#endif
         if (t < cnt) {
             const uint32_t id = point_list[rg.x + (hi - 1 - t)];
             const GsrRec* r = rec + id;
@@ -573,7 +644,30 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
         __syncthreads();
         {
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
+#ifdef GSR_BWD_SPLIT_STAGE
+            int nw;
+            if (SL == 64) {
+                bool hit = false;
+                if (lane < cnt && hi - 1 - lane < wmax) {
+                    const float4 a = sA[lane], b = sB[lane];
+#ifdef GSR_PRECISE_MATH
+                    const float ca = GSR_QSCALE(a.z), cb = GSR_QSCALE(a.w), cc = GSR_QSCALE(b.x);
+#else
+                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;
+#endif
+                    const int sx0 = tx * 16, sy0 = ty * 16 + wave * 8;  // this wavefront's 16x8 strip
+                    hit = sy0 < H && !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), (float)sx0, (float)min(sx0 + 15, W - 1),
+                                                     (float)sy0, (float)min(sy0 + 7, H - 1)) > gsr_cull_tau_fast(b.y) * GSR_LOG2E);
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (hit) mylist[__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)lane;
+                nw = __popcll(bal);
+            } else {
+                nw = gsr_compact2<SL>(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
+            }
+#else
             const int nw = gsr_compact2<SL>(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
+#endif
             __builtin_amdgcn_wave_barrier();
             for (int c0 = 0; c0 < nw; c0 += 64) {
                 const int m = min(64, nw - c0);
@@ -595,17 +689,29 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
 #endif
                     const gsr_f2 G = {gsr_gauss1(power.x), gsr_gauss1(power.y)};
                     const gsr_f2 al = B.y * G;
+#ifdef GSR_BWD_LATE_CLAMP
+                    // alpha >= 1/255 tested on the unclamped product (0.99 > 1/255: same truth value, as in the forward); the
+                    // clamp of backward.cu:524 is applied only in iterations that blend something
+                    const unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
+                                                    __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
+                    const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
+                                                    __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
+#else
                     const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
                     // lane masks straight from the compares, combined on the scalar unit (see the forward)
                     const unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
                                                     __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
                     const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
                                                     __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
+#endif
                     GSR_COUNT_ADD(0, 1);
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
                         GSR_COUNT_ADD(1, 1);
                         GSR_COUNT_ADD(2, __popcll(okma) + __popcll(okmb));
                         GSR_COUNT_ADD(3, (okma != 0ull) != (okmb != 0ull));  // only one 8x8 half of the strip blends
+#ifdef GSR_BWD_LATE_CLAMP
+                        const gsr_f2 alpha = {__builtin_amdgcn_fmed3f(al.x, 0.99f, -3.0e38f), __builtin_amdgcn_fmed3f(al.y, 0.99f, -3.0e38f)};
+#endif
                         const gsr_f2 ae = {gsr_sel0(okma, alpha.x), gsr_sel0(okmb, alpha.y)};
                         const gsr_f2 Ge = {gsr_sel0(okma, G.x), gsr_sel0(okmb, G.y)};
                         const float4 C = sC[j];
@@ -627,6 +733,20 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                         // g = G * dL/dalpha: sum g dx, sum g dy, sum g dx^2, sum g dx dy, sum g dy^2, sum g.  The
                         // per-Gaussian factors (conic, opacity, -1/2, viewport scale) are applied once per instance at
                         // flush time.
+                        float q0, q1, q2;
+#ifdef GSR_BWD_DYF
+                        {
+                            const gsr_f2 w0 = w * g0, w1 = w * g1, w2 = w * g2;
+                            float sd = 0.f, su = 0.f;
+                            if (AUX) {
+                                const gsr_f2 w3 = w * gd, w4 = w * gu;
+                                sd = w3.x + w3.y; su = w4.x + w4.y;
+                            }
+                            const gsr_f2 gdx = g * dx, mxx = gdx * dx;
+                            gsr_bank_reduce_dyf<AUX>(w0.x + w0.y, w1.x + w1.y, w2.x + w2.y, sd, su, gdx.x + gdx.y, mxx.x + mxx.y, g.x + g.y,
+                                                     dy, q0, q1, q2);
+                        }
+#else
                         float s[11];
                         const gsr_f2 w0 = w * g0, w1 = w * g1, w2 = w * g2;
                         s[0] = w0.x + w0.y; s[1] = w1.x + w1.y; s[2] = w2.x + w2.y;
@@ -648,8 +768,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                         // add, and the two quad steps run last on the single remaining register.  23 (26) VALU ops
                         // for nine (eleven) values, then ONE ds_add_f32 from 9 (11) lanes with distinct addresses
                         // (an LDS atomic instruction costs ~13 LDS cycles whatever its lane count; measured).
-                        float q0, q1, q2;
                         gsr_bank_reduce<AUX>(s, q0, q1, q2);
+#endif
                         float v0, v1;
                         {
                             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(q0), __float_as_uint(q1), false, false);
