@@ -117,7 +117,7 @@ __device__ __forceinline__ float gsr_dpp(float v)
 // into one whose even banks (4-lane groups of a DPP row) hold a + rot(a) and whose odd banks hold b + rot(b): two
 // v_add_f32_dpp with complementary bank masks, no select.  The second step (row_ror:8) does the same with the bank
 // pairs {0,1} / {2,3}.  After both, bank k of the result holds, in each of its four lanes, the sum over the row's lanes
-// of equal (lane & 3) of one value: q0 = {s0, s1, s2, s3|s5}, q1 = {s4..s7 | s6..s9}, q2 = {s8, s9, s10, s10 | s10 x4}.
+// of equal (lane & 3) of one value (which value sits in which bank: gsr_bank_reduce_dyf below).
 // Inline assembly because the masked write of a DPP destination has no IR form; the s_nop cover the VALU-write ->
 // DPP-read hazard against the surrounding compiler-scheduled code (inside the block producers and consumers are
 // at least two instructions apart).
@@ -127,38 +127,10 @@ __device__ __forceinline__ float gsr_dpp(float v)
 #define GSR_PAIR8(dst, a, b)                                                     \
     "v_add_f32_dpp " dst ", " a ", " a " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
     "v_add_f32_dpp " dst ", " b ", " b " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-template <bool AUX>
-__device__ __forceinline__ void gsr_bank_reduce(const float (&s)[11], float& q0, float& q1, float& q2)
-{
-    if (AUX) {
-        float r0, r1, r2, r3, r4, r5;
-        asm volatile("s_nop 1\n\t"
-                     GSR_PAIR4("%3", "%9", "%10") GSR_PAIR4("%4", "%11", "%12") GSR_PAIR4("%5", "%13", "%14")
-                     GSR_PAIR4("%6", "%15", "%16") GSR_PAIR4("%7", "%17", "%18")
-                     "v_add_f32_dpp %8, %19, %19 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                     GSR_PAIR8("%0", "%3", "%4") GSR_PAIR8("%1", "%5", "%6") GSR_PAIR8("%2", "%7", "%8")
-                     "s_nop 1"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
-                     : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]),
-                       "v"(s[9]), "v"(s[10]));
-    } else {
-        float r0, r1, r2, r3, r4;
-        asm volatile("s_nop 1\n\t"
-                     GSR_PAIR4("%3", "%8", "%9") GSR_PAIR4("%4", "%10", "%11") GSR_PAIR4("%5", "%12", "%13")
-                     GSR_PAIR4("%6", "%14", "%15")
-                     "v_add_f32_dpp %7, %16, %16 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                     GSR_PAIR8("%0", "%3", "%4") GSR_PAIR8("%1", "%5", "%6")
-                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
-                     : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]));
-    }
-}
-
-// Variant of the row-level reduction for the lane map  pixel row = 2 (lane >> 4) + (lane & 1), column = (lane >> 1) & 7
-// (GSR_BWD_DYF): the four lanes a DPP row's bank steps add up (l, l+4, l+8, l+12) then share their pixel row, i.e. dy, so
-// the three dy-weighted moments need not be reduced at all -- they are dy and dy^2 times the bank-level sums of (sum g,
-// sum g dx), formed between the two steps: 6 (8) values enter the butterfly instead of 9 (11).
+// The backward's lane map is  pixel row = 2 (lane >> 4) + (lane & 1), column = (lane >> 1) & 7:  the four lanes a DPP row's
+// bank steps add up (l, l+4, l+8, l+12) then share their pixel row, i.e. dy, so the three dy-weighted moments need not
+// enter the butterfly at all -- they are dy and dy^2 times the first step's sums of (sum g, sum g dx), formed between the
+// two steps: 6 (8) values are reduced instead of 9 (11)  (round 3: 161 -> 155 us).
 //   non-AUX: q0 = {c0, c1, c2, Mxx}  q1 = {M0, Mx, My, Mxy}  q2 = {Myy, -, -, -}
 //   AUX:     q0 = {c0, c1, c2, d}    q1 = {u, Mxx, M0, Mx}   q2 = {My, Mxy, Myy, -}
 template <bool AUX>
@@ -510,14 +482,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + seg_len);
     if (seg_hi <= seg_lo) return;
 
-#ifdef GSR_BWD_DYF
     // lanes l, l+4, l+8, l+12 of a DPP row share their pixel row (see gsr_bank_reduce_dyf)
     const int pxa = tx * 16 + ((lane >> 1) & 7), pxb = pxa + 8;
     const int py = ty * 16 + wave * 8 + 2 * (lane >> 4) + (lane & 1);
-#else
-    const int pxa = tx * 16 + (lane & 7), pxb = pxa + 8;
-    const int py = ty * 16 + wave * 8 + (lane >> 3);
-#endif
     const gsr_f2 pxf = {(float)pxa, (float)pxb};
     const float pyf = (float)py;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
@@ -587,16 +554,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     {
         const int row = lane >> 4, bank = (lane >> 2) & 3;
         if ((lane & 3) == 0) {
-#ifdef GSR_BWD_DYF
             // slot fields: 0-2 colour, 3 depth, 4 feature, 5 Mx, 6 My, 7 Mxx, 8 Mxy, 9 Myy, 10 M0
             const int f0a[4] = {0, 1, 2, 3}, f1a[4] = {4, 7, 10, 5}, f2a[4] = {6, 8, 9, -1};
             const int f0n[4] = {0, 1, 2, 7}, f1n[4] = {10, 5, 6, 8}, f2n[4] = {9, -1, -1, -1};
             if (AUX) accfield = row == 0 ? f0a[bank] : row == 2 ? f1a[bank] : row == 1 ? f2a[bank] : -1;
             else accfield = row == 0 ? f0n[bank] : row == 2 ? f1n[bank] : row == 1 ? f2n[bank] : -1;
-#else
-            if (AUX) accfield = row == 0 ? bank : row == 2 ? 4 + bank : (row == 1 && bank < 3) ? 8 + bank : -1;
-            else accfield = row == 0 ? (bank < 3 ? bank : 5) : row == 2 ? 6 + bank : (row == 1 && bank == 0) ? 10 : -1;
-#endif
         }
     }
 
@@ -604,7 +566,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     // the backmost instance of the batch
     for (int hi = seg_hi; hi > seg_lo; hi -= seg_len) {
         const int lo = max(seg_lo, hi - seg_len), cnt = hi - lo;
-#ifdef GSR_BWD_SPLIT_STAGE
         if (SL == 64) {
             // both wavefronts stage: wave 0 fetches {a, b} of instance `lane`, wave 1 {c, d} + the slot offset; the strip
             // test below then runs on both (one box test per wave and instance instead of four quadrant tests on wave 0)
@@ -625,7 +586,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                 }
             }
         } else
-#endif
         if (t < cnt) {
             const uint32_t id = point_list[rg.x + (hi - 1 - t)];
             const GsrRec* r = rec + id;
@@ -644,7 +604,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
         __syncthreads();
         {
             // instance j sits at list position p = hi-1-j; this wave needs it only if p < wmax
-#ifdef GSR_BWD_SPLIT_STAGE
             int nw;
             if (SL == 64) {
                 bool hit = false;
@@ -665,9 +624,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
             } else {
                 nw = gsr_compact2<SL>(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
             }
-#else
-            const int nw = gsr_compact2<SL>(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
-#endif
             __builtin_amdgcn_wave_barrier();
             for (int c0 = 0; c0 < nw; c0 += 64) {
                 const int m = min(64, nw - c0);
@@ -689,29 +645,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
 #endif
                     const gsr_f2 G = {gsr_gauss1(power.x), gsr_gauss1(power.y)};
                     const gsr_f2 al = B.y * G;
-#ifdef GSR_BWD_LATE_CLAMP
                     // alpha >= 1/255 tested on the unclamped product (0.99 > 1/255: same truth value, as in the forward); the
                     // clamp of backward.cu:524 is applied only in iterations that blend something
                     const unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
                                                     __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
                     const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
                                                     __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
-#else
-                    const gsr_f2 alpha = {fminf(0.99f, al.x), fminf(0.99f, al.y)};
-                    // lane masks straight from the compares, combined on the scalar unit (see the forward)
-                    const unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
-                                                    __builtin_amdgcn_ballot_w64(alpha.x >= (1.0f / 255.0f));
-                    const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
-                                                    __builtin_amdgcn_ballot_w64(alpha.y >= (1.0f / 255.0f));
-#endif
                     GSR_COUNT_ADD(0, 1);
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
                         GSR_COUNT_ADD(1, 1);
                         GSR_COUNT_ADD(2, __popcll(okma) + __popcll(okmb));
                         GSR_COUNT_ADD(3, (okma != 0ull) != (okmb != 0ull));  // only one 8x8 half of the strip blends
-#ifdef GSR_BWD_LATE_CLAMP
                         const gsr_f2 alpha = {__builtin_amdgcn_fmed3f(al.x, 0.99f, -3.0e38f), __builtin_amdgcn_fmed3f(al.y, 0.99f, -3.0e38f)};
-#endif
                         const gsr_f2 ae = {gsr_sel0(okma, alpha.x), gsr_sel0(okmb, alpha.y)};
                         const gsr_f2 Ge = {gsr_sel0(okma, G.x), gsr_sel0(okmb, G.y)};
                         const float4 C = sC[j];
@@ -734,7 +679,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                         // per-Gaussian factors (conic, opacity, -1/2, viewport scale) are applied once per instance at
                         // flush time.
                         float q0, q1, q2;
-#ifdef GSR_BWD_DYF
                         {
                             const gsr_f2 w0 = w * g0, w1 = w * g1, w2 = w * g2;
                             float sd = 0.f, su = 0.f;
@@ -746,30 +690,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                             gsr_bank_reduce_dyf<AUX>(w0.x + w0.y, w1.x + w1.y, w2.x + w2.y, sd, su, gdx.x + gdx.y, mxx.x + mxx.y, g.x + g.y,
                                                      dy, q0, q1, q2);
                         }
-#else
-                        float s[11];
-                        const gsr_f2 w0 = w * g0, w1 = w * g1, w2 = w * g2;
-                        s[0] = w0.x + w0.y; s[1] = w1.x + w1.y; s[2] = w2.x + w2.y;
-                        if (AUX) {
-                            const gsr_f2 w3 = w * gd, w4 = w * gu;
-                            s[3] = w3.x + w3.y; s[4] = w4.x + w4.y;
-                        } else {
-                            s[3] = 0.f; s[4] = 0.f;
-                        }
-                        // both pixels of a lane share dy: sum(g dy) = dy sum(g), sum(g dx dy) = dy sum(g dx), sum(g dy^2) = dy^2 sum(g)
-                        const gsr_f2 gdx = g * dx, mxx = gdx * dx;
-                        const float gs = g.x + g.y, sx = gdx.x + gdx.y;
-                        s[5] = sx; s[7] = mxx.x + mxx.y; s[10] = gs;
-                        s[6] = gs * dy; s[8] = sx * dy; s[9] = s[6] * dy;
-                        // Wave reduction of the 9 (11) partials as a TRANSPOSING butterfly whose pair steps need no
-                        // selects: within a DPP row the two bank-level steps (row_ror:4, row_ror:8) write the two
-                        // halves of the destination with complementary bank masks (gsr_bank_reduce), the cross-row
-                        // steps are v_permlane32_swap / v_permlane16_swap of TWO different registers followed by one
-                        // add, and the two quad steps run last on the single remaining register.  23 (26) VALU ops
-                        // for nine (eleven) values, then ONE ds_add_f32 from 9 (11) lanes with distinct addresses
-                        // (an LDS atomic instruction costs ~13 LDS cycles whatever its lane count; measured).
-                        gsr_bank_reduce<AUX>(s, q0, q1, q2);
-#endif
                         float v0, v1;
                         {
                             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(q0), __float_as_uint(q1), false, false);
