@@ -933,7 +933,7 @@ def main():
                     out["next_rows"][name] = fn()
                 except Exception as e:  # noqa: BLE001
                     out["next_rows"][name] = {"error": repr(e)}
-        if world == 1 and not os.environ.get("GSR_LIB"):
+        if world == 1 and not args.no_next_rows and not os.environ.get("GSR_LIB"):
             try:
                 out["host_ms_per_step"] = host_floor_row(dev, W, H)
                 out["host_ms_per_step_note"] = ("fwd+bwd step loop on a 1k-Gaussian scene at the bench resolution: what the host path costs per step "
@@ -941,7 +941,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["host_ms_per_step"] = None
                 out["host_ms_per_step_note"] = repr(e)
-        if world == 1 and not args.no_strict_parity and not os.environ.get("GSR_LIB"):
+        if world == 1 and not args.no_next_rows and not args.no_strict_parity and not os.environ.get("GSR_LIB"):
             try:
                 out["strict_parity_build"] = strict_parity_row(args)
             except Exception as e:  # noqa: BLE001
