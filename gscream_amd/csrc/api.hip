@@ -118,8 +118,9 @@ extern "C" size_t gsr_image_bytes(int P, int W, int H) { return gsr_carve_image(
 extern "C" size_t gsr_binning_bytes(int R) { return gsr_carve_binning(nullptr, R).bytes; }
 extern "C" size_t gsr_backward_scratch_bytes(int P, int num_slots)
 {
-    (void)P;  // slots[num_slots], 48 B each
-    return gsr_align((size_t)(num_slots > 0 ? num_slots : 1) * GSR_SLOT_FLOATS * sizeof(float));
+    // slots[num_slots], 48 B each, + the per-Gaussian backward's list of heavy 64-Gaussian groups (count + indices)
+    return gsr_align((size_t)(num_slots > 0 ? num_slots : 1) * GSR_SLOT_FLOATS * sizeof(float)) +
+           gsr_align(((size_t)(P > 0 ? P : 1) / 64 + 18) * sizeof(uint32_t));
 }
 
 static int gsr_make_cam(GsrCam& cam, int W, int H, const float* view_d, const float* proj_d, const float* campos_d,
@@ -451,14 +452,18 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binnin
     if (binning_capacity < R) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "binning_capacity < R");
     const GsrBinning bin = gsr_carve_binning(const_cast<void*>(binning_ws), binning_capacity);
     float* slots = (float*)scratch;
+    // heavy[0] = number of heavy groups (zeroed by the backward blend, which always runs first), heavy[16..] = their indices
+    uint32_t* heavy = (uint32_t*)((char*)scratch + gsr_align((size_t)(R > 0 ? R : 1) * GSR_SLOT_FLOATS * sizeof(float)));
     // written-slot flags: cleared by the forward's tile sort, set by the backward blend, cleared again by the
     // per-Gaussian backward as it consumes them -- so a second backward over the same forward state works
     uint8_t* slot_written = bin.slot_written;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
-                                            dL_dout_feature, slots, slot_written, stream),
+                                            dL_dout_feature, slots, slot_written, heavy, stream),
                   "backward blend");
-    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots, slot_written, R,
+    else
+        GSR_HIP(hipMemsetAsync(heavy, 0, 2 * sizeof(uint32_t), stream), "heavy-group counters");
+    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots, slot_written, heavy, R,
                                         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures, dL_dmeans3D, dL_dcov3D,
                                         dL_dsh, dL_dscales, dL_drotations, stream),
               "per-Gaussian backward");

@@ -450,8 +450,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
-    int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots)
+    int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots,
+    uint32_t* __restrict__ heavy_groups)
 {
+    // the per-Gaussian backward that follows appends its heavy groups to a list: this launch, which always precedes it, resets
+    // the counter (gauss_bwd.hip)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { heavy_groups[0] = 0u; heavy_groups[1] = 0u; }
     static_assert(SL == 64 || SL == GSR_SEG_LEN, "segment lengths of gsr_seg_len()");
     __shared__ float4 sA[SL], sB[SL], sC[SL];
     // one accumulator array PER WAVEFRONT: a wave's LDS adds are program-ordered and nobody else touches its copy, the flush
@@ -763,7 +767,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots, uint8_t* slot_written,
-                                     hipStream_t stream)
+                                     uint32_t* heavy_groups, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
@@ -773,7 +777,7 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 #define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
-                       geom.offsets, slot_written, s4)
+                       geom.offsets, slot_written, s4, heavy_groups)
     if (dL_ddepth && dL_dfeature) {
         if (sl == 64) GSR_BWD_LAUNCH(true, 64, dL_ddepth, dL_dfeature);
         else GSR_BWD_LAUNCH(true, GSR_SEG_LEN, dL_ddepth, dL_dfeature);

@@ -96,143 +96,51 @@ __device__ __forceinline__ float3 gsr_sh_backward(int idx, int deg, int M, float
     return r;
 }
 
-#ifndef GSR_K7_BS
-#define GSR_K7_BS 64
-#endif
-#ifndef GSR_K7_WAVES
-#define GSR_K7_WAVES 4  // minimum waves per SIMD the register allocation has to leave room for (3: 72 us, 4: 68 us, 5: spills, 109 us)
-#endif
-__global__ void __launch_bounds__(GSR_K7_BS, GSR_K7_WAVES) gsr_gauss_bwd_kernel(
-    int P, int D, int M, const GsrCam cam, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
-    const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const uint2* __restrict__ rect,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles, int num_slots,
-    const float4* __restrict__ slots, uint8_t* __restrict__ slot_written, float* __restrict__ dL_dmeans2D,
-    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeatures,
-    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations)
-{
-    // One wave per block owns 64 consecutive Gaussians; their gradient slots are one contiguous range [S0, S1) of
-    // `slots` (offsets[] is the exclusive scan of the per-Gaussian slot counts).  The backward blend writes a slot only
-    // for instances it traversed (slot_written[s] = 1, zeroed per call): on the bench scene three quarters of the
-    // instances lie behind the depth where their tile saturates.  The wave therefore
-    //   1. reads the flag bytes of its range (coalesced), turns them into 64-bit masks + running counts (ballot),
-    //   2. builds the compact list of written slots and fetches only those, 3 lanes per 48-byte slot, into LDS,
-    //   3. lets every lane sum its own written slots out of LDS in ascending slot order (double accumulators).
-    // Three dependent memory round trips per wave instead of two per 128-slot chunk; the per-Gaussian inputs of the
-    // second half are requested before any of it.
-    constexpr int BS = GSR_K7_BS;
-    static_assert(BS == 64, "one wave per block");
-    constexpr int FCH = 512;  // flags per pass (per-wave ranges average ~170 slots)
-    constexpr int WCH = 128;  // written slots staged per sub-pass (48 B each)
-    __shared__ float4 stage[WCH * 3];
-    __shared__ uint16_t wl[FCH];
-    __shared__ unsigned long long gmask[FCH / 64];
-    __shared__ uint32_t gbase[FCH / 64 + 1];
-    const int lane = threadIdx.x;
-    const int g0 = blockIdx.x * BS;
-    const int idx = g0 + lane;
-    const bool live = idx < P;
-    const bool vis = live && radii[idx] > 0;
-    const uint32_t off = live ? offsets[idx] : 0u;
-    const uint32_t cnt = live ? tiles[idx] : 0u;
-    // clamped to the slot count: a forward that binned nothing (num_slots = 0) need not have produced offsets
-    const uint32_t S1 = min((g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots, (uint32_t)num_slots);
-    const uint32_t S0 = min(offsets[g0], S1);
-    // early requests for the per-Gaussian half (independent of the slot phase)
-    float3 m = make_float3(0.f, 0.f, 0.f), sc = make_float3(0.f, 0.f, 0.f);
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vis) {
-        m = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-        if (!cov3D_precomp) {
-            sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-            q = reinterpret_cast<const float4*>(rotations)[idx];
-        }
-    }
-    double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
-    // Waves that hold a Gaussian with many slots (large splats: hundreds of tiles) spread the summation over the lanes
-    // as (Gaussian, field) tasks instead of letting that Gaussian's lane walk all its slots 11 fields at a time while
-    // 63 lanes wait: 11 consecutive lanes share a Gaussian, each sums one field in the same ascending order (so both
-    // schemes give the same bits).  Wave-uniform choice from the slot counts.  (Costs registers: 3 instead of 4 waves
-    // per SIMD; measured faster on every bench workload all the same: 75 -> 74, 100 -> 85, 218 -> 194 us, and 496 -> ~150
-    // on a scene of large splats.)
-    // (the per-lane task sums of the spread scheme stay in registers, acc[k] for task k * 64 + lane; one transposition
-    // through LDS -- aliased onto `stage`, which is free by then -- hands every Gaussian's 11 sums to its own lane)
-    double* accG = reinterpret_cast<double*>(stage);
-    static_assert(sizeof(double) * BS * 11 <= sizeof(float4) * WCH * 3, "accG must fit into the staging buffer");
-    __shared__ uint32_t sCi0[BS], sCi1[BS];
-    uint32_t cmax = cnt;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
-    const bool spread = cmax > 24u;
-    for (uint32_t base = S0; base < S1; base += FCH) {
-        const uint32_t nf = min(S1 - base, (uint32_t)FCH);
-        uint8_t f[FCH / 64];
-#pragma unroll
-        for (int k = 0; k < FCH / 64; k++) {
-            const uint32_t i = k * 64 + lane;
-            f[k] = i < nf ? slot_written[base + i] : (uint8_t)0;
-        }
-        uint32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < FCH / 64; k++) {
-            const unsigned long long mk = __ballot(f[k] != 0);
-            if (f[k]) wl[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(k * 64 + lane);
-            if (f[k]) slot_written[base + k * 64 + lane] = 0;  // consumed: the flags stay clear for the next backward
-            if (lane == 0) { gmask[k] = mk; gbase[k] = run; }
-            run += (uint32_t)__popcll(mk);
-        }
-        __syncthreads();
-        // A lane's written slots are consecutive entries [ci0, ci1) of the compact list: ci = number of written slots
-        // of the pass below the lane's first / past its last slot.  No flag test is left in the summation loop.
-        const uint32_t lo = min(max(off, base), base + nf) - base, hi = min(max(off + cnt, base), base + nf) - base;
-        uint32_t ci0 = run, ci1 = run;
-        if (lo < nf) ci0 = gbase[lo >> 6] + (uint32_t)__popcll(gmask[lo >> 6] & ((1ull << (lo & 63)) - 1ull));
-        if (hi < nf) ci1 = gbase[hi >> 6] + (uint32_t)__popcll(gmask[hi >> 6] & ((1ull << (hi & 63)) - 1ull));
-        for (uint32_t w0 = 0; w0 < run; w0 += WCH) {
-            const uint32_t nw = min(run - w0, (uint32_t)WCH);
-            float4 v[WCH * 3 / 64];
-#pragma unroll
-            for (int k = 0; k < WCH * 3 / 64; k++) {
-                const uint32_t i = lane + k * 64;
-                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < nw * 3) v[k] = slots[(size_t)(base + wl[w0 + i / 3]) * 3 + i % 3];
-            }
-#pragma unroll
-            for (int k = 0; k < WCH * 3 / 64; k++) stage[lane + k * 64] = v[k];
-            __syncthreads();
-            if (spread) {
-                if (w0 == 0) { sCi0[lane] = ci0; sCi1[lane] = ci1; }
-                __syncthreads();
-                const float* sf = reinterpret_cast<const float*>(stage);
-#pragma unroll
-                for (int k = 0; k < 11; k++) {
-                    const int task = k * BS + lane, g = task / 11, v = task - g * 11;
-                    const uint32_t e0 = max(sCi0[g], w0), e1 = min(sCi1[g], w0 + nw);
-                    for (uint32_t e = e0; e < e1; e++) acc[k] += sf[(e - w0) * 12 + v];
-                }
-            } else {
-                const uint32_t e0 = max(ci0, w0), e1 = min(ci1, w0 + nw);
-                for (uint32_t e = e0; e < e1; e++) {
-                    const float4 a = stage[(e - w0) * 3], b = stage[(e - w0) * 3 + 1], c = stage[(e - w0) * 3 + 2];
-                    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-                    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-                    acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();
-    }
-    if (spread) {  // transpose: task sums (k * 64 + lane) -> the 11 sums of Gaussian `lane`
-#pragma unroll
-        for (int k = 0; k < 11; k++) accG[k * BS + lane] = acc[k];
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < 11; v++) acc[v] = accG[lane * 11 + v];
-    }
-    if (!live) return;
+// Everything the two kernels below share: the caller's arrays.
+struct GsrGaussArgs {
+    int P, D, M;
+    GsrCam cam;
+    const float* means3D; const int32_t* radii; const float* shs; const uint8_t* clamped; const float* scales;
+    const float* rotations; const float* cov3D_precomp; const uint32_t* offsets; const uint32_t* tiles; int num_slots;
+    const float4* slots; uint8_t* slot_written;
+    uint32_t* heavy;  // [0] = number of heavy groups, [1] = groups fetched dynamically (both reset by the backward blend), [16 ..] = indices
+    float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dfeatures, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drotations;
+};
 
+// Groups of 64 consecutive Gaussians that own more than this many gradient slots go to the cooperative kernel (a few
+// large splats: the bench scene has none, a scene of large splats has them in ~1 % of its groups -- and they were its tail).
+#ifndef GSR_K7_HEAVY_SLOTS
+#define GSR_K7_HEAVY_SLOTS 1024
+#endif
+// Sum of n consecutive staged entries of one field, in ascending order, eight LDS reads in flight at a time (the adds stay
+// in order -- same bits as a plain loop --, only the read latency leaves the dependency chain: a plain loop took ~100
+// cycles per entry, and a splat that owns a whole 512-entry round made that the launch's critical path).
+__device__ __forceinline__ void gsr_sum_entries(double& acc, const float* sf, uint32_t n)
+{
+    uint32_t e = 0;
+    for (; e + 8 <= n; e += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = sf[(e + j) * 12];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += x[j];
+    }
+    for (; e < n; e++) acc += sf[e * 12];
+}
+
+// Second half of the per-Gaussian backward: from the 11 summed slot fields of Gaussian `idx` (acc) to its output rows.
+__device__ __forceinline__ void gsr_gauss_finish(const GsrGaussArgs& A, const int idx, const bool vis, const double (&acc)[11],
+                                                 const float3 m, const float3 sc, const float4 q)
+{
+    const GsrCam& cam = A.cam;
+    const int D = A.D, M = A.M;
+    const float* __restrict__ shs = A.shs;
+    const uint8_t* __restrict__ clamped = A.clamped;
+    const float* __restrict__ cov3D_precomp = A.cov3D_precomp;
+    float* __restrict__ dL_dmeans2D = A.dL_dmeans2D; float* __restrict__ dL_dcolors = A.dL_dcolors;
+    float* __restrict__ dL_dopacity = A.dL_dopacity; float* __restrict__ dL_dfeatures = A.dL_dfeatures;
+    float* __restrict__ dL_dmeans3D = A.dL_dmeans3D; float* __restrict__ dL_dcov3D = A.dL_dcov3D;
+    float* __restrict__ dL_dsh = A.dL_dsh; float* __restrict__ dL_dscales = A.dL_dscales; float* __restrict__ dL_drotations = A.dL_drotations;
     float gcol[3] = { (float)acc[0], (float)acc[1], (float)acc[2] }, gdepth = (float)acc[3], gfeat = (float)acc[4];
     float gm2x = (float)acc[5], gm2y = (float)acc[6], gcx = (float)acc[7], gcy = (float)acc[8], gcw = (float)acc[9];
     float gop = (float)acc[10];
@@ -352,17 +260,291 @@ __global__ void __launch_bounds__(GSR_K7_BS, GSR_K7_WAVES) gsr_gauss_bwd_kernel(
     if (dL_drotations) reinterpret_cast<float4*>(dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
 }
 
+#ifndef GSR_K7_WAVES
+#define GSR_K7_WAVES 4  // minimum waves per SIMD the register allocation has to leave room for
+#endif
+// LIGHT groups (at most GSR_K7_HEAVY_SLOTS gradient slots in the group's range): one wavefront per group.
+__global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const GsrGaussArgs A)
+{
+    // One wave per block owns 64 consecutive Gaussians; their gradient slots are one contiguous range [S0, S1) of
+    // `slots` (offsets[] is the exclusive scan of the per-Gaussian slot counts).  The backward blend writes a slot only
+    // for instances it traversed (slot_written[s] = 1, zeroed per call): on the bench scene three quarters of the
+    // instances lie behind the depth where their tile saturates.  The wave therefore
+    //   1. reads the flag bytes of its range (coalesced), turns them into 64-bit masks + running counts (ballot),
+    //   2. builds the compact list of written slots and fetches only those, 3 lanes per 48-byte slot, into LDS,
+    //   3. lets every lane sum its own written slots out of LDS in ascending slot order (double accumulators).
+    // Three dependent memory round trips per wave; the per-Gaussian inputs of the second half are requested before any of it.
+    constexpr int BS = 64;
+    constexpr int FCH = 512;  // flags per pass (per-wave ranges average ~170 slots)
+    constexpr int WCH = 128;  // written slots staged per sub-pass (48 B each)
+    __shared__ float4 stage[WCH * 3];
+    __shared__ uint16_t wl[FCH];
+    __shared__ unsigned long long gmask[FCH / 64];
+    __shared__ uint32_t gbase[FCH / 64 + 1];
+    const int P = A.P, num_slots = A.num_slots;
+    const uint32_t* __restrict__ offsets = A.offsets;
+    const float4* __restrict__ slots = A.slots;
+    uint8_t* __restrict__ slot_written = A.slot_written;
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * BS;
+    const int idx = g0 + lane;
+    const bool live = idx < P;
+    const uint32_t cnt = live ? A.tiles[idx] : 0u;
+    // clamped to the slot count: a forward that binned nothing (num_slots = 0) need not have produced offsets
+    const uint32_t S1 = min((g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots, (uint32_t)num_slots);
+    const uint32_t S0 = min(offsets[g0], S1);
+    if (S1 - S0 > GSR_K7_HEAVY_SLOTS) {  // a group with large splats: listed for gsr_gauss_bwd_heavy_kernel (wave-uniform)
+        if (lane == 0) A.heavy[16 + atomicAdd(&A.heavy[0], 1u)] = (uint32_t)blockIdx.x;
+        return;
+    }
+    const bool vis = live && A.radii[idx] > 0;
+    const uint32_t off = live ? offsets[idx] : 0u;
+    // early requests for the per-Gaussian half (independent of the slot phase)
+    float3 m = make_float3(0.f, 0.f, 0.f), sc = make_float3(0.f, 0.f, 0.f);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vis) {
+        m = make_float3(A.means3D[3 * idx], A.means3D[3 * idx + 1], A.means3D[3 * idx + 2]);
+        if (!A.cov3D_precomp) {
+            sc = make_float3(A.scales[3 * idx], A.scales[3 * idx + 1], A.scales[3 * idx + 2]);
+            q = reinterpret_cast<const float4*>(A.rotations)[idx];
+        }
+    }
+    double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
+    // Waves that hold a Gaussian with more than 24 slots spread the summation over the lanes as (Gaussian, field) tasks
+    // instead of letting that Gaussian's lane walk all its slots 11 fields at a time while 63 lanes wait: 11 consecutive
+    // lanes share a Gaussian, each sums one field in the same ascending order (so both schemes give the same bits).
+    // Wave-uniform choice from the slot counts.  The per-lane task sums stay in registers, acc[k] for task k * 64 + lane;
+    // one transposition through LDS -- aliased onto `stage`, which is free by then -- hands every Gaussian's 11 sums to
+    // its own lane.
+    double* accG = reinterpret_cast<double*>(stage);
+    static_assert(sizeof(double) * BS * 11 <= sizeof(float4) * WCH * 3, "accG must fit into the staging buffer");
+    __shared__ uint32_t sCi0[BS], sCi1[BS];
+    uint32_t cmax = cnt;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+    const bool spread = cmax > 24u;
+    for (uint32_t base = S0; base < S1; base += FCH) {
+        const uint32_t nf = min(S1 - base, (uint32_t)FCH);
+        uint8_t f[FCH / 64];
+#pragma unroll
+        for (int k = 0; k < FCH / 64; k++) {
+            const uint32_t i = k * 64 + lane;
+            f[k] = i < nf ? slot_written[base + i] : (uint8_t)0;
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < FCH / 64; k++) {
+            const unsigned long long mk = __ballot(f[k] != 0);
+            if (f[k]) wl[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(k * 64 + lane);
+            if (f[k]) slot_written[base + k * 64 + lane] = 0;  // consumed: the flags stay clear for the next backward
+            if (lane == 0) { gmask[k] = mk; gbase[k] = run; }
+            run += (uint32_t)__popcll(mk);
+        }
+        __syncthreads();
+        // A lane's written slots are consecutive entries [ci0, ci1) of the compact list: ci = number of written slots
+        // of the pass below the lane's first / past its last slot.  No flag test is left in the summation loop.
+        const uint32_t lo = min(max(off, base), base + nf) - base, hi = min(max(off + cnt, base), base + nf) - base;
+        uint32_t ci0 = run, ci1 = run;
+        if (lo < nf) ci0 = gbase[lo >> 6] + (uint32_t)__popcll(gmask[lo >> 6] & ((1ull << (lo & 63)) - 1ull));
+        if (hi < nf) ci1 = gbase[hi >> 6] + (uint32_t)__popcll(gmask[hi >> 6] & ((1ull << (hi & 63)) - 1ull));
+        for (uint32_t w0 = 0; w0 < run; w0 += WCH) {
+            const uint32_t nw = min(run - w0, (uint32_t)WCH);
+            float4 v[WCH * 3 / 64];
+#pragma unroll
+            for (int k = 0; k < WCH * 3 / 64; k++) {
+                const uint32_t i = lane + k * 64;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nw * 3) v[k] = slots[(size_t)(base + wl[w0 + i / 3]) * 3 + i % 3];
+            }
+#pragma unroll
+            for (int k = 0; k < WCH * 3 / 64; k++) stage[lane + k * 64] = v[k];
+            __syncthreads();
+            if (spread) {
+                if (w0 == 0) { sCi0[lane] = ci0; sCi1[lane] = ci1; }
+                __syncthreads();
+                const float* sf = reinterpret_cast<const float*>(stage);
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const int task = k * BS + lane, g = task / 11, v = task - g * 11;
+                    const uint32_t e0 = max(sCi0[g], w0), e1 = min(sCi1[g], w0 + nw);
+                    if (e1 > e0) gsr_sum_entries(acc[k], sf + (e0 - w0) * 12 + v, e1 - e0);
+                }
+            } else {
+                const uint32_t e0 = max(ci0, w0), e1 = min(ci1, w0 + nw);
+                for (uint32_t e = e0; e < e1; e++) {
+                    const float4 a = stage[(e - w0) * 3], b = stage[(e - w0) * 3 + 1], c = stage[(e - w0) * 3 + 2];
+                    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+                    acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    if (spread) {  // transpose: task sums (k * 64 + lane) -> the 11 sums of Gaussian `lane`
+#pragma unroll
+        for (int k = 0; k < 11; k++) accG[k * BS + lane] = acc[k];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 11; v++) acc[v] = accG[lane * 11 + v];
+    }
+    if (!live) return;
+    gsr_gauss_finish(A, idx, vis, acc, m, sc, q);
+}
+
+// HEAVY groups (more than GSR_K7_HEAVY_SLOTS gradient slots: a splat can cover thousands of tiles): four wavefronts per group.  A lone wave has ~6 KB of slot data in flight per memory round trip and walks a dense range of
+// thousands of slots window by window (measured on a scene of large splats: the launch lasted 347 us, of which ~35 us'
+// worth was arithmetic -- the rest was the few waves that own the big front splats).  Here the four waves scan 2048 flags
+// per pass, gather four 128-slot windows per round trip and sum them as (Gaussian, field) tasks spread over all 256
+// threads, each task in ascending slot order -- the same order, hence the same bits, as the one-wave scheme.  Wave 0
+// then runs the second half for the 64 Gaussians.
+__global__ void __launch_bounds__(256) gsr_gauss_bwd_heavy_kernel(const GsrGaussArgs A)
+{
+    constexpr int BS = 64, NW = 4, NT = 256;
+    constexpr int FCH = 2048;      // flags per pass: 8 per thread
+    constexpr int NG = FCH / 64;   // 64-flag groups per pass
+    constexpr int WCH = 128;       // written slots per wave and round
+    __shared__ float4 stage[NW * WCH * 3];  // 24 KiB: four windows, contiguous
+    __shared__ uint16_t wl[FCH];
+    __shared__ unsigned long long gmask[NG];
+    __shared__ uint32_t gcnt[NG], gbase[NG + 1];
+    __shared__ uint32_t sCi0[BS], sCi1[BS];
+    const int P = A.P, num_slots = A.num_slots;
+    const uint32_t* __restrict__ offsets = A.offsets;
+    const float4* __restrict__ slots = A.slots;
+    uint8_t* __restrict__ slot_written = A.slot_written;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t nheavy = A.heavy[0];  // the groups gsr_gauss_bwd_kernel listed (any order: groups are independent)
+    __shared__ uint32_t s_next;
+    // the first gridDim.x groups are dealt by block index, the rest is fetched from a counter as workgroups come free
+    // (groups differ in size by an order of magnitude; a few hundred fetches per launch: the counter is not a bottleneck)
+    for (uint32_t it = blockIdx.x; it < nheavy;) {
+    const int g0 = (int)A.heavy[16 + it] * BS;
+    const int idx = g0 + lane;  // every wave looks at the same 64 Gaussians
+    const bool live = idx < P;
+    const uint32_t S1 = min((g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots, (uint32_t)num_slots);
+    const uint32_t S0 = min(offsets[g0], S1);
+    const uint32_t cnt = live ? A.tiles[idx] : 0u;
+    const bool vis = live && A.radii[idx] > 0;
+    const uint32_t off = live ? offsets[idx] : 0u;
+    float3 m = make_float3(0.f, 0.f, 0.f), sc = make_float3(0.f, 0.f, 0.f);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vis && wave == 0) {
+        m = make_float3(A.means3D[3 * idx], A.means3D[3 * idx + 1], A.means3D[3 * idx + 2]);
+        if (!A.cov3D_precomp) {
+            sc = make_float3(A.scales[3 * idx], A.scales[3 * idx + 1], A.scales[3 * idx + 2]);
+            q = reinterpret_cast<const float4*>(A.rotations)[idx];
+        }
+    }
+    // (Gaussian, field) tasks: task k * 256 + t -> Gaussian task / 11, field task % 11; 704 tasks over 256 threads
+    double tacc[3] = { 0, 0, 0 };
+    int tg[3], tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int task = k * NT + t;
+        tg[k] = task < BS * 11 ? task / 11 : -1;
+        tv[k] = task - (task / 11) * 11;
+    }
+    for (uint32_t base = S0; base < S1; base += FCH) {
+        const uint32_t nf = min(S1 - base, (uint32_t)FCH);
+        uint8_t f[FCH / NT];
+#pragma unroll
+        for (int k = 0; k < FCH / NT; k++) {
+            const uint32_t i = k * NT + t;
+            f[k] = i < nf ? slot_written[base + i] : (uint8_t)0;
+        }
+        unsigned long long mk[FCH / NT];
+#pragma unroll
+        for (int k = 0; k < FCH / NT; k++) {
+            mk[k] = __ballot(f[k] != 0);
+            if (f[k]) slot_written[base + k * NT + t] = 0;  // consumed
+            if (lane == 0) { gmask[k * NW + wave] = mk[k]; gcnt[k * NW + wave] = (uint32_t)__popcll(mk[k]); }  // group = 64 consecutive flags
+        }
+        __syncthreads();
+        if (t <= NG) {  // exclusive prefix of the 32 group counts (ascending slot order); gbase[NG] = written slots of the pass
+            uint32_t s = 0;
+            for (int g = 0; g < t; g++) s += gcnt[g];
+            gbase[t] = s;
+        }
+        __syncthreads();
+        const uint32_t run = gbase[NG];
+#pragma unroll
+        for (int k = 0; k < FCH / NT; k++)
+            if (f[k]) wl[gbase[k * NW + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[k], 0u))] = (uint16_t)(k * NT + t);
+        if (wave == 0) {  // a Gaussian's written slots = entries [ci0, ci1) of the pass's compact list
+            const uint32_t lo = min(max(off, base), base + nf) - base, hi = min(max(off + cnt, base), base + nf) - base;
+            uint32_t ci0 = run, ci1 = run;
+            if (lo < nf) ci0 = gbase[lo >> 6] + (uint32_t)__popcll(gmask[lo >> 6] & ((1ull << (lo & 63)) - 1ull));
+            if (hi < nf) ci1 = gbase[hi >> 6] + (uint32_t)__popcll(gmask[hi >> 6] & ((1ull << (hi & 63)) - 1ull));
+            sCi0[lane] = ci0; sCi1[lane] = ci1;
+        }
+        __syncthreads();
+        for (uint32_t w0 = 0; w0 < run; w0 += NW * WCH) {
+            const uint32_t nall = min(run - w0, (uint32_t)(NW * WCH));   // entries of this round
+            const uint32_t wb = (uint32_t)wave * WCH;                    // this wave's window inside the round
+            const uint32_t nw = wb < nall ? min(nall - wb, (uint32_t)WCH) : 0u;
+            float4 v[WCH * 3 / 64];
+#pragma unroll
+            for (int k = 0; k < WCH * 3 / 64; k++) {
+                const uint32_t i = lane + k * 64;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nw * 3) v[k] = slots[(size_t)(base + wl[w0 + wb + i / 3]) * 3 + i % 3];
+            }
+#pragma unroll
+            for (int k = 0; k < WCH * 3 / 64; k++) stage[wb * 3 + lane + k * 64] = v[k];
+            __syncthreads();
+            const float* sf = reinterpret_cast<const float*>(stage);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (tg[k] < 0) continue;
+                const uint32_t e0 = max(sCi0[tg[k]], w0), e1 = min(sCi1[tg[k]], w0 + nall);
+                if (e1 > e0) gsr_sum_entries(tacc[k], sf + (e0 - w0) * 12 + tv[k], e1 - e0);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    // task sums -> the 11 sums of Gaussian `lane` (through LDS, aliased onto the staging buffer, which is free now)
+    double* accG = reinterpret_cast<double*>(stage);
+    static_assert(sizeof(double) * BS * 11 <= sizeof(float4) * NW * WCH * 3, "accG must fit into the staging buffer");
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (tg[k] >= 0) accG[k * NT + t] = tacc[k];
+    __syncthreads();
+    if (wave == 0 && live) {
+        double acc[11];
+#pragma unroll
+        for (int v = 0; v < 11; v++) acc[v] = accG[lane * 11 + v];
+        gsr_gauss_finish(A, idx, vis, acc, m, sc, q);
+    }
+    if (t == 0) s_next = gridDim.x + atomicAdd(&A.heavy[1], 1u);
+    __syncthreads();  // also: the next group's staging must not overtake wave 0's reads of accG
+    it = s_next;
+    __syncthreads();
+    }
+}
+
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
                                      const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
-                                     uint8_t* slot_written, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
-                                     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
-                                     float* dL_drotations, hipStream_t stream)
+                                     uint8_t* slot_written, uint32_t* heavy_groups, int num_slots, float* dL_dmeans2D, float* dL_dcolors,
+                                     float* dL_dopacity, float* dL_dfeatures, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                     float* dL_dscales, float* dL_drotations, hipStream_t stream)
 {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsr_gauss_bwd_kernel, dim3((P + GSR_K7_BS - 1) / GSR_K7_BS), dim3(GSR_K7_BS), 0, stream, P, D, M, cam, means3D, radii,
-                       shs, geom.clamped, scales, rotations, cov3D_precomp, geom.rect, geom.offsets, geom.tiles, num_slots,
-                       reinterpret_cast<const float4*>(slots), slot_written, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures,
-                       dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+    GsrGaussArgs A;
+    A.P = P; A.D = D; A.M = M; A.cam = cam;
+    A.means3D = means3D; A.radii = radii; A.shs = shs; A.clamped = geom.clamped; A.scales = scales; A.rotations = rotations;
+    A.cov3D_precomp = cov3D_precomp; A.offsets = geom.offsets; A.tiles = geom.tiles; A.num_slots = num_slots;
+    A.slots = reinterpret_cast<const float4*>(slots); A.slot_written = slot_written; A.heavy = heavy_groups;
+    A.dL_dmeans2D = dL_dmeans2D; A.dL_dcolors = dL_dcolors; A.dL_dopacity = dL_dopacity; A.dL_dfeatures = dL_dfeatures;
+    A.dL_dmeans3D = dL_dmeans3D; A.dL_dcov3D = dL_dcov3D; A.dL_dsh = dL_dsh; A.dL_dscales = dL_dscales; A.dL_drotations = dL_drotations;
+    const dim3 grid((P + 63) / 64);
+    // every group of 64 Gaussians is done by exactly one of the two kernels: the first one does the light groups and lists
+    // the heavy ones, a small grid of 256-thread workgroups then walks that list (nothing to do on a scene without large
+    // splats: 512 workgroups read a zero and leave)
+    hipLaunchKernelGGL(gsr_gauss_bwd_kernel, grid, dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(gsr_gauss_bwd_heavy_kernel, dim3(min((P + 63) / 64, 768)), dim3(256), 0, stream, A);  // 3 workgroups per CU are resident
     return hipGetLastError();
 }

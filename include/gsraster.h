@@ -90,7 +90,7 @@ size_t gsr_geom_bytes(int P);                 /* per-Gaussian state kept from fo
 size_t gsr_image_bytes(int P, int W, int H);  /* per-pixel / per-tile state kept forward -> backward (16 B + 192 B of
                                                  depth checkpoints per pixel, of which only the reached ones are touched) */
 size_t gsr_binning_bytes(int R);              /* per-instance state: sorted point list (+ sort keys)  */
-size_t gsr_backward_scratch_bytes(int P, int num_slots); /* per-instance gradient slots used inside backward */
+size_t gsr_backward_scratch_bytes(int P, int num_slots); /* per-instance gradient slots + the heavy-group list of the per-Gaussian backward */
 
 /*
  * Forward, stage 1 of 2: per-Gaussian preprocess + tile histogram + scans.
