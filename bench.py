@@ -468,7 +468,8 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10):
         loss.backward()
         with torch.no_grad():
             DS.training_statis(model, pkg["viewspace_points"], pkg["neural_opacity"], pkg["visibility_filter"], pkg["selection_mask"], vis)
-        sizes.update(visible_anchors=int(vis.sum()), gaussians=int(pkg["radii"].shape[0]))
+        if not sizes:  # once: a host sync of the row's own making has no place in the timed loop
+            sizes.update(visible_anchors=int(vis.sum()), gaussians=int(pkg["radii"].shape[0]))
         for p_ in model.parameters():
             p_.grad = None
 

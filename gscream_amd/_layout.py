@@ -49,6 +49,7 @@ def image_views(buf, P, W, H):
     Np = (N + 3) & ~3
     out["ckpt"] = _take(buf, off, CKPT_PLANES * Np * 4, torch.float32, (SEG_MAX, 6 * Np)); off += _align(CKPT_PLANES * Np * 4)
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
+    out["qresume"] = _take(buf, off, 4 * T * 4, torch.int32, (4 * T,)); off += _align(4 * T * 4)
     return out
 
 

@@ -558,10 +558,26 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_near_kernel(const uint2* __
     __shared__ uint32_t s_pick, s_near, s_far;
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n <= GSR_NEAR_CAP || rg.y > capacity) return;
+    if (rg.y > capacity) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const u64* src = seg_keys + rg.x;
     for (uint32_t i = t; i < n; i += 256) slot_written[rg.x + i] = 0;
+    if (n <= GSR_NEAR_CAP) {
+        // A list short enough for the complete LDS sort is done right here, in the same launch (this kernel's LDS covers it):
+        // as a launch of their own behind this one these few tiles were a 90 us tail of single workgroups on a scene whose
+        // other lists are long; here they overlap with the long lists' passes.
+        u64 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (uint32_t)(t + 256 * j) < n ? src[t + 256 * j] : 0ull;
+        __shared__ uint32_t wtot0[6];
+        if (gsr_sort_buckets<256, 8>(v, n, keys, hist, red, wtot0)) {
+            for (uint32_t i = t; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[i];
+        } else {
+            if (n > 1) gsr_sort_lds_fused(keys, n, 256);
+            for (uint32_t i = t; i < n; i += 256) point_list[rg.x + i] = (uint32_t)keys[GSR_PAD(i)];
+        }
+        return;  // sorted_len[tile] = n already (tile scan)
+    }
     // pass A: key range
     u64 mn = ~0ull, mx = 0ull;
     for (uint32_t i = t; i < n; i += 256) { const u64 k = src[i]; mn = min(mn, k); mx = max(mx, k); }
@@ -762,15 +778,17 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
     const uint32_t mx = max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count;
     if (!partial) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, stream);
     // lists up to GSR_NEAR_CAP: full sort in LDS; longer ones: sorted prefix only (gsr_tile_sort_near_kernel)
-    const uint32_t longest = min((uint32_t)GSR_NEAR_CAP, mx);
-    const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
-    hipLaunchKernelGGL(gsr_tile_sort_lds_kernel<256>, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys, bin.point_list,
-                       bin.slot_written, 0u, (uint32_t)GSR_NEAR_CAP, longest, (uint32_t)capacity, (const uint32_t*)nullptr,
-                       (uint32_t*)nullptr);
     // (a guess below the cap that turns out too small fails the host's check anyway and stage 2 is redone)
-    if (mx > GSR_NEAR_CAP)
+    if (mx > GSR_NEAR_CAP) {  // long lists exist: one launch does both classes (fixed 21 KiB of LDS)
         hipLaunchKernelGGL(gsr_tile_sort_near_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.seg_keys, bin.point_list,
                            bin.slot_written, image.sorted_len, (uint32_t)capacity);
+    } else {  // short lists only: LDS sized for the longest one (twice the resident workgroups on the bench scene)
+        const uint32_t longest = min((uint32_t)GSR_NEAR_CAP, mx);
+        const size_t lds = gsr_align((size_t)GSR_PAD(longest) * 8 + 8);
+        hipLaunchKernelGGL(gsr_tile_sort_lds_kernel<256>, dim3(T), dim3(256), lds, stream, image.ranges, bin.seg_keys, bin.point_list,
+                           bin.slot_written, 0u, (uint32_t)GSR_NEAR_CAP, longest, (uint32_t)capacity, (const uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
+    }
     return hipGetLastError();
 }
 

@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted,
-    const uint32_t* __restrict__ sorted_len, uint32_t* __restrict__ need_full, const uint32_t* __restrict__ only_flagged)
+    const uint32_t* __restrict__ sorted_len, uint32_t* __restrict__ need_full, const uint32_t* __restrict__ only_flagged,
+    uint32_t* __restrict__ qresume)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
@@ -264,13 +265,47 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     int npass = 0;  // checkpoints passed (wave-uniform)
     float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, A4 = 0.f;  // sums of the segments closed so far
     const uint32_t* ids = point_list + rg.x;
+    // Fix-up pass (the tile's list has been sorted completely since): a quadrant that ran off the sorted prefix at list
+    // position m RESUMES there instead of starting over -- the first m entries of the complete order are the prefix it
+    // walked, and what it left behind when it finished is its whole state: T (final_T), the last contributor and whether the
+    // pixel had stopped (n_contrib, top bit), the sums since the last checkpoint (the last checkpoint slot) and the closed
+    // segments (the other slots, re-added in order).  Same arithmetic in the same order as one uninterrupted walk: same bits.
+    // Quadrants of the tile that had finished inside the prefix are left alone.
+    int start = 0;
+    if (only_flagged) {
+        start = (int)qresume[u];
+        if (start == 0) return;  // wave-uniform
+        bool stopped = !inside;
+        if (inside) {
+            const uint32_t nc = n_contrib[pid];
+            last = nc & 0x7fffffffu;
+            stopped = (nc >> 31) != 0u;
+            Tr = final_T[pid];
+            const float4 fa = gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid];
+            const float2 fb = gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid];
+            npass = __float_as_int(fa.x);
+            C0 = fa.y; C1 = fa.z; C2 = fa.w; Dp = fb.x; Uf = fb.y;
+        }
+        npass = __builtin_amdgcn_readfirstlane(npass);  // wave-uniform by construction; lane 0 (the quadrant's first pixel) is inside
+        if (inside)
+            for (int k = 0; k < npass; k++) {
+                const float4 sa = gsr_ckpt_a(ckpt, k, HW)[pid];
+                const float2 sb = gsr_ckpt_b(ckpt, k, HW)[pid];
+                A0 += sa.y; A1 += sa.z; A2 += sa.w; A3 += sb.x; A4 += sb.y;
+            }
+        donem = __builtin_amdgcn_ballot_w64(stopped);
+    }
 
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
-    if (lane < n) {
-        const float4* r = reinterpret_cast<const float4*>(rec + ids[lane]);
-        a = r[0]; b = r[1]; c = r[2];
+    {
+        const int cnt0 = min(GSR_FWB - (start & (GSR_FWB - 1)), n - start);  // batches end at multiples of 64 list positions
+        if (lane < cnt0) {
+            const float4* r = reinterpret_cast<const float4*>(rec + ids[start + lane]);
+            a = r[0]; b = r[1]; c = r[2];
+        }
     }
-    for (int base = 0; base < n; base += GSR_FWB) {
+    int base = start, cnt = 0;
+    for (; base < n; base += cnt) {
         if (donem == full) break;  // wave-uniform
         // Issue priority grows with the depth reached: the launch lasts as long as its deepest quadrants, which share
         // their SIMD fairly with up to seven shallower ones for most of their life; letting the waves that are still
@@ -292,7 +327,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             A0 += C0; A1 += C1; A2 += C2; A3 += Dp; A4 += Uf;
             C0 = 0.f; C1 = 0.f; C2 = 0.f; Dp = 0.f; Uf = 0.f;
         }
-        const int cnt = min(GSR_FWB, n - base);
+        cnt = min(GSR_FWB - (base & (GSR_FWB - 1)), n - base);
         bool hit = false;
         if (lane < cnt) {
 #ifdef GSR_PRECISE_MATH
@@ -317,7 +352,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             dst[0] = 0.f; dst[2] = 0.f; dst[4] = 0.f; dst[6] = 0.f; dst[8] = 0.f; dst[10] = 0.f; dst[12] = 0.f; dst[14] = 0.f;
         }
         {  // next batch's records: in flight during the blend loop
-            const int i = base + GSR_FWB + lane;
+            const int i = base + cnt + lane;  // (the next batch is a full one, or the list's tail)
             if (i < n) {
                 const float4* r = reinterpret_cast<const float4*>(rec + ids[i]);
                 a = r[0]; b = r[1]; c = r[2];
@@ -383,7 +418,12 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         __syncthreads();
     }
 
-    if (nsort < nlist && rg.y <= capacity && donem != full && lane == 0) need_full[tile] = 1u;  // ran off the sorted prefix
+    // ran off the sorted prefix with pixels still blending: the tile is sorted completely and this quadrant resumes at n
+    const bool ran_off = nsort < nlist && rg.y <= capacity && donem != full;
+    if (lane == 0) {
+        if (ran_off) need_full[tile] = 1u;
+        qresume[u] = ran_off ? (uint32_t)n : 0u;
+    }
 
     // deepest contributor of the quadrant -> of the tile: what the backward has to traverse (drives its launch order)
     uint32_t wl = last;
@@ -397,7 +437,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float2(Dp, Uf);
         C0 += A0; C1 += A1; C2 += A2; Dp += A3; Uf += A4;  // image sums = sum of the segment sums
         final_T[pid] = Tr;
-        n_contrib[pid] = last;
+        n_contrib[pid] = last | ((ran_off && __builtin_amdgcn_inverse_ballot_w64(donem)) ? 0x80000000u : 0u);  // top bit: for the resume only
         out_color[pid] = C0 + Tr * bg[0];
         out_color[HW + pid] = C1 + Tr * bg[1];
         out_color[2 * (size_t)HW + pid] = C2 + Tr * bg[2];
@@ -760,7 +800,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
     hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H,
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,
-                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr);
+                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume);
     return hipGetLastError();
 }
 

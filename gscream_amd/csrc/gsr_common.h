@@ -25,6 +25,7 @@
 //                              sums over the segment that ends there; last slot: {checkpoints passed, sums behind the
 //                              last one}.  Lets the backward start in the middle of a list (independent depth segments)
 //           info           16 B {R, max tile count}
+//           qresume[4T]    4 B  forward blend: where a quadrant ran off its tile's sorted prefix (resume point of the fix-up)
 //   binning: point_list[R] 4 B Gaussian ids per tile segment (unsorted after the scatter, sorted in place by the
 //            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
 //   scratch (backward): slots[R] 48 B  per-instance partial gradients (12 floats)
@@ -84,6 +85,7 @@ struct GsrImage {
     float* ckpt;           // [GSR_CKPT_PLANES][N], see the header comment
     size_t N;
     uint32_t* info;  // [0] = R, [1] = max tile count
+    uint32_t* qresume;  // [4 T] per 8x8 quadrant: list position at which the forward ran off the sorted prefix (0 = it did not)
     size_t bytes;
 };
 
@@ -143,6 +145,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.N = N;
     im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * ((N + 3) & ~(size_t)3) * 4);
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
+    im.qresume = (uint32_t*)(b + off); off += gsr_align(4 * T * 4);
     im.bytes = off;
     return im;
 }

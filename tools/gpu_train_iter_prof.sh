@@ -8,6 +8,12 @@ timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o n -- python tools/t
 tail -1 "$OUT/kt.log" | cut -c1-1500
 DB=$(find "$OUT/kt" -name "*_results.db" | head -1)
 python tools/rocprof_summary.py "$DB" | head -40 | cut -c1-140 | tee "$OUT/kernel_stats.md"
+python tools/rocprof_durations.py "$DB" blend_fwd
+python - "$DB" <<PYEOF
+import sqlite3,sys
+cur=sqlite3.connect(sys.argv[1]).cursor()
+print([d[0] for d in cur.execute("select * from top_kernels limit 1").description])
+PYEOF
 rm -rf "$OUT/kt"
 if [ "${2:-}" = "pmc" ]; then
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD -d "$OUT/p1" -o p -- python tools/train_iteration_probe.py > "$OUT/p1.log" 2>&1

@@ -12,12 +12,15 @@ import sys
 
 def kernel_stats(db):
     cur = sqlite3.connect(db).cursor()
-    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    print("| kernel | calls | total (us) | avg (us) | % of GPU time |")
-    print("|---|---:|---:|---:|---:|")
-    for name, calls, total, avg, pct in rows:
+    cols = [d[0] for d in cur.execute("select * from top_kernels limit 1").description]
+    mm = "min_ns" in cols and "max_ns" in cols
+    rows = list(cur.execute(f"select name, total_calls, total_duration, average, percentage{', min_ns, max_ns' if mm else ''} from top_kernels"))
+    print("| kernel | calls | total (us) | avg (us) | % of GPU time |" + (" min (us) | max (us) |" if mm else ""))
+    print("|---|---:|---:|---:|---:|" + ("---:|---:|" if mm else ""))
+    for row in rows:
+        name, calls, total, avg, pct = row[:5]
         short = name.split("(")[0].replace("void ", "")
-        print(f"| `{short}` | {calls} | {total:.1f} | {avg:.2f} | {pct:.2f} |")
+        print(f"| `{short}` | {calls} | {total:.1f} | {avg:.2f} | {pct:.2f} |" + (f" {row[5] / 1e3:.1f} | {row[6] / 1e3:.1f} |" if mm else ""))
 
 
 def pmc(db):
