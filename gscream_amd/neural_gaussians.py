@@ -72,6 +72,7 @@ class _Decode(torch.autograd.Function):
         ctx.in_shapes = [tuple(t.shape) for t in (feat, anchor, offsets, gscale)] + [tuple(w.shape) for w in weights]
         bmask = mask.bool()
         ctx.mark_non_differentiable(nop, bmask)
+        _last_decode.update(vis=vis, first=first, N=N, K=K, M=M)  # handed to densify_stats through the selection mask (see decode)
         return xyz, color, opacity, unc, scaling, rot, nop, bmask
 
     @staticmethod
@@ -87,8 +88,13 @@ class _Decode(torch.autograd.Function):
             e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
             vis = ctx.vis
             full = feat_c.shape[0]  # model-sized gradients; rows outside `vis` stay zero
-            mk = (lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)) if vis is not None else e
-            d_feat, d_anchor, d_off, d_gs = mk(full, 32), mk(full, 3), mk(full, K, 3), mk(full, 6)
+            # model-sized gradients; with a row list the rows outside it must be zero: ONE fill for the four tensors
+            per = 32 + 3 + 3 * K + 6
+            flatg = torch.zeros((full * per,), dtype=torch.float32, device=dev) if vis is not None else e(full * per)
+            d_feat = flatg[:full * 32].view(full, 32)
+            d_anchor = flatg[full * 32:full * 35].view(full, 3)
+            d_off = flatg[full * 35:full * (35 + 3 * K)].view(full, K, 3)
+            d_gs = flatg[full * (35 + 3 * K):].view(full, 6)
             # one native call: input / geometry gradients and all 16 weight / bias gradients (accumulated in registers on the
             # f32 matrix cores, workgroup partials added in a fixed order) straight into the gradient tensors
             outs = (K, K, 3 * K, 7 * K)
@@ -111,6 +117,29 @@ class _Decode(torch.autograd.Function):
         sh = ctx.in_shapes
         return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None, None,
                 *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
+
+
+_last_decode = {}
+
+
+class DecodeBookkeeping:
+    """What the decode knows about the rows it produced, attached to the selection mask it returns (attribute `_gsr_decode`):
+    `training_statis` (densify_stats.py) receives that very tensor from train.py:599 and finds the row list of the visible
+    anchors, each anchor's first output row and the row count here instead of re-deriving them with a dozen small torch
+    kernels and two host syncs per iteration.  Plain data; absent or stale -> the consumer recomputes everything."""
+    __slots__ = ("vis", "first", "N", "K", "M", "visible_mask_ref", "visible_mask_version")
+
+    def __init__(self, vis, first, N, K, M, visible_mask):
+        import weakref
+        self.vis, self.first, self.N, self.K, self.M = vis, first, N, K, M
+        self.visible_mask_ref = None if visible_mask is None else weakref.ref(visible_mask)
+        self.visible_mask_version = None if visible_mask is None else visible_mask._version
+
+    def matches(self, anchor_visible_mask, n_offsets):
+        if self.K != int(n_offsets) or self.visible_mask_ref is None:
+            return False
+        m = self.visible_mask_ref()
+        return m is anchor_visible_mask and m._version == self.visible_mask_version
 
 
 def _workspace(dev, nbytes):
@@ -162,9 +191,16 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     # gaussian_renderer/__init__.py:20-28: `x[visible_mask]` for four tensors.  Here the mask becomes a row list once
     # and the kernels read (and, in the backward, write) the model-sized tensors through it; no mask = every row.
     vis_idx = None if visible_mask is None else torch.nonzero(visible_mask, as_tuple=False).view(-1).int()
+    _last_decode.clear()
     xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask = decode(
         pc._anchor_feat, pc.get_anchor, pc._offset, pc.get_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,
         pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp, vis_idx)
+    if _last_decode and visible_mask is not None:
+        try:
+            mask._gsr_decode = DecodeBookkeeping(_last_decode["vis"], _last_decode["first"], _last_decode["N"], _last_decode["K"],
+                                                 _last_decode["M"], visible_mask)
+        except Exception:  # noqa: BLE001  (a tensor subclass that refuses attributes: the consumer recomputes)
+            pass
     if is_training:  # :98-102
         return xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask
     return xyz, color, opacity, uncertainty, scaling, rot

@@ -172,11 +172,16 @@ def test_training_statistics_against_oracle():
     cam_d = DO.Camera(torch.tensor(CAM, device="cuda"))
     for it in range(2):
         vm = torch.rand(N, generator=g) > 0.3
-        xyz, color, opacity, unc, scaling, rot, nop, mask = generate_neural_gaussians(cam_d, dut, vm.cuda(), True)
+        vmd = vm.cuda()
+        xyz, color, opacity, unc, scaling, rot, nop, mask = generate_neural_gaussians(cam_d, dut, vmd, True)
         M = xyz.shape[0]
         update_filter = torch.rand(M, generator=g) > 0.4                      # stands for radii > 0
         vsp = types.SimpleNamespace(grad=torch.randn(M, 3, generator=g))
-        training_statis(acc_d, types.SimpleNamespace(grad=vsp.grad.cuda()), nop, update_filter.cuda(), mask, vm.cuda())
+        # iteration 0: the visibility mask arrives as ANOTHER tensor object -> everything is re-derived from the masks;
+        # iteration 1: the very tensors of the decode, as train.py passes them -> the decode's bookkeeping is reused
+        book = getattr(mask, "_gsr_decode", None)
+        assert book is not None and book.matches(vmd, K) and not book.matches(vm.cuda(), K) and book.M == M
+        training_statis(acc_d, types.SimpleNamespace(grad=vsp.grad.cuda()), nop, update_filter.cuda(), mask, vm.cuda() if it == 0 else vmd)
         DO.training_statis(acc_r, vsp, nop.detach().cpu(), update_filter, mask.cpu(), vm)
     for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
         a, b = getattr(acc_d, name).cpu(), getattr(acc_r, name)
