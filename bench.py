@@ -921,6 +921,15 @@ def main():
                                                    "whole_iteration_frac_of_it": round(out["whole_iteration"]["GBps"] / ceil, 4)}
             except Exception as e:  # noqa: BLE001
                 out["roofline"]["copy_ceiling"] = {"error": repr(e)}
+        if world == 1 and not args.no_next_rows and not os.environ.get("GSR_LIB"):
+            # (before the next rows: one of them uses torch's profiler, whose tracer hooks stay in the HIP API path afterwards)
+            try:
+                out["host_ms_per_step"] = host_floor_row(dev, W, H)
+                out["host_ms_per_step_note"] = ("fwd+bwd step loop on a 1k-Gaussian scene at the bench resolution: what the host path costs per step "
+                                                "(Python wrapper, ctypes, allocator, autograd engine, ~12 HIP launches, the num_rendered wait)")
+            except Exception as e:  # noqa: BLE001
+                out["host_ms_per_step"] = None
+                out["host_ms_per_step_note"] = repr(e)
         if world == 1 and not args.no_next_rows:
             rows = (("rgb_loss", lambda: loss_row(dev, H, W, not args.no_cpu_baseline)),
                     ("depth_loss", lambda: depth_loss_row(dev, H, W, not args.no_cpu_baseline)),
@@ -934,14 +943,6 @@ def main():
                     out["next_rows"][name] = fn()
                 except Exception as e:  # noqa: BLE001
                     out["next_rows"][name] = {"error": repr(e)}
-        if world == 1 and not args.no_next_rows and not os.environ.get("GSR_LIB"):
-            try:
-                out["host_ms_per_step"] = host_floor_row(dev, W, H)
-                out["host_ms_per_step_note"] = ("fwd+bwd step loop on a 1k-Gaussian scene at the bench resolution: what the host path costs per step "
-                                                "(Python wrapper, ctypes, allocator, autograd engine, ~12 HIP launches, the num_rendered wait)")
-            except Exception as e:  # noqa: BLE001
-                out["host_ms_per_step"] = None
-                out["host_ms_per_step_note"] = repr(e)
         if world == 1 and not args.no_next_rows and not args.no_strict_parity and not os.environ.get("GSR_LIB"):
             try:
                 out["strict_parity_build"] = strict_parity_row(args)

@@ -11,8 +11,11 @@ def _align(x):
     return (x + 255) & ~255
 
 
+MAX_CHUNKS, CHUNK_GAUSS = 256, 1024  # GSR_MAX_CHUNKS, GSR_CHUNK_GAUSS (gsr_common.h)
+
+
 def num_chunks(P):
-    return max(1, min(512, (P + 2047) // 2048))  # GSR_MAX_CHUNKS
+    return max(1, min(MAX_CHUNKS, (P + CHUNK_GAUSS - 1) // CHUNK_GAUSS))
 
 
 def _take(buf, off, nbytes, dtype, shape):

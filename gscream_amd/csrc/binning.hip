@@ -79,13 +79,18 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
 
 // Column pass over table[nchunks][T]: for every tile, exclusive prefix over chunks (in place) and the
 // tile total.  Block = 64 tiles x 8 chunk groups.
-#define GSR_COLSCAN_GROUPS 8  // chunk groups per workgroup: 64 tiles x 8 groups = 512 threads, <= 64 rows per thread
-__global__ void __launch_bounds__(64 * GSR_COLSCAN_GROUPS) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
+#ifndef GSR_COLSCAN_GROUPS
+#define GSR_COLSCAN_GROUPS 8  // chunk groups per workgroup: GSR_COLSCAN_TILES tiles x 8 groups = 512 threads, <= 64 rows per thread
+#endif
+#ifndef GSR_COLSCAN_TILES
+#define GSR_COLSCAN_TILES 64
+#endif
+__global__ void __launch_bounds__(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
                                                                                     uint32_t* __restrict__ tile_count)
 {
-    __shared__ uint32_t part[GSR_COLSCAN_GROUPS][64];
-    const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 64 + tl;
+    __shared__ uint32_t part[GSR_COLSCAN_GROUPS][GSR_COLSCAN_TILES];
+    const int tl = threadIdx.x % GSR_COLSCAN_TILES, grp = threadIdx.x / GSR_COLSCAN_TILES;
+    const int tile = blockIdx.x * GSR_COLSCAN_TILES + tl;
     const int per = (nchunks + GSR_COLSCAN_GROUPS - 1) / GSR_COLSCAN_GROUPS;
     const int c0 = grp * per, c1 = min(nchunks, c0 + per);
     // each thread owns <= 64 table rows of one tile: keep them in registers between the two passes (the loads of
@@ -204,9 +209,10 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     }
     if (threadIdx.x == 0) chunk_first = 0u;
     __syncthreads();
-    // first gradient slot of the chunk = instances of all earlier chunks (nchunks <= GSR_MAX_CHUNKS <= blockDim)
+    // first gradient slot of the chunk = instances of all earlier chunks
     {
-        uint32_t pv = (int)threadIdx.x < (int)blockIdx.x ? chunk_sum[threadIdx.x] : 0u;
+        uint32_t pv = 0u;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += blockDim.x) pv += chunk_sum[i];
         pv = gsr_wave_scan_add(pv);
         if (lane == 63 && pv != 0u) atomicAdd(&chunk_first, pv);
     }
@@ -706,7 +712,7 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
         hipLaunchKernelGGL(gsr_tile_hist_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx,
                            nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums);
         // (2) column scan -> per-(chunk, tile) offsets + tile totals
-        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + 63) / 64), dim3(64 * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
+        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + GSR_COLSCAN_TILES - 1) / GSR_COLSCAN_TILES), dim3(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
                            image.tile_count);
     }
     // (3) tile scan -> ranges, info
