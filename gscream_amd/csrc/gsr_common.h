@@ -126,7 +126,7 @@ static inline GsrGeom gsr_carve_geom(void* base, int P)
     g.offsets = (uint32_t*)(b + off); off += gsr_align(p * 4);
     g.tmask = (unsigned long long*)(b + off); off += gsr_align(p * 8);
     g.clamped = (uint8_t*)(b + off); off += gsr_align(p * 3);
-    g.scan_sums = (uint32_t*)(b + off); off += gsr_align((size_t)(gsr_scan_blocks((int)p) + 1) * 4);
+    g.scan_sums = (uint32_t*)(b + off); off += gsr_align((size_t)(GSR_MAX_CHUNKS + 1) * 4);  // per-chunk instance totals (gsr_num_chunks(P) <= GSR_MAX_CHUNKS)
     g.bytes = off;
     return g;
 }

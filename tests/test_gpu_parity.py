@@ -142,7 +142,8 @@ def test_config1_against_live_oracle():
     _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
 
 
-@pytest.mark.parametrize("P,W,H,seed", [(60_000, 504, 284, 21), (20_000, 252, 142, 22)])
+@pytest.mark.parametrize("P,W,H,seed", [(60_000, 504, 284, 21), (20_000, 252, 142, 22),
+                                        (180_000, 400, 240, 23)])  # 180k: several hundred binning chunks, odd chunk sizes
 def test_slab_scene_against_live_oracle(P, W, H, seed):
     """Down-scaled config 2/3 generator (the bench workload's distribution), depth + feature heads on."""
     s = S.scene_slab(seed, P, W, H)
