@@ -226,6 +226,12 @@ __device__ __forceinline__ float2* gsr_ckpt_b(float* ckpt, int k, size_t HW) { r
 __device__ __forceinline__ const float4* gsr_ckpt_a(const float* ckpt, int k, size_t HW) { return reinterpret_cast<const float4*>(ckpt + (size_t)k * 6 * gsr_ckpt_stride(HW)); }
 __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, size_t HW) { return reinterpret_cast<const float2*>(ckpt + ((size_t)k * 6 + 4) * gsr_ckpt_stride(HW)); }
 
+#ifndef GSR_FWD_WAVES
+#define GSR_FWD_WAVES 0
+#endif
+#if GSR_FWD_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES)))
+#endif
 __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
