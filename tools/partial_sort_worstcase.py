@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 from gscream_amd import GaussianRasterizationSettings, _native, _layout, rasterizer, set_tuning
 from gscream_amd import synthetic as S
 from gscream_amd.neural_gaussians import generate_neural_gaussians
-from oracle import decode_oracle as DO
+from gscream_amd import standin_model as DO
 
 W, H, N, K = 1008, 567, 200_000, 10
 dev = torch.device("cuda", 0)
