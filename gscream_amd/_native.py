@@ -15,7 +15,8 @@ EXPORTED_SYMBOLS = (
     "gsr_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
     "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
-    "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward",
+    "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward", "gsr_rgb_loss_forward_window",
+    "gsr_rgb_loss_backward_window",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
     "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward", "gsr_training_stats",
     "gsr_decode_weight_grad_workspace_bytes",
@@ -92,6 +93,10 @@ def load():
     lib.gsr_rgb_loss_forward.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _vp, _vp, _c_int, _vp]
     lib.gsr_rgb_loss_backward.restype = _c_int
     lib.gsr_rgb_loss_backward.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _vp, _vp, _vp, _vp]
+    lib.gsr_rgb_loss_forward_window.restype = _c_int
+    lib.gsr_rgb_loss_forward_window.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _c_int, _vp, _vp, _c_int, _vp]
+    lib.gsr_rgb_loss_backward_window.restype = _c_int
+    lib.gsr_rgb_loss_backward_window.argtypes = [_c_int] * 3 + [_vp] * 3 + [_c_float, _c_float, _c_int, _vp, _vp, _vp, _vp]
     lib.gsr_knn_workspace_bytes.restype = ctypes.c_size_t
     lib.gsr_knn_workspace_bytes.argtypes = [_c_int]
     lib.gsr_knn_mean_dist2.restype = _c_int

@@ -518,27 +518,52 @@ static int gsr_check_loss_args(int C, int H, int W, const float* img, const floa
     return GSR_OK;
 }
 
-extern "C" int gsr_rgb_loss_forward(int C, int H, int W, const float* img, const float* gt, const float* weight,
-                                    float a_l1, float a_ssim, void* workspace, float* out3, int keep_state, void* stream)
+static int gsr_check_window(int window_size)
+{
+    if (window_size < 1 || window_size > 11 || (window_size & 1) == 0)
+        return gsr_fail(GSR_ERR_UNSUPPORTED, "loss: window_size must be odd and in 1..11 (got %d)", window_size);
+    return GSR_OK;
+}
+
+extern "C" int gsr_rgb_loss_forward_window(int C, int H, int W, const float* img, const float* gt, const float* weight,
+                                           float a_l1, float a_ssim, int window_size, void* workspace, float* out3, int keep_state,
+                                           void* stream)
 {
     int rc = gsr_check_loss_args(C, H, W, img, gt, workspace);
     if (rc) return rc;
+    rc = gsr_check_window(window_size);
+    if (rc) return rc;
     if (!out3) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: out3 is NULL");
-    GSR_HIP(gsl_launch_forward(C, H, W, img, gt, weight, a_l1, a_ssim, workspace, out3, keep_state, (hipStream_t)stream),
+    GSR_HIP(gsl_launch_forward(C, H, W, img, gt, weight, a_l1, a_ssim, workspace, out3, keep_state, window_size, (hipStream_t)stream),
             "rgb loss forward");
     return GSR_OK;
+}
+
+extern "C" int gsr_rgb_loss_backward_window(int C, int H, int W, const float* img, const float* gt, const float* weight,
+                                            float a_l1, float a_ssim, int window_size, const void* workspace,
+                                            const float* upstream, float* dL_dimg, void* stream)
+{
+    int rc = gsr_check_loss_args(C, H, W, img, gt, workspace);
+    if (rc) return rc;
+    rc = gsr_check_window(window_size);
+    if (rc) return rc;
+    if (!dL_dimg) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: dL_dimg is NULL");
+    GSR_HIP(gsl_launch_backward(C, H, W, img, gt, weight, a_l1, a_ssim, workspace, upstream, dL_dimg, window_size, (hipStream_t)stream),
+            "rgb loss backward");
+    return GSR_OK;
+}
+
+extern "C" int gsr_rgb_loss_forward(int C, int H, int W, const float* img, const float* gt, const float* weight,
+                                    float a_l1, float a_ssim, void* workspace, float* out3, int keep_state, void* stream)
+{
+    return gsr_rgb_loss_forward_window(C, H, W, img, gt, weight, a_l1, a_ssim, 11, workspace, out3, keep_state, stream);
 }
 
 extern "C" int gsr_rgb_loss_backward(int C, int H, int W, const float* img, const float* gt, const float* weight,
                                      float a_l1, float a_ssim, const void* workspace, const float* upstream,
                                      float* dL_dimg, void* stream)
 {
-    int rc = gsr_check_loss_args(C, H, W, img, gt, workspace);
-    if (rc) return rc;
-    if (!dL_dimg) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "loss: dL_dimg is NULL");
-    GSR_HIP(gsl_launch_backward(C, H, W, img, gt, weight, a_l1, a_ssim, workspace, upstream, dL_dimg, (hipStream_t)stream),
-            "rgb loss backward");
-    return GSR_OK;
+    return gsr_rgb_loss_backward_window(C, H, W, img, gt, weight, a_l1, a_ssim, 11, workspace, upstream, dL_dimg, stream);
 }
 
 // ---- simple_knn (knn.hip) ----

@@ -212,10 +212,10 @@ hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, con
 // ---- loss.hip ----
 size_t gsl_workspace_bytes(int C, int H, int W);
 hipError_t gsl_launch_forward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
-                              float a_ssim, void* workspace, float* out, int keep_state, hipStream_t stream);
+                              float a_ssim, void* workspace, float* out, int keep_state, int window_size, hipStream_t stream);
 hipError_t gsl_launch_backward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
                                float a_ssim, const void* workspace, const float* upstream, float* dL_dimg,
-                               hipStream_t stream);
+                               int window_size, hipStream_t stream);
 
 // ---- knn.hip ----
 size_t gsk_workspace_bytes(int P);

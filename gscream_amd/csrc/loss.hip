@@ -29,8 +29,11 @@
 #define GSL_HW (GSL_TW + 2 * GSL_R)  // 42
 #define GSL_HH (GSL_TH + 2 * GSL_R)  // 26
 
-// normalised 1-D Gaussian, sigma = 1.5, 11 taps (loss_utils.py:113-115), rounded to fp32 like torch.Tensor(...)
-__constant__ float GSL_G[11] = { 0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c3ep-3f, 0x1.10656p-2f,
+// normalised 1-D Gaussian, sigma = 1.5, 11 taps (loss_utils.py:113-115), rounded to fp32 like torch.Tensor(...).  The
+// kernels take their taps as an argument (GslTaps, in the kernel-argument segment: scalar loads like __constant__): a smaller
+// odd window is the same 11-tap machinery with zeros at both ends -- identical to conv2d with padding window_size // 2.
+struct GslTaps { float g[11]; };
+static const float GSL_G11[11] = { 0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c3ep-3f, 0x1.10656p-2f,
                                  0x1.b43c3ep-3f, 0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f, 0x1.0d956cp-10f };
 
 struct GslPartial { double l1, ssim; };
@@ -45,8 +48,9 @@ __global__ void __launch_bounds__(256) gsl_forward_kernel(int H, int W, const fl
                                                           const float* __restrict__ gt,
                                                           const float* __restrict__ weight, float* __restrict__ d_mu1,
                                                           float* __restrict__ d_e11, float* __restrict__ d_e12,
-                                                          GslPartial* __restrict__ partial)
+                                                          GslPartial* __restrict__ partial, const GslTaps taps)
 {
+    const float* GSL_G = taps.g;
     __shared__ float sx[GSL_HH][GSL_HW + 1], sy[GSL_HH][GSL_HW + 1];
     __shared__ float hx[5][GSL_HH][GSL_TW];
     __shared__ double red[2][4];
@@ -177,8 +181,9 @@ __global__ void __launch_bounds__(256) gsl_backward_kernel(int H, int W, const f
                                                            const float* __restrict__ weight,
                                                            const float* __restrict__ d_mu1, const float* __restrict__ d_e11,
                                                            const float* __restrict__ d_e12, float c_l1, float c_ssim,
-                                                           const float* __restrict__ upstream, float* __restrict__ dL_dimg)
+                                                           const float* __restrict__ upstream, float* __restrict__ dL_dimg, const GslTaps taps)
 {
+    const float* GSL_G = taps.g;
     __shared__ float sm[3][GSL_HH][GSL_HW + 1];
     __shared__ float hx[3][GSL_HH][GSL_TW];
     const int t = threadIdx.x, ch = blockIdx.z;
@@ -278,17 +283,38 @@ static GslWorkspace gsl_carve(void* base, int C, int H, int W)
 
 size_t gsl_workspace_bytes(int C, int H, int W) { return gsl_carve(nullptr, C, H, W).bytes; }
 
-hipError_t gsl_launch_forward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
-                              float a_ssim, void* workspace, float* out, int keep_state, hipStream_t stream)
+// taps of create_window(window_size) (loss_utils.py:113-121) centred in the 11-tap frame; window_size odd, 1..11
+static bool gsl_make_taps(int window_size, GslTaps& t)
 {
+    if (window_size < 1 || window_size > 11 || (window_size & 1) == 0) return false;
+    for (int k = 0; k < 11; k++) t.g[k] = 0.f;
+    if (window_size == 11) {
+        for (int k = 0; k < 11; k++) t.g[k] = GSL_G11[k];
+        return true;
+    }
+    const int r = window_size / 2;
+    float g[11], sum = 0.f;
+    for (int x = 0; x < window_size; x++) {  // torch.Tensor([exp(...)]) rounds each double to fp32; the sum and the division are fp32
+        g[x] = (float)exp(-(double)((x - r) * (x - r)) / (2.0 * 1.5 * 1.5));
+        sum += g[x];
+    }
+    for (int x = 0; x < window_size; x++) t.g[GSL_R - r + x] = g[x] / sum;
+    return true;
+}
+
+hipError_t gsl_launch_forward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                              float a_ssim, void* workspace, float* out, int keep_state, int window_size, hipStream_t stream)
+{
+    GslTaps taps;
+    if (!gsl_make_taps(window_size, taps)) return hipErrorInvalidValue;
     const GslWorkspace w = gsl_carve(workspace, C, H, W);
     const dim3 grid(w.gx, w.gy, C);
     if (keep_state)
         hipLaunchKernelGGL(gsl_forward_kernel<true>, grid, dim3(256), 0, stream, H, W, img, gt, weight, w.d_mu1, w.d_e11,
-                           w.d_e12, w.partial);
+                           w.d_e12, w.partial, taps);
     else
         hipLaunchKernelGGL(gsl_forward_kernel<false>, grid, dim3(256), 0, stream, H, W, img, gt, weight, w.d_mu1, w.d_e11,
-                           w.d_e12, w.partial);
+                           w.d_e12, w.partial, taps);
     hipLaunchKernelGGL(gsl_finish_kernel, dim3(1), dim3(256), 0, stream, w.gx * w.gy * C, w.partial,
                        (double)C * (double)H * (double)W, a_l1, a_ssim, out);
     return hipGetLastError();
@@ -296,11 +322,13 @@ hipError_t gsl_launch_forward(int C, int H, int W, const float* img, const float
 
 hipError_t gsl_launch_backward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
                                float a_ssim, const void* workspace, const float* upstream, float* dL_dimg,
-                               hipStream_t stream)
+                               int window_size, hipStream_t stream)
 {
+    GslTaps taps;
+    if (!gsl_make_taps(window_size, taps)) return hipErrorInvalidValue;
     const GslWorkspace w = gsl_carve(const_cast<void*>(workspace), C, H, W);
     const double count = (double)C * (double)H * (double)W;
     hipLaunchKernelGGL(gsl_backward_kernel, dim3(w.gx, w.gy, C), dim3(256), 0, stream, H, W, img, gt, weight, w.d_mu1,
-                       w.d_e11, w.d_e12, (float)((double)a_l1 / count), (float)((double)a_ssim / count), upstream, dL_dimg);
+                       w.d_e11, w.d_e12, (float)((double)a_l1 / count), (float)((double)a_ssim / count), upstream, dL_dimg, taps);
     return hipGetLastError();
 }

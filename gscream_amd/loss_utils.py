@@ -14,7 +14,7 @@ and adds ``rgb_loss`` = the composition train.py:538-545 builds from them, in ON
 
 All of them run `gsr_rgb_loss_forward/backward` (include/gsraster.h) through ctypes; gradients flow to the first
 image argument only (the ground truth is a constant in the trainer).  There is no CPU fallback: tensors must live on
-a HIP device.  Differences from the reference: the 11x11 window is applied separably (two 11-tap passes) instead of
+a HIP device.  `window_size`: odd, up to 11 (11 everywhere in GScream).  Differences from the reference: the window is applied separably (two 11-tap passes) instead of
 as one 121-tap depthwise conv2d, so values agree to fp32 rounding (~1e-6), not bit for bit.
 """
 import ctypes
@@ -55,18 +55,19 @@ class _FusedLoss(torch.autograd.Function):
     """L = a_l1 * mean(|img - gt| * m) + a_ssim * mean(ssim_map(img, gt) * m)."""
 
     @staticmethod
-    def forward(ctx, img, gt, weight, a_l1, a_ssim):
+    def forward(ctx, img, gt, weight, a_l1, a_ssim, window_size=11):
         lib = _native.load()
         x, y, w, C, H, W = _prep(img, gt, weight)
         need_grad = img.requires_grad
         with torch.cuda.device(x.device):
             ws = torch.empty((lib.gsr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=x.device)
             out = torch.empty((3,), dtype=torch.float32, device=x.device)
-            _native.check(lib.gsr_rgb_loss_forward(C, H, W, _native.ptr(x), _native.ptr(y), _native.ptr(w), float(a_l1),
-                                                   float(a_ssim), _native.ptr(ws), _native.ptr(out), int(need_grad),
-                                                   _stream()), "gsr_rgb_loss_forward")
+            _native.check(lib.gsr_rgb_loss_forward_window(C, H, W, _native.ptr(x), _native.ptr(y), _native.ptr(w), float(a_l1),
+                                                          float(a_ssim), int(window_size), _native.ptr(ws), _native.ptr(out),
+                                                          int(need_grad), _stream()), "gsr_rgb_loss_forward")
         ctx.save_for_backward(x, y, w if w is not None else torch.empty(0, device=x.device), ws)
         ctx.coef = (float(a_l1), float(a_ssim))
+        ctx.window_size = int(window_size)
         ctx.in_shape = tuple(img.shape)
         ctx.mark_non_differentiable(out)
         return out[0], out
@@ -79,15 +80,17 @@ class _FusedLoss(torch.autograd.Function):
         up = g_loss.detach().reshape(1).float().contiguous()
         with torch.cuda.device(x.device):
             grad = torch.empty_like(x)
-            _native.check(lib.gsr_rgb_loss_backward(C, H, W, _native.ptr(x), _native.ptr(y), _native.ptr(w), ctx.coef[0],
-                                                    ctx.coef[1], _native.ptr(ws), _native.ptr(up), _native.ptr(grad),
-                                                    _stream()), "gsr_rgb_loss_backward")
-        return grad.reshape(ctx.in_shape), None, None, None, None
+            _native.check(lib.gsr_rgb_loss_backward_window(C, H, W, _native.ptr(x), _native.ptr(y), _native.ptr(w), ctx.coef[0],
+                                                           ctx.coef[1], ctx.window_size, _native.ptr(ws), _native.ptr(up),
+                                                           _native.ptr(grad), _stream()), "gsr_rgb_loss_backward")
+        return grad.reshape(ctx.in_shape), None, None, None, None, None
 
 
 def _check_window(window_size, size_average, img):
-    if window_size != 11:
-        raise NotImplementedError("only window_size=11 (what GScream uses everywhere) is implemented")
+    if not (1 <= int(window_size) <= 11) or int(window_size) % 2 == 0:
+        # even windows change the map's size in the reference (padding = window_size // 2) and fail against the mask; larger
+        # ones are beyond the kernels' 11-tap frame.  GScream uses 11 everywhere.
+        raise NotImplementedError("window_size must be odd and at most 11")
     if not size_average and not (img.dim() == 4 and img.shape[0] == 1):
         # loss_utils.py:160 `ssim_map.mean(1).mean(1).mean(1)`: a per-image mean, defined for [B,C,H,W] input only
         # (the reference itself fails on the [C,H,W] images the trainer passes); one image per call here
@@ -108,12 +111,12 @@ def l1_loss_masked(network_output, gt, mask):
 
 def ssim(img1, img2, window_size=11, size_average=True):
     _check_window(window_size, size_average, img1)
-    return _per_image(_FusedLoss.apply(img1, img2, None, 0.0, 1.0)[0], size_average)
+    return _per_image(_FusedLoss.apply(img1, img2, None, 0.0, 1.0, window_size)[0], size_average)
 
 
 def ssim_masked(img1, img2, mask, window_size=11, size_average=True):
     _check_window(window_size, size_average, img1)
-    return _per_image(_FusedLoss.apply(img1, img2, mask, 0.0, 1.0)[0], size_average)
+    return _per_image(_FusedLoss.apply(img1, img2, mask, 0.0, 1.0, window_size)[0], size_average)
 
 
 def rgb_loss(image, gt, weight=None, lambda_dssim=0.2, scale=1.0, return_parts=False):

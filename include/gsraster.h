@@ -251,6 +251,13 @@ int gsr_rgb_loss_forward(int C, int H, int W, const float* img, const float* gt,
                          float a_ssim, void* workspace, float* out3, int keep_state, void* stream);
 int gsr_rgb_loss_backward(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
                           float a_ssim, const void* workspace, const float* upstream, float* dL_dimg, void* stream);
+/* The same with ssim's `window_size` argument (utils/loss_utils.py:131,165; create_window :117-121): odd, 1..11 (11 = the two
+ * entry points above = what GScream's trainer uses everywhere); other values -> GSR_ERR_UNSUPPORTED. */
+int gsr_rgb_loss_forward_window(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                                float a_ssim, int window_size, void* workspace, float* out3, int keep_state, void* stream);
+int gsr_rgb_loss_backward_window(int C, int H, int W, const float* img, const float* gt, const float* weight, float a_l1,
+                                 float a_ssim, int window_size, const void* workspace, const float* upstream, float* dL_dimg,
+                                 void* stream);
 
 /*
  * The depth terms of the same loss (train.py:548-573): least-squares scale/shift alignment of the rendered depth to the

@@ -69,8 +69,22 @@ def test_mirrored_functions_and_upstream_gradient():
     ref.backward()
     assert abs(float(total.detach()) - float(ref.detach())) < 3e-6
     assert (x.grad.cpu().double() - xr.grad).abs().max() <= 1e-4 * xr.grad.abs().max()
+    # other window sizes (loss_utils.py:131 `window_size`): odd, up to 11 -- the same kernels with zero taps at both ends
+    for ws in (1, 3, 7):
+        x2 = torch.from_numpy(img).cuda().requires_grad_(True)
+        v = L.ssim(x2, y, window_size=ws)
+        vm = L.ssim_masked(x2, y, m, window_size=ws)
+        (v + 0.5 * vm).backward()
+        x3 = torch.from_numpy(img).double().requires_grad_(True)
+        r = LO.ssim_map(x3, yr, ws).mean()
+        rm = (LO.ssim_map(x3, yr, ws) * mr).mean()
+        (r + 0.5 * rm).backward()
+        assert abs(float(v.detach()) - float(r.detach())) < 3e-6 and abs(float(vm.detach()) - float(rm.detach())) < 3e-6, ws
+        assert (x2.grad.cpu().double() - x3.grad).abs().max() <= 1e-4 * x3.grad.abs().max(), ws
     with pytest.raises(NotImplementedError):
-        L.ssim(x, y, window_size=7)
+        L.ssim(x, y, window_size=8)   # even: the reference's map changes size
+    with pytest.raises(NotImplementedError):
+        L.ssim(x, y, window_size=13)  # beyond the 11-tap frame
     with pytest.raises(RuntimeError):
         L.ssim(x.detach().cpu(), y.cpu())
     # size_average=False (loss_utils.py:157-160): one mean per image of a [B,C,H,W] batch; B = 1 here
