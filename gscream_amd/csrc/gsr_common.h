@@ -55,7 +55,10 @@
 #define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
 // Segment length of a launch: small images have few tiles, so their lists are cut finer to get enough tasks for the
 // 5120 wavefront slots; large ones already have them and shorter tasks would only add fixed costs (measured both ways).
-static inline int gsr_seg_len(int T) { return T <= 4096 ? 64 : 128; }
+#ifndef GSR_SEG64_MAX_TILES
+#define GSR_SEG64_MAX_TILES 4096
+#endif
+static inline int gsr_seg_len(int T) { return T <= GSR_SEG64_MAX_TILES ? 64 : 128; }
 #define GSR_LOG2E 1.4426950408889634f
 
 struct GsrRec {
