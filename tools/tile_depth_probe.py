@@ -31,3 +31,12 @@ print("R", R, "tiles", len(n))
 print("list length   pct", q, np.percentile(n, q).astype(int), "mean", n.mean())
 print("traversed     pct", q, np.percentile(work, q).astype(int), "mean", work.mean())
 print("sum traversed / sum list", work.sum() / n.sum())
+# how well do quantities known BEFORE the blend predict a tile's traversal depth?
+nc = v["n_contrib"].cpu().numpy().astype(np.int64)
+gx = (W + 15) // 16
+print("corr(list length, traversed) =", round(float(np.corrcoef(n, work)[0, 1]), 3))
+# per 8x8 quadrant: deepest pixel of the quadrant vs the tile's list length
+Hq, Wq = (H + 7) // 8, (W + 7) // 8
+pad = np.zeros((Hq * 8, Wq * 8), np.int64); pad[:H, :W] = nc
+qd = pad.reshape(Hq, 8, Wq, 8).max(axis=(1, 3))
+print("quadrant depth pct", q, np.percentile(qd, q).astype(int), "mean", qd.mean())
