@@ -567,16 +567,33 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     {
         auto behind = [&](const size_t p, const float gc0, const float gc1, const float gc2, const float gdd, const float guu,
                           float& T_, float& A_) {
+            // two memory round trips instead of up to eight: {last slot, slot `seg`} first (the count of checkpoints the pixel
+            // passed is in the last slot), then every slot behind this segment at once; the sums are formed back to front in
+            // the same order as a slot-by-slot loop.
             const float4 fa = gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[p];
+            const float Te = gsr_ckpt_a(ckpt, seg, HW)[p].x;
+            float2 fb = make_float2(0.f, 0.f);
+            if (AUX) fb = gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[p];
             const int np = __float_as_int(fa.x);  // checkpoints this pixel passed (>= seg + 1 here)
-            float t0 = fa.y, t1 = fa.z, t2 = fa.w, td = 0.f, tu = 0.f;
-            if (AUX) { const float2 fb = gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[p]; td = fb.x; tu = fb.y; }
-            for (int k = np - 1; k >= seg + 1; k--) {  // the segments behind this one, back to front
-                const float4 sa = gsr_ckpt_a(ckpt, k, HW)[p];
-                t0 += sa.y; t1 += sa.z; t2 += sa.w;
-                if (AUX) { const float2 sb = gsr_ckpt_b(ckpt, k, HW)[p]; td += sb.x; tu += sb.y; }
+            float4 sa[GSR_SEG_MAX - 1];
+            float2 sb[GSR_SEG_MAX - 1];
+#pragma unroll
+            for (int k = 1; k < GSR_SEG_MAX - 1; k++) {
+                sa[k] = make_float4(0.f, 0.f, 0.f, 0.f); sb[k] = make_float2(0.f, 0.f);
+                if (k < np && k >= seg + 1) {
+                    sa[k] = gsr_ckpt_a(ckpt, k, HW)[p];
+                    if (AUX) sb[k] = gsr_ckpt_b(ckpt, k, HW)[p];
+                }
             }
-            const float Te = gsr_ckpt_a(ckpt, seg, HW)[p].x, r = 1.0f / Te;
+            float t0 = fa.y, t1 = fa.z, t2 = fa.w, td = fb.x, tu = fb.y;
+#pragma unroll
+            for (int k = GSR_SEG_MAX - 2; k >= 1; k--) {  // the segments behind this one, back to front
+                if (k < np && k >= seg + 1) {
+                    t0 += sa[k].y; t1 += sa[k].z; t2 += sa[k].w;
+                    if (AUX) { td += sb[k].x; tu += sb[k].y; }
+                }
+            }
+            const float r = 1.0f / Te;
             T_ = Te;
             A_ = (t0 * r) * gc0 + (t1 * r) * gc1 + (t2 * r) * gc2;
             if (AUX) A_ += (td * r) * gdd + (tu * r) * guu;
@@ -675,7 +692,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
                 nw = gsr_compact2<SL>(sQ, mylist, cnt, qmask, lane, [=](int i) { return hi - 1 - i < wmax; });
             }
             __builtin_amdgcn_wave_barrier();
+#ifdef GSR_BWD_NOLOOP  // diagnostic: everything but the instance loop (what a task costs around it)
+            for (int c0 = 0; c0 < 0; c0 += 64) {
+#else
             for (int c0 = 0; c0 < nw; c0 += 64) {
+#endif
                 const int m = min(64, nw - c0);
                 const int jj = mylist[min(c0 + lane, nw - 1)];
                 int j = __builtin_amdgcn_readlane(jj, 0);
