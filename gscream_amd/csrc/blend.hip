@@ -531,6 +531,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     const int seg_lo = seg * seg_len;
     const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + seg_len);
     if (seg_hi <= seg_lo) return;
+#if defined(GSR_BWD_DIAG) && GSR_BWD_DIAG == 1  // diagnostic: dispatch + task lookup only
+    return;
+#endif
 
     // lanes l, l+4, l+8, l+12 of a DPP row share their pixel row (see gsr_bank_reduce_dyf)
     const int pxa = tx * 16 + ((lane >> 1) & 7), pxb = pxa + 8;
@@ -610,6 +613,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
         }
     }
 
+#if defined(GSR_BWD_DIAG) && GSR_BWD_DIAG == 2  // diagnostic: ... + the pixel prologue (final T, gradients, checkpoint sums)
+    if (Tr.x + Ar.x + Tr.y + Ar.y + g0.x + g1.x + g2.x == 12345.678f) slots[0] = make_float4(Tr.x, Ar.x, Tr.y, Ar.y);
+    return;
+#endif
     // wave-level maximum of the last contributor: nothing at a position >= it is blended by this strip
     int wmax = max(lastca, lastcb);
 #pragma unroll
