@@ -13,6 +13,7 @@ gradients in one native call on the f32 matrix cores; no library GEMM on the pat
 `use_feat_bank=True` (off in every GScream config, arguments/__init__.py:57) runs the bank MLP + blend as a torch pre-step.
 No CPU fallback."""
 import ctypes
+import threading
 
 import torch
 
@@ -130,15 +131,43 @@ class _Decode(torch.autograd.Function):
                 *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
 
 
-_last_decode = {}
-_readback_cache = {}
+_tls = threading.local()  # per host thread: the last decode's bookkeeping and the read-back word (two threads may decode at once)
+
+
+class _LastDecode:
+    """dict-like view of this thread's slot"""
+
+    def _d(self):
+        d = getattr(_tls, "last", None)
+        if d is None:
+            d = _tls.last = {}
+        return d
+
+    def update(self, **kw):
+        self._d().update(**kw)
+
+    def clear(self):
+        self._d().clear()
+
+    def __bool__(self):
+        return bool(self._d())
+
+    def __getitem__(self, k):
+        return self._d()[k]
+
+
+_last_decode = _LastDecode()
 
 
 def _readback(dev):
-    """(pinned int32[1], event) per device: the row count travels through them without a stream-wide synchronisation."""
-    r = _readback_cache.get(dev.index)
+    """(pinned int32[1], event) per host thread and device: the row count travels through them without a stream-wide
+    synchronisation."""
+    cache = getattr(_tls, "readback", None)
+    if cache is None:
+        cache = _tls.readback = {}
+    r = cache.get(dev.index)
     if r is None:
-        r = _readback_cache[dev.index] = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        r = cache[dev.index] = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
     return r
 
 

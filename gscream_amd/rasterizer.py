@@ -14,6 +14,7 @@ Underneath, instead of the pybind module `_C` (DGR/ext.cpp:15-21) the calls go t
 through the C ABI of include/gsraster.h (gscream_amd/_native.py).  PyTorch only provides device
 memory (caching allocator), the current HIP stream and autograd plumbing.
 """
+import threading
 from typing import NamedTuple
 
 import torch
@@ -26,7 +27,7 @@ _tuning_ref = _native.ctypes.byref(_tuning)  # built once: the struct is mutated
 _capacity_hint = {}  # per-device: (binning capacity, longest-list provision) for the next speculative forward
 _recent = {}         # per-device: (num_rendered, max_tile_count) of the last few forwards (training hops between views)
 _RECENT_FRAMES = 8
-_pinned = {}  # per-device (pinned int32[4] that receives gsr_stage1_result, its ctypes pointer)
+_pinned_tls = threading.local()  # per host thread and device: (pinned int32[4] that receives gsr_stage1_result, its ctypes pointer)
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
@@ -157,10 +158,13 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
 
     geom = empty((lib.gsr_geom_bytes(P),), dtype=torch.uint8, device=dev)
     img = empty((lib.gsr_image_bytes(P, W, H),), dtype=torch.uint8, device=dev)
-    pin = _pinned.get(idx)
+    pins = getattr(_pinned_tls, "pins", None)
+    if pins is None:
+        pins = _pinned_tls.pins = {}
+    pin = pins.get(idx)
     if pin is None:
         t = torch.zeros(4, dtype=torch.int32).pin_memory()
-        pin = _pinned[idx] = (t, _native.ctypes.cast(t.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result)))
+        pin = pins[idx] = (t, _native.ctypes.cast(t.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result)))
     res = pin[1]
     debug = 1 if rs.debug else 0
     tuning = _tuning_ref
