@@ -179,7 +179,7 @@ template <bool GLOBAL>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ depthkey, const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum,
-    const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity)
+    const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity, uint32_t stage_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor_lds[];
     uint32_t* cursor = GLOBAL ? const_cast<uint32_t*>(table) : cursor_lds;
@@ -188,38 +188,81 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     __shared__ uint32_t chunk_first;
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // workgroup b runs on XCD b % 8: consecutive CHUNKS go to one XCD, so that the runs two neighbouring chunks write into a
+    // tile segment (they share a 32-byte sector at their border) meet in the same L2
+    const int chunk = (nchunks & 7) == 0 ? (int)(blockIdx.x & 7u) * (nchunks >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // STAGED form (round 3).  Written straight to its tile segment, every 8-byte key costs a 32-byte sector write (86 MB of
+    // write requests for 21 MB of keys; with the stores cut out the launch takes 24 instead of 38 us).  When the chunk's
+    // instances fit the rest of the LDS they are first placed TILE-MAJOR in a staging buffer -- the chunk's own count per tile
+    // is the difference of two rows of the scanned table, an LDS scan of those gives the local offsets -- and then streamed
+    // out: neighbouring staging entries of one tile are neighbouring keys of that tile's segment, so a wave's store covers
+    // runs (4.6 keys on the bench scene) instead of 64 lone sectors.  Which slot of its (chunk, tile) run a key gets is as
+    // arbitrary as before; the per-tile sort does not care (keys are unique).
+    //   dynamic LDS: cursor[T] | loff[T] | gbase[T] | keys[cap] (8 B) | tile[cap] (2 B)
+    uint32_t* loff = cursor_lds + T;
+    uint32_t* gbase = cursor_lds + 2 * (size_t)T;
+    u64* skey = reinterpret_cast<u64*>(cursor_lds + 3 * (size_t)T + ((3 * (size_t)T) & 1));
+    uint16_t* stile = reinterpret_cast<uint16_t*>(skey + stage_cap);
+    const uint32_t chunk_total = GLOBAL ? 0u : chunk_sum[chunk];
+    const bool staged = !GLOBAL && stage_cap > 0u && chunk_total <= stage_cap && T <= 65535;  // block-uniform
     if (!GLOBAL) {
         // cursor = tile start + this chunk's offset inside the tile; eight entries per thread per trip with all loads
         // issued before the first LDS store (one memory round trip per trip instead of one per entry)
-        const uint32_t* row = table + (size_t)blockIdx.x * T;
+        const uint32_t* row = table + (size_t)chunk * T;
+        const uint32_t* nrow = row + T;  // the next chunk's offsets (the last chunk ends at the tile's end)
+        const bool last_chunk = chunk + 1 >= nchunks;
         for (int t0 = threadIdx.x; t0 < T; t0 += blockDim.x * 8) {
-            uint32_t a[8], b[8];
+            uint32_t a[8], b[8], c[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int t = t0 + k * (int)blockDim.x;
-                a[k] = t < T ? ranges[t].x : 0u;
+                const uint2 rg = t < T ? ranges[t] : make_uint2(0u, 0u);
+                a[k] = rg.x;
                 b[k] = t < T ? row[t] : 0u;
+                c[k] = !staged ? 0u : last_chunk ? rg.y - rg.x : (t < T ? nrow[t] : 0u);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int t = t0 + k * (int)blockDim.x;
-                if (t < T) cursor[t] = a[k] + b[k];
+                if (t < T) {
+                    if (staged) { gbase[t] = a[k] + b[k]; loff[t] = c[k] - b[k]; }  // loff: count for now, offset after the scan
+                    else cursor[t] = a[k] + b[k];
+                }
             }
         }
     }
     if (threadIdx.x == 0) chunk_first = 0u;
     __syncthreads();
+    if (staged) {
+        // exclusive scan of the chunk's per-tile counts -> local offsets (thread i owns ceil(T / blockDim) consecutive tiles)
+        const int per = (T + (int)blockDim.x - 1) / (int)blockDim.x, t0 = (int)threadIdx.x * per;
+        uint32_t sum = 0;
+        for (int i = 0; i < per; i++) sum += t0 + i < T ? loff[t0 + i] : 0u;
+        const uint32_t incl = gsr_wave_scan_add(sum);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < wave; w++) run += wsum[w];
+        for (int i = 0; i < per; i++) {
+            if (t0 + i >= T) break;
+            const uint32_t v = loff[t0 + i];
+            loff[t0 + i] = run;
+            cursor[t0 + i] = run;  // the staging cursor of the tile
+            run += v;
+        }
+        __syncthreads();
+    }
     // first gradient slot of the chunk = instances of all earlier chunks
     {
         uint32_t pv = 0u;
-        for (int i = threadIdx.x; i < (int)blockIdx.x; i += blockDim.x) pv += chunk_sum[i];
+        for (int i = threadIdx.x; i < chunk; i += blockDim.x) pv += chunk_sum[i];
         pv = gsr_wave_scan_add(pv);
         if (lane == 63 && pv != 0u) atomicAdd(&chunk_first, pv);
     }
     __syncthreads();
     uint32_t carry = chunk_first;
     int lo, hi;
-    gsr_chunk_bounds(P, nchunks, blockIdx.x, lo, hi);
+    gsr_chunk_bounds(P, nchunks, chunk, lo, hi);
     constexpr int U = 4;
     for (int tb = lo; tb < hi; tb += blockDim.x * U) {  // block-uniform trip count (barriers inside)
         const int gb = tb + (int)threadIdx.x;
@@ -258,8 +301,23 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             // instead of gathering 4-byte depths
             gsr_wave_for_each_instance(rcs[k], mks[k], dks[k], heads, [&](int owner, int x, int y, uint32_t odk) {
                 const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
-                if (slot < capacity) seg_keys[slot] = ((u64)odk << 32) | (uint32_t)(g_lane0 + owner);  // capacity < R only in a speculative launch that is redone
+#ifdef GSR_SCATTER_NOSTORE  // diagnostic: everything but the key stores (are the 32-byte-sector writes what the kernel waits for?)
+                if (slot == 0xffffffffu) seg_keys[0] = odk;
+#else
+                const u64 key = ((u64)odk << 32) | (uint32_t)(g_lane0 + owner);
+                if (staged) {
+                    if (slot < stage_cap) { skey[slot] = key; stile[slot] = (uint16_t)(y * gx + x); }  // (always true: the counts are exact)
+                } else if (slot < capacity) seg_keys[slot] = key;  // capacity < R only in a speculative launch that is redone
+#endif
             });
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < chunk_total; i += blockDim.x) {
+            const uint32_t t = stile[i];
+            const uint32_t dst = gbase[t] + (i - loff[t]);
+            if (dst < capacity) seg_keys[dst] = skey[i];
         }
     }
 }
@@ -729,14 +787,24 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
         hipLaunchKernelGGL(gsr_cursor_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, image.ranges, image.table);
         hipLaunchKernelGGL(gsr_scatter_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
                            geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
-                           bin.seg_keys, (uint32_t)capacity);
+                           bin.seg_keys, (uint32_t)capacity, 0u);
         return hipGetLastError();
     }
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx, nchunks,
+    // dynamic LDS: the three T-entry arrays + as much staging (10 B per instance) as the CU has left; a chunk with more
+    // instances than that takes the direct path inside the same launch
+    const size_t budget = 160 * 1024 - 8192 - 1024;  // static arrays of the kernel: ~4.3 KiB
+    const size_t fixed = gsr_align((size_t)T * 12 + 8);
+    size_t stage_cap = budget > fixed + 4096 ? (budget - fixed) / 10 : 0;
+    stage_cap &= ~(size_t)63;
+#ifdef GSR_SCATTER_NO_STAGING
+    stage_cap = 0;
+#endif
+    const size_t lds = stage_cap ? fixed + stage_cap * 10 : (size_t)T * 4;
+    hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
                        geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
-                       bin.seg_keys, (uint32_t)capacity);
+                       bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap);
     return hipGetLastError();
 }
 
