@@ -454,8 +454,8 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binnin
     float* slots = (float*)scratch;
     // heavy[0] = number of heavy groups (zeroed by the backward blend, which always runs first), heavy[16..] = their indices
     uint32_t* heavy = (uint32_t*)((char*)scratch + gsr_align((size_t)(R > 0 ? R : 1) * GSR_SLOT_FLOATS * sizeof(float)));
-    // written-slot flags: cleared by the forward's tile sort, set by the backward blend, cleared again by the
-    // per-Gaussian backward as it consumes them -- so a second backward over the same forward state works
+    // written-slot flags: cleared by the forward's tile sort, set by the backward blend; the set of written slots is a function
+    // of the forward state alone, so a second backward over the same forward state finds exactly the flags it would set
     uint8_t* slot_written = bin.slot_written;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,

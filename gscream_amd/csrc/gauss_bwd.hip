@@ -268,7 +268,8 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
 {
     // One wave per block owns 64 consecutive Gaussians; their gradient slots are one contiguous range [S0, S1) of
     // `slots` (offsets[] is the exclusive scan of the per-Gaussian slot counts).  The backward blend writes a slot only
-    // for instances it traversed (slot_written[s] = 1, zeroed per call): on the bench scene three quarters of the
+    // for instances it traversed (slot_written[s] = 1; cleared by the forward's tile sort and left set here: which slots a backward
+    // writes depends on the forward state only, so a second backward over the same forward sets exactly the same flags): on the bench scene three quarters of the
     // instances lie behind the depth where their tile saturates.  The wave therefore
     //   1. reads the flag bytes of its range (coalesced), turns them into 64-bit masks + running counts (ballot),
     //   2. builds the compact list of written slots and fetches only those, 3 lanes per 48-byte slot, into LDS,
@@ -279,12 +280,14 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
     constexpr int WCH = 128;  // written slots staged per sub-pass (48 B each)
     __shared__ float4 stage[WCH * 3];
     __shared__ uint16_t wl[FCH];
+#ifdef GSR_K7_BYTE_FLAGS
     __shared__ unsigned long long gmask[FCH / 64];
     __shared__ uint32_t gbase[FCH / 64 + 1];
+#endif
     const int P = A.P, num_slots = A.num_slots;
     const uint32_t* __restrict__ offsets = A.offsets;
     const float4* __restrict__ slots = A.slots;
-    uint8_t* __restrict__ slot_written = A.slot_written;
+    const uint8_t* __restrict__ slot_written = A.slot_written;
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * BS;
     const int idx = g0 + lane;
@@ -323,8 +326,41 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
     const bool spread = cmax > 24u;
-    for (uint32_t base = S0; base < S1; base += FCH) {
-        const uint32_t nf = min(S1 - base, (uint32_t)FCH);
+#ifndef GSR_K7_BYTE_FLAGS
+    for (uint32_t base = S0, nf; base < S1; base += nf) {
+        // One 8-byte load per lane covers the 512 flag bytes from the 8-aligned address below `base` (every pass but the
+        // first starts aligned); lane l holds the flags of slots base - shift + 8 l + k, k = 0..7, as bit k of m.
+        const uint32_t shift = base & 7u;
+        nf = min(S1 - base, (uint32_t)FCH - shift);
+        uint2 w8 = make_uint2(0u, 0u);
+        if (8u * lane < shift + nf) w8 = *reinterpret_cast<const uint2*>(slot_written + (base - shift) + 8u * lane);
+        // bytes are 0 / 1: a multiplication gathers the four low bits of a word's bytes in its top byte
+        uint32_t m = (((w8.x & 0x01010101u) * 0x01020408u) >> 24) | ((((w8.y & 0x01010101u) * 0x01020408u) >> 24) << 4);
+        {
+            const int lo_k = min(max((int)shift - 8 * lane, 0), 8), hi_k = min(max((int)(shift + nf) - 8 * lane, 0), 8);
+            m &= ((1u << hi_k) - 1u) & ~((1u << lo_k) - 1u);  // slots of the neighbouring groups / behind the range
+        }
+        const uint32_t c = (uint32_t)__popc(m), incl = gsr_wave_scan_add(c), excl = incl - c;
+        const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((m >> k) & 1u) wl[excl + (uint32_t)__popc(m & ((1u << k) - 1u))] = (uint16_t)(8 * lane + k - (int)shift);
+        __syncthreads();
+        // A lane's written slots are consecutive entries [ci0, ci1) of the compact list: ci = number of written slots
+        // of the pass below the lane's first / past its last slot (the owner lane's running count + the set bits below the
+        // position, fetched with one cross-lane read each).  No flag test is left in the summation loop.
+        const uint32_t lo = min(max(off, base), base + nf) - base, hi = min(max(off + cnt, base), base + nf) - base;
+        const uint32_t pk = (excl << 8) | m;
+        uint32_t ci0, ci1;
+        {
+            const uint32_t a0 = lo + shift, a1 = hi + shift;
+            const uint32_t p0 = (uint32_t)__shfl((int)pk, (int)min(a0 >> 3, 63u), 64), p1 = (uint32_t)__shfl((int)pk, (int)min(a1 >> 3, 63u), 64);
+            ci0 = lo < nf ? (p0 >> 8) + (uint32_t)__popc(p0 & 0xffu & ((1u << (a0 & 7u)) - 1u)) : run;
+            ci1 = hi < nf ? (p1 >> 8) + (uint32_t)__popc(p1 & 0xffu & ((1u << (a1 & 7u)) - 1u)) : run;
+        }
+#else
+    for (uint32_t base = S0, nf; base < S1; base += nf) {
+        nf = min(S1 - base, (uint32_t)FCH);
         uint8_t f[FCH / 64];
 #pragma unroll
         for (int k = 0; k < FCH / 64; k++) {
@@ -336,17 +372,15 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
         for (int k = 0; k < FCH / 64; k++) {
             const unsigned long long mk = __ballot(f[k] != 0);
             if (f[k]) wl[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint16_t)(k * 64 + lane);
-            if (f[k]) slot_written[base + k * 64 + lane] = 0;  // consumed: the flags stay clear for the next backward
             if (lane == 0) { gmask[k] = mk; gbase[k] = run; }
             run += (uint32_t)__popcll(mk);
         }
         __syncthreads();
-        // A lane's written slots are consecutive entries [ci0, ci1) of the compact list: ci = number of written slots
-        // of the pass below the lane's first / past its last slot.  No flag test is left in the summation loop.
         const uint32_t lo = min(max(off, base), base + nf) - base, hi = min(max(off + cnt, base), base + nf) - base;
         uint32_t ci0 = run, ci1 = run;
         if (lo < nf) ci0 = gbase[lo >> 6] + (uint32_t)__popcll(gmask[lo >> 6] & ((1ull << (lo & 63)) - 1ull));
         if (hi < nf) ci1 = gbase[hi >> 6] + (uint32_t)__popcll(gmask[hi >> 6] & ((1ull << (hi & 63)) - 1ull));
+#endif
         for (uint32_t w0 = 0; w0 < run; w0 += WCH) {
             const uint32_t nw = min(run - w0, (uint32_t)WCH);
             float4 v[WCH * 3 / 64];
@@ -458,7 +492,6 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_heavy_kernel(const GsrGauss
 #pragma unroll
         for (int k = 0; k < FCH / NT; k++) {
             mk[k] = __ballot(f[k] != 0);
-            if (f[k]) slot_written[base + k * NT + t] = 0;  // consumed
             if (lane == 0) { gmask[k * NW + wave] = mk[k]; gcnt[k * NW + wave] = (uint32_t)__popcll(mk[k]); }  // group = 64 consecutive flags
         }
         __syncthreads();

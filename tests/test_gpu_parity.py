@@ -382,12 +382,24 @@ def test_render_call_pattern_of_gaussian_renderer():
     assert screenspace_points.grad.shape == (3000, 3) and screenspace_points.grad[visibility_filter, :2].abs().sum() > 0
     assert xyz.grad.shape == (3000, 3) and opacity.grad.shape == (3000, 1) and unc.grad.shape == (3000, 1)
     assert not unc.grad.any(), "no loss on the feature map -> zero feature gradient"
-    # a second backward over the same saved forward state (the written-slot flags must have been left clear)
+    # a second backward over the same saved forward state
     g1 = xyz.grad.clone()
     xyz.grad = None
     loss.backward(retain_graph=True)
     # the backward is bit-reproducible (per-wavefront LDS accumulators added in a fixed order)
     assert torch.equal(xyz.grad, g1), f"second backward differs by {(xyz.grad - g1).abs().max().item()}"
+    # ... and a third one with OTHER upstream gradients: the flags the earlier backwards left set mark exactly the slots any
+    # backward of this forward writes (the traversal depends on the forward state only), so nothing stale can be summed
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    wimg = torch.rand(rendered_image.shape, device="cuda", generator=gen)
+    wdep = torch.rand(rendered_depth.shape, device="cuda", generator=gen)
+    leaves = (xyz, color, opacity, scaling, rot)
+    got = torch.autograd.grad((rendered_image * wimg).sum() + (rendered_depth * wdep).sum(), leaves, retain_graph=True)
+    fresh = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color, opacities=opacity,
+                       uncertainties=unc, scales=scaling, rotations=rot, cov3D_precomp=None)
+    want = torch.autograd.grad((fresh[0] * wimg).sum() + (fresh[1] * wdep).sum(), leaves)
+    for g, w_ in zip(got, want):
+        assert torch.equal(g, w_), "backward over a reused forward state differs from a fresh forward + backward"
     with torch.no_grad():  # eval path, train.py:756-763
         img2 = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color, opacities=opacity,
                           uncertainties=unc, scales=scaling, rotations=rot, cov3D_precomp=None)[0]
