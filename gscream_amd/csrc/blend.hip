@@ -300,6 +300,9 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
                 A0 += sa.y; A1 += sa.z; A2 += sa.w; A3 += sb.x; A4 += sb.y;
             }
         donem = __builtin_amdgcn_ballot_w64(stopped);
+        // the walk state above came from memory: settle it here, or the blend loop waits for `Tr` with a counter that also
+        // covers the NEXT batch's record loads (the prefetch would be waited for at the first blend of every batch)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
 
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
@@ -388,7 +391,14 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             // forward.cu:531 is applied only to instances that blend
             const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
             const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
-            auto blend = [&](const unsigned long long okm, const float alu, const int j, const float feat) {
+            // colour / depth of both instances requested up front (addressed per lane, no scalar round trip): their LDS latency
+            // passes behind the falloff arithmetic instead of sitting in the blend chain.  That chain is what a wave that has its
+            // SIMD (nearly) to itself is bound by, and the second half of every launch is such waves (tools/wave_trace.py,
+            // tools/lone_wave_probe.py: 123 -> 109 ns per instance for a lone wave, the launch 92.5 -> 87 us).
+            const int ja = __float_as_int(P3.x), jb = __float_as_int(P3.y);
+            float4 Ca = sC[ja];
+            const float4 Cb = sC[jb];
+            auto blend = [&](const unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
                 const float al1 = __builtin_amdgcn_fmed3f(alu, 0.99f, -3.0e38f);  // = min(0.99, alu), one instruction (no NaN canonicalisation in front)
                 const float test_T = Tr * (1.0f - al1);
                 const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
@@ -397,7 +407,6 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 #ifdef GSR_FWD_EXEC_MASK
                 if (__builtin_amdgcn_inverse_ballot_w64(okf)) {  // EXEC = the pixels that blend: no selects
                     const float w = al1 * Tr;
-                    const float4 C = sC[j];
                     C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
                     Dp += C.w * w; Uf += feat * w;
                     Tr = test_T;
@@ -405,7 +414,6 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
                 }
 #else
                 const float w = gsr_sel0(okf, al1 * Tr);
-                const float4 C = sC[j];
                 C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
                 Dp += C.w * w; Uf += feat * w;
                 Tr = gsr_sel(okf, test_T, Tr);
@@ -416,9 +424,11 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             GSR_COUNT_ADD(4, 1);                                 // forward: pair iterations
             GSR_COUNT_ADD(5, (okma != 0ull) + ((cmb & ~donem) != 0ull));  // ... instances of them that blend a pixel
             GSR_COUNT_ADD(6, __popcll(okma) + __popcll(cmb & ~donem));
-            if (okma != 0ull) blend(okma, al.x, __builtin_amdgcn_readfirstlane(__float_as_int(P3.x)), P3.z);
+            // (an opaque use in front of the branch: the compiler would otherwise sink the first read into the branch)
+            asm volatile("" : "+v"(Ca.x), "+v"(Ca.y), "+v"(Ca.z), "+v"(Ca.w));
+            if (okma != 0ull) blend(okma, al.x, ja, Ca, P3.z);
             const unsigned long long okmb = cmb & ~donem;  // after a: pixels it finished no longer blend b
-            if (okmb != 0ull) blend(okmb, al.y, __builtin_amdgcn_readfirstlane(__float_as_int(P3.y)), P3.w);
+            if (okmb != 0ull) blend(okmb, al.y, jb, Cb, P3.w);
             P0 = N0; P1 = N1; P2 = N2; P3 = N3;
         }
         __syncthreads();
@@ -451,6 +461,12 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         out_feature[pid] = Uf;
     }
     GSR_TRACE_END_AT(1, 4 * 4 * 36864)
+#ifdef GSR_TRACE  // + list length, deepest contributor and the position the walk ended at
+    if (lane == 0) {
+        gsr_trace_buf[4 * 4 * 36864 + (size_t)blockIdx.x * 4 + 3] |= ((unsigned long long)(uint32_t)n << 8) | ((unsigned long long)wl << 32);
+        gsr_trace_buf[4 * 4 * 36864 + (size_t)blockIdx.x * 4 + 2] |= (unsigned long long)(uint32_t)base << 32;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

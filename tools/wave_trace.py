@@ -68,3 +68,31 @@ per_simd = collections.Counter((slot * 4 + simd).tolist())
 print("waves per (CU,SIMD): pct", q, np.percentile(list(per_simd.values()), q), "slots used", len(per_simd))
 for tt in np.linspace(0, en.max(), 9)[:-1]:
     print("  t=%6.1f us  resident waves %5d" % (tt, int(((st <= tt) & (en > tt)).sum())))
+# finer timeline + when each SIMD runs dry (the launch lasts until the last one does)
+key = slot * 4 + simd
+last_end = collections.defaultdict(float)
+busy = collections.defaultdict(float)
+for k, e, l in zip(key.tolist(), en.tolist(), life.tolist()):
+    last_end[k] = max(last_end[k], e)
+    busy[k] += l
+le = np.array(list(last_end.values()))
+print("per-SIMD time of its last wave's end: pct", q, np.round(np.percentile(le, q), 1))
+for tt in np.linspace(0, en.max(), 21)[:-1]:
+    res = (st <= tt) & (en > tt)
+    act = len(set(key[res].tolist()))
+    print("  t=%6.1f us  resident waves %5d  SIMDs with >=1 wave %4d  mean waves on those %.2f" % (tt, int(res.sum()), act, res.sum() / max(act, 1)))
+if which == "fwd":
+    nlist = (xcc >> 8) & 0xffffff
+    deep = (rows[:, 3] >> np.uint64(32)).astype(np.int64)
+    walked = (rows[:, 2] >> np.uint64(32)).astype(np.int64)
+    print("list length pct", q, np.percentile(nlist, q), " deepest contributor pct", np.percentile(deep, q), " walked pct", np.percentile(walked, q))
+    print("corr(life, walked) %.3f  corr(life, list length) %.3f  corr(walked, list length) %.3f" % (
+        np.corrcoef(life, walked)[0, 1], np.corrcoef(life, nlist)[0, 1], np.corrcoef(walked, nlist)[0, 1]))
+    order = np.argsort(-en)
+    print("the 25 waves that end last: start, end, life, list length, walked, deepest contributor")
+    for i in order[:25]:
+        print("   %6.1f %6.1f %6.1f %6d %6d %6d" % (st[i], en[i], life[i], nlist[i], walked[i], deep[i]))
+    early = st < 5
+    late = st > 25
+    for name, sel in (("started < 5 us", early), ("started > 25 us", late)):
+        print(name, "n", int(sel.sum()), "life mean %.1f" % life[sel].mean(), "walked mean %.0f" % walked[sel].mean(), "ns per walked position %.0f" % (1e3 * life[sel].sum() / max(walked[sel].sum(), 1)))
