@@ -174,6 +174,9 @@ static int gsr_current_device(int* d)
     return GSR_OK;
 }
 
+// words of the pinned, device-mapped block (one per host thread and device): 0, 1 = {R, longest list} of stage 1, 4 = prefiltered
+// trap, 8 = "the per-Gaussian backward met a heavy group"
+#define GSR_PINNED_HEAVY_SEEN 8
 static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
 {
     int d = 0;
@@ -184,6 +187,7 @@ static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
         GSR_HIP(hipHostMalloc(&p, 64, hipHostMallocMapped), "hipHostMalloc(info)");
         void* pd = nullptr;
         GSR_HIP(hipHostGetDevicePointer(&pd, p, 0), "hipHostGetDevicePointer(info)");
+        memset(p, 0, 64);
         g_tds.host[d] = (uint32_t*)p; g_tds.dev[d] = (uint32_t*)pd;
     }
     *host = g_tds.host[d]; *dev = g_tds.dev[d];
@@ -463,7 +467,17 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binnin
                   "backward blend");
     else
         GSR_HIP(hipMemsetAsync(heavy, 0, 2 * sizeof(uint32_t), stream), "heavy-group counters");
-    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots, slot_written, heavy, R,
+    // Did this thread's previous backward (on this device) meet a group of large splats?  One word of the pinned block: the
+    // per-Gaussian kernel sets it, the host reads and clears it here.  A hint only: without the heavy kernel the first kernel
+    // does such groups itself.
+    volatile uint32_t* pinned = nullptr;
+    uint32_t* pinned_dev = nullptr;
+    rc = gsr_info_buffer(&pinned, &pinned_dev);
+    if (rc) return rc;
+    const bool heavy_expected = pinned[GSR_PINNED_HEAVY_SEEN] != 0u;
+    pinned[GSR_PINNED_HEAVY_SEEN] = 0u;
+    GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots, slot_written, heavy,
+                                        pinned_dev + GSR_PINNED_HEAVY_SEEN, heavy_expected, R,
                                         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dfeatures, dL_dmeans3D, dL_dcov3D,
                                         dL_dsh, dL_dscales, dL_drotations, stream),
               "per-Gaussian backward");

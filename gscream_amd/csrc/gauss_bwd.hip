@@ -104,6 +104,8 @@ struct GsrGaussArgs {
     const float* rotations; const float* cov3D_precomp; const uint32_t* offsets; const uint32_t* tiles; int num_slots;
     const float4* slots; uint8_t* slot_written;
     uint32_t* heavy;  // [0] = number of heavy groups, [1] = groups fetched dynamically (both reset by the backward blend), [16 ..] = indices
+    uint32_t* heavy_seen;  // host-mapped word (may be null): set to 1 by any heavy group -- the host's hint for its NEXT backward
+    int inline_heavy;      // 1 = no heavy kernel follows this launch: the one-wave kernel does the heavy groups itself
     float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dfeatures, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drotations;
 };
 
@@ -296,9 +298,14 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
     // clamped to the slot count: a forward that binned nothing (num_slots = 0) need not have produced offsets
     const uint32_t S1 = min((g0 + BS < P) ? offsets[g0 + BS] : (uint32_t)num_slots, (uint32_t)num_slots);
     const uint32_t S0 = min(offsets[g0], S1);
-    if (S1 - S0 > GSR_K7_HEAVY_SLOTS) {  // a group with large splats: listed for gsr_gauss_bwd_heavy_kernel (wave-uniform)
-        if (lane == 0) A.heavy[16 + atomicAdd(&A.heavy[0], 1u)] = (uint32_t)blockIdx.x;
-        return;
+    if (S1 - S0 > GSR_K7_HEAVY_SLOTS) {  // a group with large splats (wave-uniform)
+        if (lane == 0 && A.heavy_seen) *A.heavy_seen = 1u;  // plain store, every such group writes the same value
+        if (!A.inline_heavy) {                              // listed for gsr_gauss_bwd_heavy_kernel
+            if (lane == 0) A.heavy[16 + atomicAdd(&A.heavy[0], 1u)] = (uint32_t)blockIdx.x;
+            return;
+        }
+        // no heavy kernel was launched (the host had seen no heavy group in its previous backward): done here, window by
+        // window on one wave -- same bits, slow, and only until the next call, which the store above switches over
     }
     const bool vis = live && A.radii[idx] > 0;
     const uint32_t off = live ? offsets[idx] : 0u;
@@ -561,7 +568,8 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_heavy_kernel(const GsrGauss
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
                                      const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
-                                     uint8_t* slot_written, uint32_t* heavy_groups, int num_slots, float* dL_dmeans2D, float* dL_dcolors,
+                                     uint8_t* slot_written, uint32_t* heavy_groups, uint32_t* heavy_seen_mapped, bool heavy_expected,
+                                     int num_slots, float* dL_dmeans2D, float* dL_dcolors,
                                      float* dL_dopacity, float* dL_dfeatures, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                      float* dL_dscales, float* dL_drotations, hipStream_t stream)
 {
@@ -574,10 +582,14 @@ hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, con
     A.dL_dmeans2D = dL_dmeans2D; A.dL_dcolors = dL_dcolors; A.dL_dopacity = dL_dopacity; A.dL_dfeatures = dL_dfeatures;
     A.dL_dmeans3D = dL_dmeans3D; A.dL_dcov3D = dL_dcov3D; A.dL_dsh = dL_dsh; A.dL_dscales = dL_dscales; A.dL_drotations = dL_drotations;
     const dim3 grid((P + 63) / 64);
-    // every group of 64 Gaussians is done by exactly one of the two kernels: the first one does the light groups and lists
-    // the heavy ones, a small grid of 256-thread workgroups then walks that list (nothing to do on a scene without large
-    // splats: 512 workgroups read a zero and leave)
+    // every group of 64 Gaussians is done by exactly one kernel: the first one does the light groups and lists the heavy
+    // ones, a small grid of 256-thread workgroups then walks that list.  On a scene without large splats that second launch
+    // found nothing to do and still cost 4.5 us, so it is only made when the caller's PREVIOUS backward met a heavy group
+    // (heavy_expected, from the host-mapped word the first kernel sets); otherwise the first kernel does whatever heavy groups
+    // turn up itself -- same bits either way.
+    A.heavy_seen = heavy_seen_mapped; A.inline_heavy = heavy_expected ? 0 : 1;
     hipLaunchKernelGGL(gsr_gauss_bwd_kernel, grid, dim3(64), 0, stream, A);
-    hipLaunchKernelGGL(gsr_gauss_bwd_heavy_kernel, dim3(min((P + 63) / 64, 768)), dim3(256), 0, stream, A);  // 3 workgroups per CU are resident
+    if (heavy_expected)
+        hipLaunchKernelGGL(gsr_gauss_bwd_heavy_kernel, dim3(min((P + 63) / 64, 768)), dim3(256), 0, stream, A);  // 3 workgroups per CU are resident
     return hipGetLastError();
 }

@@ -208,7 +208,8 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
                                      const float* cov3D_precomp, const GsrGeom& geom, const float* slots,
-                                     uint8_t* slot_written, uint32_t* heavy_groups, int num_slots, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
+                                     uint8_t* slot_written, uint32_t* heavy_groups, uint32_t* heavy_seen_mapped, bool heavy_expected, int num_slots,
+                                     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dfeatures,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, hipStream_t stream);
 

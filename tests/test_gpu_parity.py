@@ -550,10 +550,16 @@ def test_more_cases_against_live_oracle(variant):
         # the first 64 Gaussians own far more than 1024 gradient slots: the per-Gaussian backward's cooperative (heavy-group)
         # kernel did their sums above; it must be as bit-reproducible as the one-wave path
         assert int(got["radii"][:64].astype(bool).sum()) > 0 and int(st["tiles_touched"][:64].sum()) > 4096
-        again = Hh.hip_run(s, grads)
+        # ... and the same bits come out of the one-wave kernel, which does the heavy groups itself when the caller's previous
+        # backward had met none (the heavy kernel is then not launched; the first kernel sets the hint for the next call)
+        small = S.scene_config1(seed=1, P=200, W=64, H=64)
+        Hh.hip_run(small, S.upstream_grads(1, 64, 64))  # a backward without heavy groups clears the hint
+        inline = Hh.hip_run(s, grads)                    # heavy groups done inline
+        again = Hh.hip_run(s, grads)                     # ... by the cooperative kernel
         for k in Hh.GRAD_KEYS:
             if k in got:
                 assert np.array_equal(got[k], again[k]), f"{k}: the heavy-group backward is bit-reproducible"
+                assert np.array_equal(inline[k], again[k]), f"{k}: one-wave and cooperative heavy-group sums differ"
         set_tuning(tile_cull=False)
         full = Hh.hip_run(s, keep_state=True)
         assert full["num_rendered"] == st["num_rendered"]
