@@ -20,8 +20,9 @@
  *   - the library owns no device memory: workspaces are sized by the gsr_*_bytes queries, allocated by the
  *     caller (PyTorch's caching allocator) and passed in.  All workspace pointers must be 256-byte aligned.
  *     State it does keep, none of it observable through results: per host thread and device one 64-byte pinned,
- *     device-mapped word block (the read-back of num_rendered) and one event, created on first use and released
- *     when the thread exits; the last-error string (thread-local); the optional profiler's event list
+ *     device-mapped word block (the read-back of num_rendered; a flag "the last backward met a group of very large
+ *     splats", which only selects between two launch plans that produce the same bits) and one event, created on
+ *     first use and released when the thread exits; the last-error string (thread-local); the optional profiler's event list
  *     (process-wide, mutex-guarded, only between gsr_profile_begin / _end).  Entry points are re-entrant.
  *   - `stream` is a hipStream_t (NULL = the legacy default stream, which is what the reference
  *     launches on).  debug != 0 synchronises and checks for errors after every stage, the
@@ -155,9 +156,9 @@ int gsr_forward(int P, int D, int M, int W, int H,
  *   dL_dmeans3D[P,3]  dL_dscales[P,3]  dL_drotations[P,4]
  * dL_dout_depth and dL_dout_feature may both be NULL (= no gradient flows into those maps; a cheaper
  * kernel variant runs).  No floating-point atomics on global memory are used.
- * The image workspace (backward task list) and the binning workspace (one "slot written" byte per instance: set by
- * the blend, cleared again by the per-Gaussian pass) are used as scratch during the call and left as the forward
- * produced them, so the backward may run again on the same forward state; two backward calls on ONE forward state
+ * The image workspace (backward task list) and the binning workspace (one "slot written" byte per instance: cleared
+ * by the forward, set by the blend -- to the same set on every backward of one forward state) are used as scratch
+ * during the call, so the backward may run again on the same forward state; two backward calls on ONE forward state
  * must not overlap on different streams.
  */
 int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity /* what the forward's binning
