@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "gsr_rgb_loss_backward_window",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
     "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward", "gsr_training_stats",
-    "gsr_decode_weight_grad_workspace_bytes",
+    "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows",
 )
 NUM_STAGES = 7
 
@@ -109,6 +109,8 @@ def load():
     lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 22
     lib.gsr_decode_weight_grad_workspace_bytes.restype = ctypes.c_size_t
     lib.gsr_decode_weight_grad_workspace_bytes.argtypes = []
+    lib.gsr_decode_zero_hidden_rows.restype = _c_int
+    lib.gsr_decode_zero_hidden_rows.argtypes = [_c_int, _c_int] + [_vp] * 6
     lib.gsr_depth_loss_workspace_bytes.restype = ctypes.c_size_t
     lib.gsr_depth_loss_workspace_bytes.argtypes = [_c_int, _c_int]
     lib.gsr_depth_loss_forward.restype = _c_int

@@ -660,6 +660,17 @@ extern "C" int gsr_decode_backward(int N, int K, const float* const* weights, co
 
 extern "C" size_t gsr_decode_weight_grad_workspace_bytes(void) { return gsd_weight_grad_workspace_bytes(); }
 
+extern "C" int gsr_decode_zero_hidden_rows(int N, int K, const uint8_t* visible_mask, float* d_feat, float* d_anchor, float* d_offsets,
+                                           float* d_grid_scaling, void* stream)
+{
+    if (N < 0 || K < 1 || K > 10) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: bad sizes N=%d K=%d", N, K);
+    if (N == 0) return GSR_OK;
+    if (!visible_mask || !d_feat || !d_anchor || !d_offsets || !d_grid_scaling)
+        return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    GSR_HIP(gsd_launch_zero_hidden(N, K, visible_mask, d_feat, d_anchor, d_offsets, d_grid_scaling, (hipStream_t)stream), "decode zero hidden rows");
+    return GSR_OK;
+}
+
 // ---- depth loss (depth_loss.hip) ----
 extern "C" size_t gsr_depth_loss_workspace_bytes(int H, int W) { return gdl_workspace_bytes(H, W); }
 

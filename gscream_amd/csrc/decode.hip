@@ -1006,3 +1006,27 @@ hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const 
 }
 
 size_t gsd_weight_grad_workspace_bytes() { return (size_t)GSD_WG_BLOCKS * (GSD_WG2_ROWS * GSD_WG2_COLS + GSD_WG1_ROWS * GSD_WG1_COLS) * sizeof(float); }
+
+// Gradient rows of the anchors a decode did NOT touch (hidden by the visibility mask): exact zeros, as the reference's
+// x[visible_mask] indexing leaves them.  One thread per model row; the visible rows are written by the backward kernel, so
+// the caller needs no model-sized zero-fill (57 MB per iteration at 200k anchors; typically a tenth of the rows are hidden).
+__global__ void __launch_bounds__(256) gsd_zero_hidden_kernel(int N, int K, const uint8_t* __restrict__ visible_mask, float* __restrict__ d_feat,
+                                                              float* __restrict__ d_anchor, float* __restrict__ d_off, float* __restrict__ d_gs)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N || visible_mask[r]) return;
+    float4* f = reinterpret_cast<float4*>(d_feat + (size_t)r * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) f[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 3; i++) d_anchor[(size_t)r * 3 + i] = 0.f;
+    for (int i = 0; i < 3 * K; i++) d_off[(size_t)r * 3 * K + i] = 0.f;
+    for (int i = 0; i < 6; i++) d_gs[(size_t)r * 6 + i] = 0.f;
+}
+
+hipError_t gsd_launch_zero_hidden(int N, int K, const uint8_t* visible_mask, float* d_feat, float* d_anchor, float* d_off, float* d_gs,
+                                  hipStream_t stream)
+{
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gsd_zero_hidden_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, K, visible_mask, d_feat, d_anchor, d_off, d_gs);
+    return hipGetLastError();
+}

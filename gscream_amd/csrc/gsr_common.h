@@ -233,6 +233,8 @@ hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int3
                            const float* offsets, const float* gscale, const float* campos, const float* neural_opacity,
                            const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream);
+hipError_t gsd_launch_zero_hidden(int N, int K, const uint8_t* visible_mask, float* d_feat, float* d_anchor, float* d_off, float* d_gs,
+                                  hipStream_t stream);
 hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
                                      const float* offsets, const float* gscale, const float* campos, const uint8_t* mask,
                                      const uint32_t* first, const float* g_xyz, const float* g_color, const float* g_opacity,

@@ -36,7 +36,7 @@ class _Decode(torch.autograd.Function):
     {w1[4], b1[4], w2[4], b2[4]} for the MLPs {opacity, uncertainty, color, cov}."""
 
     @staticmethod
-    def forward(ctx, feat, anchor, offsets, gscale, campos, vis_idx, *weights):
+    def forward(ctx, feat, anchor, offsets, gscale, campos, vis_idx, vis_mask, *weights):
         lib = _native.load()
         if not feat.is_cuda:
             raise RuntimeError("gscream_amd.neural_gaussians: tensors must be on a HIP device (no CPU fallback)")
@@ -80,6 +80,9 @@ class _Decode(torch.autograd.Function):
             xyz, color, opacity, unc, scaling, rot = xyz[:M], color[:M], opacity[:M], unc[:M], scaling[:M], rot[:M]
         ctx.save_for_backward(feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws)
         ctx.vis = vis
+        # the boolean mask the row list came from (one byte per model row), if the caller has it: lets the backward zero the hidden
+        # rows only instead of zero-filling the model-sized gradients
+        ctx.vis_mask = None if (vis is None or vis_mask is None) else vis_mask.detach().contiguous().view(torch.uint8)
         ctx.dims = (N, K, M)
         ctx.in_shapes = [tuple(t.shape) for t in (feat, anchor, offsets, gscale)] + [tuple(w.shape) for w in weights]
         bmask = mask.bool()
@@ -102,7 +105,8 @@ class _Decode(torch.autograd.Function):
             full = feat_c.shape[0]  # model-sized gradients; rows outside `vis` stay zero
             # model-sized gradients; with a row list the rows outside it must be zero: ONE fill for the four tensors
             per = 32 + 3 + 3 * K + 6
-            flatg = torch.zeros((full * per,), dtype=torch.float32, device=dev) if vis is not None else e(full * per)
+            hidden_by_kernel = vis is not None and ctx.vis_mask is not None and ctx.vis_mask.numel() == full
+            flatg = torch.zeros((full * per,), dtype=torch.float32, device=dev) if (vis is not None and not hidden_by_kernel) else e(full * per)
             d_feat = flatg[:full * 32].view(full, 32)
             d_anchor = flatg[full * 32:full * 35].view(full, 3)
             d_off = flatg[full * 35:full * (35 + 3 * K)].view(full, K, 3)
@@ -125,9 +129,12 @@ class _Decode(torch.autograd.Function):
                 _native.ptr(cam_c), _native.ptr(mask), _native.ptr(first), _native.ptr(g_xyz), _native.ptr(g_color), _native.ptr(g_opacity),
                 _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
                 _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(wsp), garr, _stream()), "gsr_decode_backward")
+            if hidden_by_kernel:
+                _native.check(lib.gsr_decode_zero_hidden_rows(full, K, _native.ptr(ctx.vis_mask), _native.ptr(d_feat), _native.ptr(d_anchor),
+                                                              _native.ptr(d_off), _native.ptr(d_gs), _stream()), "gsr_decode_zero_hidden_rows")
         grads_w = gw1 + gb1 + gw2 + gb2
         sh = ctx.in_shapes
-        return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None, None,
+        return (d_feat.reshape(sh[0]), d_anchor.reshape(sh[1]), d_off.reshape(sh[2]), d_gs.reshape(sh[3]), None, None, None,
                 *[g.reshape(s) for g, s in zip(grads_w, sh[4:])])
 
 
@@ -206,12 +213,13 @@ def _mlp_tensors(mlp):
     return lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias
 
 
-def decode(feat, anchor, offsets, grid_scaling, campos, opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp, visible_idx=None):
+def decode(feat, anchor, offsets, grid_scaling, campos, opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp, visible_idx=None, visible_mask=None):
     """-> xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask.  `visible_idx` (int tensor of anchor rows,
-    ascending) folds the reference's visible-anchor gather into the kernels; None decodes every row."""
+    ascending) folds the reference's visible-anchor gather into the kernels; None decodes every row.  `visible_mask` (the boolean
+    mask that row list was made from, optional) spares the backward a model-sized zero-fill."""
     t = [_mlp_tensors(m) for m in (opacity_mlp, uncertainty_mlp, color_mlp, cov_mlp)]
     weights = [t[m][i] for i in range(4) for m in range(4)]  # {w1[4], b1[4], w2[4], b2[4]}
-    return _Decode.apply(feat, anchor, offsets, grid_scaling, campos, visible_idx, *weights)
+    return _Decode.apply(feat, anchor, offsets, grid_scaling, campos, visible_idx, visible_mask, *weights)
 
 
 def _generate_with_feature_bank(viewpoint_camera, pc, visible_mask, is_training):
@@ -244,7 +252,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     _last_decode.clear()
     xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask = decode(
         pc._anchor_feat, pc.get_anchor, pc._offset, pc.get_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,
-        pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp, vis_idx)
+        pc.get_uncertainty_mlp, pc.get_color_mlp, pc.get_cov_mlp, vis_idx,
+        visible_mask if (visible_mask is not None and visible_mask.dtype == torch.bool) else None)
     if _last_decode and visible_mask is not None:
         try:
             mask._gsr_decode = DecodeBookkeeping(_last_decode["vis"], _last_decode["first"], _last_decode["N"], _last_decode["K"],

@@ -198,7 +198,8 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * weights[16] = { w1[4], b1[4], w2[4], b2[4] } for the MLPs {opacity, uncertainty, color, cov} (torch Linear layout).
  * visible (optional): int32[N] rows of the model-sized tensors to decode -- the visible-anchor gather (:25-28) folded
  * in; NULL = rows 0..N-1.  With `visible`, feat/anchor/offsets/grid_scaling and the four d_* outputs are MODEL-sized
- * (the backward writes the visible rows only: pre-zero them).
+ * (the backward writes the visible rows only: pre-zero them, or let
+ * gsr_decode_zero_hidden_rows fill the others).
  *   gsr_decode_count : neural_opacity[N*K], mask[N*K] (u8), count[N] (u8), first[N] (u32, exclusive scan), total[1] (u32);
  *                      block_scratch: ceil(N/256) u32 of scratch
  *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
@@ -223,6 +224,11 @@ int gsr_decode_backward(int N, int K, const float* const* weights, const int32_t
                         const float* g_uncertainty, const float* g_scaling, const float* g_rot, float* d_feat, float* d_anchor,
                         float* d_offsets, float* d_grid_scaling, void* workspace, float* const* grads16, void* stream);
 size_t gsr_decode_weight_grad_workspace_bytes(void);
+/* With `visible`, gsr_decode_backward writes the visible rows of the model-sized d_* tensors only.  This fills the OTHER rows
+ * (visible_mask[r] == 0, one byte per model row: the boolean mask the row list was made from) with zeros, so that the caller
+ * can hand in uninitialised tensors instead of zero-filling all N rows.  N = model rows here. */
+int gsr_decode_zero_hidden_rows(int N, int K, const uint8_t* visible_mask, float* d_feat, float* d_anchor, float* d_offsets,
+                                float* d_grid_scaling, void* stream);
 
 /*
  * Densification statistics of one training iteration: replaces the body of
