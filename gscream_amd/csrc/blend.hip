@@ -567,9 +567,15 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
     const gsr_f2 g1 = {ina ? dL_dcolor[HW + pa] : 0.f, inb ? dL_dcolor[HW + pb] : 0.f};
     const gsr_f2 g2 = {ina ? dL_dcolor[2 * HW + pa] : 0.f, inb ? dL_dcolor[2 * HW + pb] : 0.f};
     gsr_f2 gd = {0.f, 0.f}, gu = {0.f, 0.f};
-    if (AUX) {
-        if (ina) { gd.x = dL_ddepth[pa]; gu.x = dL_dfeature[pa]; }
-        if (inb) { gd.y = dL_ddepth[pb]; gu.y = dL_dfeature[pb]; }
+    if (AUX) {  // either auxiliary map may be absent on its own (NULL = no gradient flows into it)
+        if (dL_ddepth) {
+            if (ina) gd.x = dL_ddepth[pa];
+            if (inb) gd.y = dL_ddepth[pb];
+        }
+        if (dL_dfeature) {
+            if (ina) gu.x = dL_dfeature[pa];
+            if (inb) gu.y = dL_dfeature[pb];
+        }
     }
     const gsr_f2 nTfb = -Tf * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);  // -T_final * (bg . dL/dC)
 
@@ -868,7 +874,7 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
                        geom.offsets, slot_written, s4, heavy_groups)
-    if (dL_ddepth && dL_dfeature) {
+    if (dL_ddepth || dL_dfeature) {
         if (sl == 64) GSR_BWD_LAUNCH(true, 64, dL_ddepth, dL_dfeature);
         else GSR_BWD_LAUNCH(true, GSR_SEG_LEN, dL_ddepth, dL_dfeature);
     } else {

@@ -249,11 +249,9 @@ def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_
     # set_materialize_grads(False): an output the loss never touched arrives as None.  GScream's loss never uses
     # the uncertainty map (train.py:532) and early iterations use no depth either -> cheaper kernel variant.
     gc = _f32c(g_color, dev) if g_color is not None else torch.zeros((3, H, W), dtype=_F32, device=dev)
-    if g_depth is None and g_unc is None:
-        gd = gu = None
-    else:
-        gd = _f32c(g_depth, dev) if g_depth is not None else torch.zeros((1, H, W), dtype=_F32, device=dev)
-        gu = _f32c(g_unc, dev) if g_unc is not None else torch.zeros((1, H, W), dtype=_F32, device=dev)
+    # (either of the two auxiliary maps may be absent on its own: the kernel reads zeros for a NULL one, no fill kernel)
+    gd = _f32c(g_depth, dev) if g_depth is not None else None
+    gu = _f32c(g_unc, dev) if g_unc is not None else None
     # keep every converted tensor referenced until the launches are enqueued: a temporary freed early
     # could hand its block to the next temporary
     means3D_c, colors_c, sh_c = _f32c(means3D), _f32c(colors_precomp, dev), _f32c(sh, dev)
@@ -384,9 +382,10 @@ class GaussianRasterizer(nn.Module):
             _require_gpu(means3D, "means3D")
             dev = means3D.device
             P = means3D.shape[0]
-            radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-            px = torch.zeros((P,), dtype=torch.float32, device=dev) if want_xy else None
-            py = torch.zeros((P,), dtype=torch.float32, device=dev) if want_xy else None
+            # every element is written by the kernel (0 for culled points): no fill kernels in front of it
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            px = torch.empty((P,), dtype=torch.float32, device=dev) if want_xy else None
+            py = torch.empty((P,), dtype=torch.float32, device=dev) if want_xy else None
             if P:
                 view, proj, _ = _cam(rs, dev)
                 means_c, scales_c = _f32c(means3D), _f32c(scales, dev)  # e.g. get_scaling[:, :3] is a strided slice

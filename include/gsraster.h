@@ -154,8 +154,8 @@ int gsr_forward(int P, int D, int M, int W, int H,
  * caller need not zero-fill.  Optional outputs may be NULL: dL_dcov3D[P,6], dL_dsh[P,M,3].
  *   dL_dmeans2D[P,3] (z = 0)  dL_dcolors[P,3]  dL_dopacity[P]  dL_dfeatures[P]
  *   dL_dmeans3D[P,3]  dL_dscales[P,3]  dL_drotations[P,4]
- * dL_dout_depth and dL_dout_feature may both be NULL (= no gradient flows into those maps; a cheaper
- * kernel variant runs).  No floating-point atomics on global memory are used.
+ * dL_dout_depth and dL_dout_feature may each be NULL (= no gradient flows into that map; with both NULL a
+ * cheaper kernel variant runs).  No floating-point atomics on global memory are used.
  * The image workspace (backward task list) and the binning workspace (one "slot written" byte per instance: cleared
  * by the forward, set by the blend -- to the same set on every backward of one forward state) are used as scratch
  * during the call, so the backward may run again on the same forward state; two backward calls on ONE forward state

@@ -627,3 +627,34 @@ def test_image_beyond_the_lds_tile_limit():
     g2 = Hh.hip_run(s, keep_state=True)
     assert g2["num_rendered"] == st["num_rendered"]
     _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+
+
+@pytest.mark.parametrize("absent", ["depth", "uncertainty"])
+def test_one_absent_auxiliary_gradient_equals_zeros(absent):
+    """A loss that touches the image and only ONE of the two auxiliary maps (train.py:532-561 uses depth, never the uncertainty map):
+    the absent upstream gradient reaches the kernel as NULL, not as a zero-filled map -- same bits as explicit zeros."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    s = S.scene_config1(seed=33, P=2500, W=144, H=80)
+    t = lambda a: torch.from_numpy(a).cuda()
+    rs = GaussianRasterizationSettings(image_height=int(s["H"]), image_width=int(s["W"]), tanfovx=s["tanfovx"], tanfovy=s["tanfovy"],
+                                       bg=t(s["bg"]), scale_modifier=1.0, viewmatrix=t(s["viewmatrix"]), projmatrix=t(s["projmatrix"]),
+                                       sh_degree=1, campos=t(s["campos"]), prefiltered=False, debug=False)
+    gc, gd, gu = (t(g) for g in S.upstream_grads(34, s["W"], s["H"]))
+    res = []
+    for explicit_zeros in (False, True):
+        leaves = [t(s[k]).requires_grad_(True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")]
+        m3, op, un, col, sc, rot = leaves
+        img, dep, unc, _ = GaussianRasterizer(rs)(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=True), opacities=op, uncertainties=un,
+                                                 colors_precomp=col, scales=sc, rotations=rot)
+        outs, gos = [img], [gc]
+        for name, o, g in (("depth", dep, gd), ("uncertainty", unc, gu)):
+            if name != absent:
+                outs.append(o); gos.append(g)
+            elif explicit_zeros:
+                outs.append(o); gos.append(torch.zeros_like(g))
+        res.append(torch.autograd.grad(outs, leaves, gos, allow_unused=True))
+    for a, b in zip(*res):
+        if a is None or b is None:  # a head nothing flowed into at all
+            assert (a is None or not a.any()) and (b is None or not b.any())
+        else:
+            assert torch.equal(a, b)
