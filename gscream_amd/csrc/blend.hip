@@ -507,7 +507,8 @@ __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, 
 #endif
 // SL = the launch's segment length (64 up to 4096 tiles, 128 beyond): sizes the LDS arrays.
 template <bool AUX, int SL>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, GSR_BWD_WAVES))) gsr_blend_bwd_kernel(
+// (the 128-entry form is held to 4 waves per SIMD by its 19.5 KB of LDS per workgroup: its register budget says so too)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 64 ? GSR_BWD_WAVES : 4, SL == 64 ? GSR_BWD_WAVES : 4))) gsr_blend_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
@@ -660,8 +661,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GSR_BW
 
     // back to front, in batches of GSR_SEG_LEN instances (one batch, except in a tile's last segment); local j = 0 is
     // the backmost instance of the batch
-    for (int hi = seg_hi; hi > seg_lo; hi -= seg_len) {
-        const int lo = max(seg_lo, hi - seg_len), cnt = hi - lo;
+    // (SL = the batch length the LDS arrays are sized for; the segment, i.e. the checkpoint spacing seg_len, may be longer)
+    for (int hi = seg_hi; hi > seg_lo; hi -= SL) {
+        const int lo = max(seg_lo, hi - SL), cnt = hi - lo;
         if (SL == 64) {
             // both wavefronts stage: wave 0 fetches {a, b} of instance `lane`, wave 1 {c, d} + the slot offset; the strip
             // test below then runs on both (one box test per wave and instance instead of four quadrant tests on wave 0)
@@ -874,11 +876,16 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
                        geom.offsets, slot_written, s4, heavy_groups)
+#ifdef GSR_BWD_BATCH128  // long segments staged 128 instances at a time (19.5 KB of LDS: 4 waves per SIMD)
+    const bool b64 = sl == 64;
+#else                    // long segments in two batches of 64 (9.7 KB: 5 waves per SIMD)
+    const bool b64 = true;
+#endif
     if (dL_ddepth || dL_dfeature) {
-        if (sl == 64) GSR_BWD_LAUNCH(true, 64, dL_ddepth, dL_dfeature);
+        if (b64) GSR_BWD_LAUNCH(true, 64, dL_ddepth, dL_dfeature);
         else GSR_BWD_LAUNCH(true, GSR_SEG_LEN, dL_ddepth, dL_dfeature);
     } else {
-        if (sl == 64) GSR_BWD_LAUNCH(false, 64, nullptr, nullptr);
+        if (b64) GSR_BWD_LAUNCH(false, 64, nullptr, nullptr);
         else GSR_BWD_LAUNCH(false, GSR_SEG_LEN, nullptr, nullptr);
     }
 #undef GSR_BWD_LAUNCH
