@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = (
     "gsr_rgb_loss_backward_window",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
     "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward", "gsr_training_stats",
-    "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows",
+    "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows",
 )
 NUM_STAGES = 7
 
@@ -102,9 +102,11 @@ def load():
     lib.gsr_knn_mean_dist2.restype = _c_int
     lib.gsr_knn_mean_dist2.argtypes = [_c_int, _vp, _vp, _vp, _vp]
     lib.gsr_decode_count.restype = _c_int
-    lib.gsr_decode_count.argtypes = [_c_int, _c_int] + [_vp] * 12
+    lib.gsr_decode_count.argtypes = [_c_int, _c_int] + [_vp] * 13
     lib.gsr_decode_emit.restype = _c_int
-    lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 17
+    lib.gsr_decode_emit.argtypes = [_c_int, _c_int] + [_vp] * 18
+    lib.gsr_decode_visible_rows.restype = _c_int
+    lib.gsr_decode_visible_rows.argtypes = [_c_int] + [_vp] * 5
     lib.gsr_decode_backward.restype = _c_int
     lib.gsr_decode_backward.argtypes = [_c_int, _c_int] + [_vp] * 22
     lib.gsr_decode_weight_grad_workspace_bytes.restype = ctypes.c_size_t

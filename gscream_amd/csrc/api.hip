@@ -605,7 +605,15 @@ static int gsr_check_decode(int N, int K, const float* const* weights)
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
+extern "C" int gsr_decode_visible_rows(int N, const uint8_t* visible_mask, int32_t* rows, uint32_t* count, uint32_t* block_scratch, void* stream)
+{
+    if (N < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: N must be >= 0 (got %d)", N);
+    if (!count || (N > 0 && (!visible_mask || !rows || !block_scratch))) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
+    GSR_HIP(gsd_launch_visible_rows(N, visible_mask, rows, count, block_scratch, (hipStream_t)stream), "decode visible rows");
+    return GSR_OK;
+}
+
+extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const uint32_t* visible_count, const float* feat, const float* anchor,
                                 const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
                                 uint32_t* total, uint32_t* block_scratch, void* stream)
 {
@@ -615,13 +623,14 @@ extern "C" int gsr_decode_count(int N, int K, const float* const* weights, const
     if (N == 0) { GSR_HIP(hipMemsetAsync(total, 0, 4, (hipStream_t)stream), "decode total"); return GSR_OK; }
     if (!feat || !anchor || !campos || !neural_opacity || !mask || !count || !first || !block_scratch)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_count(N, K, weights, visible, feat, anchor, campos, neural_opacity, mask, count, first, total, block_scratch,
+    if (visible_count && !visible) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: visible_count without a row list");
+    GSR_HIP(gsd_launch_count(N, K, weights, visible, visible_count, feat, anchor, campos, neural_opacity, mask, count, first, total, block_scratch,
                              (hipStream_t)stream),
             "decode count");
     return GSR_OK;
 }
 
-extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor,
+extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const int32_t* visible, const uint32_t* visible_count, const float* feat, const float* anchor,
                                const float* offsets, const float* grid_scaling, const float* campos,
                                const float* neural_opacity, const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity, float* uncertainty,
                                float* scaling, float* rot, void* stream)
@@ -631,7 +640,7 @@ extern "C" int gsr_decode_emit(int N, int K, const float* const* weights, const 
     if (N == 0) return GSR_OK;
     if (!feat || !anchor || !offsets || !grid_scaling || !campos || !neural_opacity || !mask || !first)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "decode: a required pointer is NULL");
-    GSR_HIP(gsd_launch_emit(N, K, weights, visible, feat, anchor, offsets, grid_scaling, campos, neural_opacity, mask, first, xyz, color, opacity,
+    GSR_HIP(gsd_launch_emit(N, K, weights, visible, visible_count, feat, anchor, offsets, grid_scaling, campos, neural_opacity, mask, first, xyz, color, opacity,
                             uncertainty, scaling, rot, (hipStream_t)stream), "decode emit");
     return GSR_OK;
 }

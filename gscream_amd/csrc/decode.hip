@@ -209,7 +209,11 @@ __device__ __forceinline__ void gsd_stage(float* sw, int wave, int lane, Entry e
 // ---- pass A: opacity MLP, mask, count ---------------------------------------------------------------------------
 // Workgroups walk 256-anchor blocks (the unit of the scan); wave w of a block takes its anchors 64 w .. 64 w + 63 as four
 // groups of 16.
+// `vis_count` (optional): the number of valid entries of `vis`, read HERE instead of on the host (the row list was compacted on the
+// device, gsd_rows_*): N is then only the upper bound the launch and the buffers were sized for; anchors / blocks past the count get
+// count = 0 / block total = 0, so the scans downstream need not know.
 __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, GsdMlps P, const int32_t* __restrict__ vis,
+                                                                const uint32_t* __restrict__ vis_count,
                                                                 const float* __restrict__ feat,
                                                                 const float* __restrict__ anchor,
                                                                 const float* __restrict__ campos,
@@ -229,15 +233,22 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
     const float* t2 = sw + GSD_L1_ENTRIES * 64 + lane;
     const float cx = campos[0], cy = campos[1], cz = campos[2];
     const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
+    const int Nv = vis_count ? min(N, (int)vis_count[0]) : N;  // rows that exist
     for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+        if (blk * GSD_THREADS >= Nv) {  // a block past the row count (block-uniform): nothing survives here
+            const int n = blk * GSD_THREADS + (int)threadIdx.x;
+            if (n < N) count[n] = 0;
+            if (threadIdx.x == 0) block_sum[blk] = 0u;
+            continue;
+        }
         if (threadIdx.x == 0) bs = 0u;
         __syncthreads();  // (also orders the table writes above against the first reads)
         uint32_t mine = 0;  // survivors among this lane's offsets
 #pragma unroll
         for (int t = 0; t < GSD_GROUPS; t++) {
             const int n = blk * GSD_THREADS + wave * 64 + t * 16 + a;
-            const bool live = n < N;
-            const int nn = live ? n : N - 1;
+            const bool live = n < Nv;
+            const int nn = live ? n : Nv - 1;
             GsdIn X;
             gsd_load_in(X, feat, anchor, cx, cy, cz, vis ? vis[nn] : nn, g);
             gsd_v4 h[2];
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_count_kernel(int N, int K, Gs
             mine += c;
             c += (uint32_t)__shfl_xor((int)c, 16, 64);
             c += (uint32_t)__shfl_xor((int)c, 32, 64);
-            if (g == 0 && live) count[n] = (uint8_t)c;
+            if (g == 0 && n < N) count[n] = live ? (uint8_t)c : (uint8_t)0;
         }
         // survivors of this block of 256 anchors: the scan below only has to cover N/256 block totals
         const uint32_t ws = gsr_wave_scan_add(mine);
@@ -309,13 +320,15 @@ __global__ void __launch_bounds__(GSD_THREADS) gsd_first_kernel(int N, const uin
 #define GSD_EMIT_THREADS 512
 #define GSD_EMIT_ENTRIES (3 * GSD_L1_ENTRIES + 10 * GSD_L2_ENTRIES)  // tiles: uncertainty | colour q = 0..2 | scale q | rotation q
 __global__ void __launch_bounds__(GSD_EMIT_THREADS) gsd_emit_kernel(
-    int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const float* __restrict__ feat, const float* __restrict__ anchor,
-    const float* __restrict__ offsets /*[N,K,3]*/, const float* __restrict__ gscale /*[N,6]*/,
+    int N, int K, GsdMlps P, const int32_t* __restrict__ vis, const uint32_t* __restrict__ vis_count, const float* __restrict__ feat,
+    const float* __restrict__ anchor, const float* __restrict__ offsets /*[N,K,3]*/, const float* __restrict__ gscale /*[N,6]*/,
     const float* __restrict__ campos, const float* __restrict__ neural_opacity, const uint8_t* __restrict__ mask,
     const uint32_t* __restrict__ first, float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity, float* __restrict__ uncertainty,
     float* __restrict__ scaling, float* __restrict__ rot)
 {
     __shared__ float sw[GSD_EMIT_ENTRIES * 64];
+    if (vis_count) N = min(N, (int)vis_count[0]);  // the row count, read on the device (see gsd_count_kernel)
+    if (N <= 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, a = lane & 15;
     gsd_stage<GSD_EMIT_THREADS / 64, GSD_EMIT_ENTRIES>(sw, wave, lane, [&](auto ec) {
         constexpr int e = decltype(ec)::value;
@@ -942,20 +955,20 @@ static GsdMlps gsd_pack(const float* const* w)  // w[16] = {w1[4], b1[4], w2[4],
     return P;
 }
 
-hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
+hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int32_t* vis, const uint32_t* vis_count, const float* feat, const float* anchor,
                             const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
                             uint32_t* total, uint32_t* block_scratch, hipStream_t stream)
 {
     if (N <= 0) return hipSuccess;
     const int nb = (N + GSD_THREADS - 1) / GSD_THREADS;
-    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb < 8 * GSD_MLP_GRID ? nb : 8 * GSD_MLP_GRID), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), vis, feat, anchor, campos,
+    hipLaunchKernelGGL(gsd_count_kernel, dim3(nb < 8 * GSD_MLP_GRID ? nb : 8 * GSD_MLP_GRID), dim3(GSD_THREADS), 0, stream, N, K, gsd_pack(weights), vis, vis_count, feat, anchor, campos,
                        neural_opacity, mask, count, block_scratch);
     hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, block_scratch, total);
     hipLaunchKernelGGL(gsd_first_kernel, dim3(nb), dim3(GSD_THREADS), 0, stream, N, count, block_scratch, first);
     return hipGetLastError();
 }
 
-hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
+hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int32_t* vis, const uint32_t* vis_count, const float* feat, const float* anchor,
                            const float* offsets, const float* gscale, const float* campos, const float* neural_opacity,
                            const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream)
@@ -965,7 +978,7 @@ hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int3
     const int emit_grid = GSD_MLP_GRID;
     const int nb = ((N + 15) / 16 + GSD_EMIT_THREADS / 64 - 1) / (GSD_EMIT_THREADS / 64);
     hipLaunchKernelGGL(gsd_emit_kernel, dim3(nb < emit_grid ? nb : emit_grid), dim3(GSD_EMIT_THREADS), 0, stream, N, K,
-                       gsd_pack(weights), vis, feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
+                       gsd_pack(weights), vis, vis_count, feat, anchor, offsets, gscale, campos, neural_opacity, mask, first, xyz, color,
                        opacity, uncertainty, scaling, rot);
     return hipGetLastError();
 }
@@ -1028,5 +1041,43 @@ hipError_t gsd_launch_zero_hidden(int N, int K, const uint8_t* visible_mask, flo
 {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(gsd_zero_hidden_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, K, visible_mask, d_feat, d_anchor, d_off, d_gs);
+    return hipGetLastError();
+}
+
+// ---- visible-row list on the device (replaces torch.nonzero(visible_mask) and its host round trip) ------------------
+// rows[] = the indices r with visible_mask[r] != 0 in ascending order, count[0] = how many.  Three small launches: per-block
+// counts, the one-block scan above, per-block placement.
+__global__ void __launch_bounds__(256) gsd_rows_count_kernel(int N, const uint8_t* __restrict__ visible_mask, uint32_t* __restrict__ block_sum)
+{
+    __shared__ uint32_t wsum[4];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const bool v = n < N && visible_mask[n] != 0;
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(256) gsd_rows_place_kernel(int N, const uint8_t* __restrict__ visible_mask, const uint32_t* __restrict__ block_base,
+                                                             int32_t* __restrict__ rows)
+{
+    __shared__ uint32_t wsum[4];
+    const int n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool v = n < N && visible_mask[n] != 0;
+    const unsigned long long b = __ballot(v);
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (v) rows[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = n;
+}
+
+hipError_t gsd_launch_visible_rows(int N, const uint8_t* visible_mask, int32_t* rows, uint32_t* count, uint32_t* block_scratch, hipStream_t stream)
+{
+    if (N <= 0) return hipMemsetAsync(count, 0, 4, stream);
+    const int nb = (N + 255) / 256;
+    hipLaunchKernelGGL(gsd_rows_count_kernel, dim3(nb), dim3(256), 0, stream, N, visible_mask, block_scratch);
+    hipLaunchKernelGGL(gsd_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, block_scratch, count);
+    hipLaunchKernelGGL(gsd_rows_place_kernel, dim3(nb), dim3(256), 0, stream, N, visible_mask, block_scratch, rows);
     return hipGetLastError();
 }

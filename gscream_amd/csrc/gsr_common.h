@@ -226,13 +226,14 @@ size_t gsk_workspace_bytes(int P);
 hipError_t gsk_launch(int P, const float* points, float* mean_dist2, void* workspace, hipStream_t stream, const char** why);
 
 // ---- decode.hip ----
-hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
+hipError_t gsd_launch_count(int N, int K, const float* const* weights, const int32_t* vis, const uint32_t* vis_count, const float* feat, const float* anchor,
                             const float* campos, float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first,
                             uint32_t* total, uint32_t* block_scratch, hipStream_t stream);
-hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,
+hipError_t gsd_launch_emit(int N, int K, const float* const* weights, const int32_t* vis, const uint32_t* vis_count, const float* feat, const float* anchor,
                            const float* offsets, const float* gscale, const float* campos, const float* neural_opacity,
                            const uint8_t* mask, const uint32_t* first, float* xyz, float* color, float* opacity,
                            float* uncertainty, float* scaling, float* rot, hipStream_t stream);
+hipError_t gsd_launch_visible_rows(int N, const uint8_t* visible_mask, int32_t* rows, uint32_t* count, uint32_t* block_scratch, hipStream_t stream);
 hipError_t gsd_launch_zero_hidden(int N, int K, const uint8_t* visible_mask, float* d_feat, float* d_anchor, float* d_off, float* d_gs,
                                   hipStream_t stream);
 hipError_t gsd_launch_backward(int N, int K, const float* const* weights, const int32_t* vis, const float* feat, const float* anchor,

@@ -41,7 +41,12 @@ class _Decode(torch.autograd.Function):
         if not feat.is_cuda:
             raise RuntimeError("gscream_amd.neural_gaussians: tensors must be on a HIP device (no CPU fallback)")
         K = int(offsets.shape[1])
-        N = int(anchor.shape[0]) if vis_idx is None else int(vis_idx.shape[0])  # anchors decoded
+        # Three ways to say which anchors: every row; an explicit row list (its length known on the host); or the boolean mask
+        # alone -- then the row list is compacted ON THE DEVICE and its length read back together with the output row count,
+        # after the emit pass is enqueued: no host round trip in front of the decode (torch.nonzero, like the reference's
+        # x[visible_mask], drains the stream first, and that was the one point of a training iteration where the GPU ran dry).
+        device_rows = vis_idx is None and vis_mask is not None
+        N = int(anchor.shape[0]) if vis_idx is None else int(vis_idx.shape[0])  # anchors decoded (device_rows: the upper bound)
         vis = None if vis_idx is None else vis_idx.detach().contiguous().int()
         if feat.shape[1] != 32:
             raise NotImplementedError("feat_dim must be 32 (arguments/__init__.py:50)")
@@ -55,9 +60,16 @@ class _Decode(torch.autograd.Function):
             mask = torch.empty((N * K,), dtype=torch.uint8, device=dev)
             count = torch.empty((max(N, 1),), dtype=torch.uint8, device=dev)
             first = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
-            total = torch.zeros((1,), dtype=torch.int32, device=dev)
+            total = torch.empty((2,), dtype=torch.int32, device=dev)  # [0] output rows (count pass), [1] visible anchors (row compaction)
             scratch = torch.empty((N // 256 + 2,), dtype=torch.int32, device=dev)
-            _native.check(lib.gsr_decode_count(N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(cam_c),
+            vis_count = None
+            if device_rows:
+                vmask8 = vis_mask.detach().contiguous().view(torch.uint8)
+                vis = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
+                vis_count = total[1:]
+                _native.check(lib.gsr_decode_visible_rows(N, _native.ptr(vmask8), _native.ptr(vis), _native.ptr(vis_count), _native.ptr(scratch),
+                                                          _stream()), "gsr_decode_visible_rows")
+            _native.check(lib.gsr_decode_count(N, K, warr, _native.ptr(vis), _native.ptr(vis_count), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(cam_c),
                                                _native.ptr(nop), _native.ptr(mask), _native.ptr(count), _native.ptr(first),
                                                _native.ptr(total), _native.ptr(scratch), _stream()), "gsr_decode_count")
             # The row count M has to reach the host (the outputs' shapes), as it does in the reference's boolean-mask indexing --
@@ -71,13 +83,16 @@ class _Decode(torch.autograd.Function):
             cap = N * K
             e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
             xyz, color, opacity, unc, scaling, rot = e(cap, 3), e(cap, 3), e(cap, 1), e(cap, 1), e(cap, 3), e(cap, 4)
-            _native.check(lib.gsr_decode_emit(N, K, warr, _native.ptr(vis), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c),
+            _native.check(lib.gsr_decode_emit(N, K, warr, _native.ptr(vis), _native.ptr(vis_count), _native.ptr(feat_c), _native.ptr(anchor_c), _native.ptr(off_c),
                                               _native.ptr(gs_c), _native.ptr(cam_c), _native.ptr(nop), _native.ptr(mask), _native.ptr(first),
                                               _native.ptr(xyz), _native.ptr(color), _native.ptr(opacity), _native.ptr(unc),
                                               _native.ptr(scaling), _native.ptr(rot), _stream()), "gsr_decode_emit")
             ev.synchronize()   # waits for the count pass only: the copy was enqueued in front of the emit pass
             M = int(pin[0])
             xyz, color, opacity, unc, scaling, rot = xyz[:M], color[:M], opacity[:M], unc[:M], scaling[:M], rot[:M]
+            if device_rows:  # the buffers were provisioned for every model row: cut them to the visible anchors
+                N = int(pin[1])
+                vis, nop, mask, first = vis[:N], nop[:N * K], mask[:N * K], first[:N]
         ctx.save_for_backward(feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws)
         ctx.vis = vis
         # the boolean mask the row list came from (one byte per model row), if the caller has it: lets the backward zero the hidden
@@ -167,14 +182,14 @@ _last_decode = _LastDecode()
 
 
 def _readback(dev):
-    """(pinned int32[1], event) per host thread and device: the row count travels through them without a stream-wide
+    """(pinned int32[2], event) per host thread and device: the row counts travel through them without a stream-wide
     synchronisation."""
     cache = getattr(_tls, "readback", None)
     if cache is None:
         cache = _tls.readback = {}
     r = cache.get(dev.index)
     if r is None:
-        r = cache[dev.index] = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        r = cache[dev.index] = (torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event())
     return r
 
 
@@ -248,7 +263,9 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         return _generate_with_feature_bank(viewpoint_camera, pc, visible_mask, is_training)
     # gaussian_renderer/__init__.py:20-28: `x[visible_mask]` for four tensors.  Here the mask becomes a row list once
     # and the kernels read (and, in the backward, write) the model-sized tensors through it; no mask = every row.
-    vis_idx = None if visible_mask is None else torch.nonzero(visible_mask, as_tuple=False).view(-1).int()
+    on_device = visible_mask is not None and visible_mask.dtype == torch.bool and visible_mask.is_cuda and visible_mask.dim() == 1
+    # (a boolean mask on the device is compacted there; anything else -- index tensors, CPU masks -- takes the host's nonzero)
+    vis_idx = None if (visible_mask is None or on_device) else torch.nonzero(visible_mask, as_tuple=False).view(-1).int()
     _last_decode.clear()
     xyz, color, opacity, uncertainty, scaling, rot, neural_opacity, mask = decode(
         pc._anchor_feat, pc.get_anchor, pc._offset, pc.get_scaling, viewpoint_camera.camera_center, pc.get_opacity_mlp,

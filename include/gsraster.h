@@ -200,6 +200,11 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * in; NULL = rows 0..N-1.  With `visible`, feat/anchor/offsets/grid_scaling and the four d_* outputs are MODEL-sized
  * (the backward writes the visible rows only: pre-zero them, or let
  * gsr_decode_zero_hidden_rows fill the others).
+ * visible_count (optional, with `visible`): device word holding how many entries of `visible` are valid, read by the kernels
+ * instead of being passed by the host (N is then the upper bound everything was sized for); with gsr_decode_visible_rows, which
+ * compacts a boolean mask into that row list + count on the device, a training iteration needs no host round trip for the
+ * visible-anchor gather (the reference's x[visible_mask] synchronises; so does torch.nonzero).
+ *   gsr_decode_visible_rows : rows[<= N] = ascending indices of the set bytes of visible_mask[N], count[1]; block_scratch: ceil(N/256) u32
  *   gsr_decode_count : neural_opacity[N*K], mask[N*K] (u8), count[N] (u8), first[N] (u32, exclusive scan), total[1] (u32);
  *                      block_scratch: ceil(N/256) u32 of scratch
  *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
@@ -211,10 +216,11 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *                      (workgroup partials, nothing to initialise).  Replaces the autograd backward of
  *                      generate_neural_gaussians including the reference's nn.Linear layers (scene/gaussian_model.py:118-144).
  */
-int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor, const float* campos,
+int gsr_decode_visible_rows(int N, const uint8_t* visible_mask, int32_t* rows, uint32_t* count, uint32_t* block_scratch, void* stream);
+int gsr_decode_count(int N, int K, const float* const* weights, const int32_t* visible, const uint32_t* visible_count, const float* feat, const float* anchor, const float* campos,
                      float* neural_opacity, uint8_t* mask, uint8_t* count, uint32_t* first, uint32_t* total,
                      uint32_t* block_scratch, void* stream);
-int gsr_decode_emit(int N, int K, const float* const* weights, const int32_t* visible, const float* feat, const float* anchor, const float* offsets,
+int gsr_decode_emit(int N, int K, const float* const* weights, const int32_t* visible, const uint32_t* visible_count, const float* feat, const float* anchor, const float* offsets,
                     const float* grid_scaling, const float* campos, const float* neural_opacity /* from gsr_decode_count */,
                     const uint8_t* mask, const uint32_t* first, float* xyz,
                     float* color, float* opacity, float* uncertainty, float* scaling, float* rot, void* stream);
