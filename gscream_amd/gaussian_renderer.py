@@ -34,12 +34,16 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
     out = generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=is_training)
     xyz, color, opacity, uncertainty, scaling, rot = out[:6]
     # gradient carrier of the 2-D (screen-space) means, as in the reference (:120-125)
-    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True, device=xyz.device) + 0
+    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True, device=xyz.device)
     if retain_grad:
+        # a leaf keeps its .grad by itself: the reference's "+ 0" (a non-leaf copy, one more model-sized elementwise kernel per
+        # iteration) followed by retain_grad() gives the caller the same thing
         try:
-            screenspace_points.retain_grad()
+            screenspace_points.retain_grad()  # no-op on a leaf
         except Exception:  # noqa: BLE001  (the reference swallows this too)
             pass
+    else:
+        screenspace_points = screenspace_points + 0  # the reference's non-leaf, whose gradient is not kept
     rendered_image, rendered_depth, uncer, radii = _rasterizer(viewpoint_camera, pipe, bg_color, scaling_modifier)(
         means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color, opacities=opacity,
         uncertainties=uncertainty, scales=scaling, rotations=rot, cov3D_precomp=None)
