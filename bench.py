@@ -235,7 +235,7 @@ def decode_native_ms(dev, model, cam, N, K):
     P = _native.ptr
 
     def fwd_count():
-        _native.check(lib.gsr_decode_count(N, K, warr, None, P(feat), P(anchor), P(campos), P(nop), P(mask), P(count), P(first), P(total),
+        _native.check(lib.gsr_decode_count(N, K, warr, None, None, P(feat), P(anchor), P(campos), P(nop), P(mask), P(count), P(first), P(total),
                                            P(scratch), stream), "gsr_decode_count")
     fwd_count()
     M = int(total.item())
@@ -249,7 +249,7 @@ def decode_native_ms(dev, model, cam, N, K):
 
     def fwd():
         fwd_count()
-        _native.check(lib.gsr_decode_emit(N, K, warr, None, P(feat), P(anchor), P(off), P(gs), P(campos), P(nop), P(mask), P(first), P(xyz),
+        _native.check(lib.gsr_decode_emit(N, K, warr, None, None, P(feat), P(anchor), P(off), P(gs), P(campos), P(nop), P(mask), P(first), P(xyz),
                                           P(color), P(opacity), P(unc), P(scaling), P(rot), stream), "gsr_decode_emit")
 
     def fwdbwd():
