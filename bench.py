@@ -393,8 +393,9 @@ def pipeline_row(dev, W=1008, H=567, N=200_000, K=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
+    kms, _top = gpu_kernel_ms(step, 5)  # GPU kernel time of the same iteration: what is left of the row is the GPU waiting for the host
     return {"what": f"decode ({N} anchors x {K}) -> rasterize {M} Gaussians @ {W}x{H} -> fused L1+SSIM loss -> backward to the MLP weights, all on the HIP rows",
-            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1)}
+            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1), "gpu_kernel_ms_sum": None if kms is None else round(kms, 3)}
 
 
 def gpu_kernel_ms(fn, iters):
