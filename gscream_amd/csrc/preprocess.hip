@@ -5,7 +5,8 @@
 // -ffp-contract=off (see gsr_math.h): outputs are bit-exact against oracle/gs_oracle.c.
 //
 // HBM traffic per Gaussian (mode 0): read 60 B (mean 12, scale 12, quat 16, opacity 4, feature 4,
-// colour 12), write 48 B of the 64-B record + rect 8 + depthkey 4 + tiles 4 + radii 4 = 68 B.
+// colour 12), write the 64-B record (whole waves write all their records, zeros for culled Gaussians: the
+// stores go out coalesced through LDS) + rect 8 + depthkey 4 + tiles 4 + tmask 8 + radii 4 = 92 B.
 // cov3D is NOT stored: the backward recomputes it from scale/quat (bit-identical, cheaper than
 // 24 B out + 24 B in).
 #include "gsr_math.h"
