@@ -93,11 +93,13 @@ class _Decode(torch.autograd.Function):
             if device_rows:  # the buffers were provisioned for every model row: cut them to the visible anchors
                 N = int(pin[1])
                 vis, nop, mask, first = vis[:N], nop[:N * K], mask[:N * K], first[:N]
-        ctx.save_for_backward(feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws)
-        ctx.vis = vis
         # the boolean mask the row list came from (one byte per model row), if the caller has it: lets the backward zero the hidden
-        # rows only instead of zero-filling the model-sized gradients
-        ctx.vis_mask = None if (vis is None or vis_mask is None) else vis_mask.detach().contiguous().view(torch.uint8)
+        # rows only instead of zero-filling the model-sized gradients.  Saved through autograd, whose version check turns an in-place
+        # change of the mask between forward and backward into an error instead of wrong zeros.
+        vmask_saved = None if (vis is None or vis_mask is None) else vis_mask.detach().contiguous().view(torch.uint8)
+        ctx.has_vis_mask = vmask_saved is not None
+        ctx.save_for_backward(feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws, *([vmask_saved] if vmask_saved is not None else []))
+        ctx.vis = vis
         ctx.dims = (N, K, M)
         ctx.in_shapes = [tuple(t.shape) for t in (feat, anchor, offsets, gscale)] + [tuple(w.shape) for w in weights]
         bmask = mask.bool()
@@ -109,6 +111,7 @@ class _Decode(torch.autograd.Function):
     def backward(ctx, g_xyz, g_color, g_opacity, g_unc, g_scaling, g_rot, _g_nop, _g_mask):
         lib = _native.load()
         feat_c, anchor_c, off_c, gs_c, cam_c, mask, first, *ws = ctx.saved_tensors
+        vis_mask8 = ws.pop() if ctx.has_vis_mask else None
         N, K, M = ctx.dims
         dev = feat_c.device
         z = lambda g, c: (torch.zeros((M, c), dtype=torch.float32, device=dev) if g is None else g.detach().contiguous().float())
@@ -120,7 +123,7 @@ class _Decode(torch.autograd.Function):
             full = feat_c.shape[0]  # model-sized gradients; rows outside `vis` stay zero
             # model-sized gradients; with a row list the rows outside it must be zero: ONE fill for the four tensors
             per = 32 + 3 + 3 * K + 6
-            hidden_by_kernel = vis is not None and ctx.vis_mask is not None and ctx.vis_mask.numel() == full
+            hidden_by_kernel = vis is not None and vis_mask8 is not None and vis_mask8.numel() == full
             flatg = torch.zeros((full * per,), dtype=torch.float32, device=dev) if (vis is not None and not hidden_by_kernel) else e(full * per)
             d_feat = flatg[:full * 32].view(full, 32)
             d_anchor = flatg[full * 32:full * 35].view(full, 3)
@@ -145,7 +148,7 @@ class _Decode(torch.autograd.Function):
                 _native.ptr(g_unc), _native.ptr(g_scaling), _native.ptr(g_rot), _native.ptr(d_feat), _native.ptr(d_anchor),
                 _native.ptr(d_off), _native.ptr(d_gs), _native.ptr(wsp), garr, _stream()), "gsr_decode_backward")
             if hidden_by_kernel:
-                _native.check(lib.gsr_decode_zero_hidden_rows(full, K, _native.ptr(ctx.vis_mask), _native.ptr(d_feat), _native.ptr(d_anchor),
+                _native.check(lib.gsr_decode_zero_hidden_rows(full, K, _native.ptr(vis_mask8), _native.ptr(d_feat), _native.ptr(d_anchor),
                                                               _native.ptr(d_off), _native.ptr(d_gs), _stream()), "gsr_decode_zero_hidden_rows")
         grads_w = gw1 + gb1 + gw2 + gb2
         sh = ctx.in_shapes
