@@ -424,7 +424,7 @@ def gpu_kernel_ms(fn, iters):
         return None, None
 
 
-def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10):
+def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0):
     """One complete training iteration of the renderer as train.py runs it on the reference view (train.py:433 anchor
     prefilter -> :527 render with the visible mask -> :535-561 RGB loss incl. the foreground term and the depth loss with
     its foreground term -> :575 backward -> :597-602 training_statis), minus the optimiser step, every piece on the HIP rows."""
@@ -436,6 +436,13 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10):
     from gscream_amd import loss_utils as L
     from gscream_amd import standin_model as SM
     model = SM.Model(N, K, seed=11, dtype=torch.float32, spread=1.5).to(dev)
+    if log_scale_shift:
+        # (diagnostic) The stand-in's random covariance MLP decodes splats with a sigma of ~10 px (13 tiles each: R = 13.5M);
+        # shifting the anchors' log-scales shrinks them.  At -2 the scene is 860k tiny, faint splats in a blob: R = 1.6M, nothing
+        # saturates, every tile's whole list (575 median, 2008 longest) is walked -- the blends take longer than with the large
+        # splats (backward 820 us), so this is not the "realistic small-splat" case either; the bench scene is.
+        with torch.no_grad():
+            model._scaling += float(log_scale_shift)
     w2c = np.eye(4, dtype=np.float32)
     w2c[2, 3] = 6.0
     tfx, tfy = 0.6, 0.6 * H / W
@@ -496,7 +503,16 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10):
             "host_ms": round(host_ms, 3),
             "host_ms_note": "wall time of the Python loop until the last iteration is enqueued (it contains the two host syncs a training iteration has: "
                             "the decode's row count and the rasterizer's num_rendered)",
-            "gpu_kernel_ms_sum": None if kms is None else round(kms, 3), "gpu_top_kernels_us": top}
+            "gpu_kernel_ms_sum": None if kms is None else round(kms, 3), "gpu_top_kernels_us": top,
+            "log_scale_shift": float(log_scale_shift), "num_rendered": _last_num_rendered()}
+
+
+def _last_num_rendered():
+    try:
+        from gscream_amd import rasterizer as RZ
+        return int(RZ._last_stage1["num_rendered"])
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def host_floor_row(dev, W, H):

@@ -51,7 +51,9 @@
 #define GSR_NEAR_CAP 2048        // longer lists are sorted only up to (at most) this many nearest instances first
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
+#ifndef GSR_SEG_MAX
 #define GSR_SEG_MAX 8            // segments per tile; the last one takes everything behind (GSR_SEG_MAX-1) * segment length
+#endif
 #define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
 // Segment length of a launch: small images have few tiles, so their lists are cut finer to get enough tasks for the
 // 5120 wavefront slots; large ones already have them and shorter tasks would only add fixed costs (measured both ways).
