@@ -6,6 +6,7 @@ tensor.  The compaction mask is `tanh(z) > 0`: an fp32 pre-activation within rou
 so the mask is required to agree wherever |neural_opacity| > 1e-5 and the row-wise comparison uses seeds where it
 agrees everywhere (checked)."""
 import copy
+import ctypes
 import os
 import sys
 
@@ -187,3 +188,26 @@ def test_training_statistics_against_oracle():
         a, b = getattr(acc_d, name).cpu(), getattr(acc_r, name)
         assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-6, atol=1e-7), name
     assert acc_d.anchor_demon.max() == 2 and acc_d.offset_denom.sum() > 0
+
+
+@pytest.mark.parametrize("N", [0, 1, 63, 255, 256, 257, 1000, 200_001])
+def test_visible_rows_on_the_device_match_nonzero(N):
+    """gsr_decode_visible_rows (the row list of the visible anchors without torch.nonzero's host round trip): same rows, same
+    order, same count as torch.nonzero, for sizes around the block edges."""
+    from gscream_amd import _native
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(N + 5)
+    for frac in (0.0, 0.1, 0.9, 1.0):
+        mask = torch.rand((N,), device=dev, generator=g) < frac
+        rows = torch.full((max(N, 1),), -7, dtype=torch.int32, device=dev)
+        cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        scratch = torch.empty((N // 256 + 2,), dtype=torch.int32, device=dev)
+        m8 = mask.view(torch.uint8) if N else torch.empty((0,), dtype=torch.uint8, device=dev)
+        _native.check(lib.gsr_decode_visible_rows(N, _native.ptr(m8) if N else None, _native.ptr(rows), _native.ptr(cnt), _native.ptr(scratch),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_decode_visible_rows")
+        want = torch.nonzero(mask).view(-1).int()
+        n = int(cnt.item())
+        assert n == want.numel()
+        assert torch.equal(rows[:n], want)
+        assert bool((rows[n:] == -7).all()), "nothing is written behind the count"
