@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     uint32_t* cursor = GLOBAL ? const_cast<uint32_t*>(table) : cursor_lds;
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
     __shared__ uint32_t wsum[GSR_HIST_THREADS / 64];
+    __shared__ uint32_t wsum4[4][GSR_HIST_THREADS / 64];
     __shared__ uint32_t chunk_first;
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,24 +278,35 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             mks[k] = v ? tmask[g] : 0ull;
             dks[k] = v ? depthkey[g] : 0u;
         }
+        // offsets[] = exclusive scan of the per-Gaussian instance counts in index order: the Gaussian's first gradient slot
+        // (blend backward, gauss_bwd).  Same count as the enumeration below by construction.  The four sub-trips' block scans
+        // share ONE pair of barriers (wave totals of all four in LDS at once) instead of taking a pair each.
+        {
+            uint32_t cnt[U], incl[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                cnt[k] = gsr_rect_count(rcs[k], mks[k]);
+                incl[k] = gsr_wave_scan_add(cnt[k]);
+                if (lane == 63) wsum4[k][wave] = incl[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int g = gb + k * blockDim.x;
+                uint32_t before = 0, tot = 0;
+                for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+                    const uint32_t sw = wsum4[k][w];
+                    tot += sw;
+                    before += w < wave ? sw : 0u;
+                }
+                if (g < hi) offsets[g] = carry + before + incl[k] - cnt[k];
+                carry += tot;
+            }
+            __syncthreads();  // (the next trip rewrites the wave totals)
+        }
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
-            // offsets[] = exclusive scan of the per-Gaussian instance counts in index order: the Gaussian's first
-            // gradient slot (blend backward, gauss_bwd).  Same count as the enumeration below by construction.
-            const uint32_t cnt = gsr_rect_count(rcs[k], mks[k]);
-            const uint32_t incl = gsr_wave_scan_add(cnt);
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = 0, tot = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
-                const uint32_t sw = wsum[w];
-                tot += sw;
-                before += w < wave ? sw : 0u;
-            }
-            if (g < hi) offsets[g] = carry + before + incl - cnt;
-            carry += tot;
-            __syncthreads();
             const int g_lane0 = g - lane;  // lanes of a wave hold consecutive Gaussians
             // the instance's 64-bit sort key (depth bits, id) goes straight into its tile's segment: a scattered store
             // costs one 32-byte sector whether it carries 4 or 8 bytes, and the sort then reads its keys coalesced
