@@ -232,7 +232,8 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
                               const float* features, const float* shs, const float* cov3D_precomp,
                               const float* colors_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, float tan_fovx, float tan_fovy, void* geom_ws, void* image_ws,
-                              int32_t* radii, volatile uint32_t** info_pinned, const gsr_tuning* tuning, int debug, hipStream_t stream)
+                              int32_t* radii, volatile uint32_t** info_pinned, uint32_t** info_mapped_dev, bool defer_tile_scan,
+                              const gsr_tuning* tuning, int debug, hipStream_t stream)
 {
     if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
@@ -256,7 +257,8 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
     uint32_t* mapped_dev = nullptr;
     rc = gsr_info_buffer(info_pinned, &mapped_dev);
     if (rc) return rc;
-    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, stream), "tile count / scans");
+    if (info_mapped_dev) *info_mapped_dev = mapped_dev;
+    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, defer_tile_scan, stream), "tile count / scans");
     return GSR_OK;
 }
 
@@ -290,7 +292,7 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     volatile uint32_t* info = nullptr;  // pinned words the scan kernel writes {R, max} into
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, &info, tuning, debug, stream);
+                            image_ws, radii, &info, nullptr, false, tuning, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
     uint32_t got[2] = { info[0], info[1] };
@@ -326,7 +328,7 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
-    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, stream), "scatter");
+    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, false, nullptr, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
                                                             out_feature, capacity, max_tile_count, false, stream),
@@ -365,11 +367,13 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     rc = gsr_info_event(&ev);
     if (rc) return rc;
     volatile uint32_t* info = nullptr;
+    uint32_t* info_dev = nullptr;
+    // The tile scan (ranges, R, longest list) is folded into the scatter kernel here: nobody needs R before stage 2 is
+    // enqueued, and the one-block launch cost as much as the whole column scan.  The event therefore follows the scatter.
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, &info, tuning, debug, stream);
+                            image_ws, radii, &info, &info_dev, true, tuning, debug, stream);
     if (rc) return rc;
-    GSR_HIP(hipEventRecord(ev, stream), "record");
     const bool partial = gsr_partial_sort(tuning);
     // (speculative: the sort variants are chosen from the hint; with partial sorting the hint only sizes the LDS of the
     // lists up to GSR_NEAR_CAP)
@@ -379,7 +383,9 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         const GsrImage image = gsr_carve_image(image_ws, P, W, H);
         const GsrBinning bin = gsr_carve_binning(binning_ws, binning_capacity);
         const int hint = max_tile_count_hint > 0 ? max_tile_count_hint : -1;
-        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, stream), "scatter");
+        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, true, info_dev, stream), "scatter");
+        // (beyond the LDS tile limit stage 1 ran the stand-alone tile scan: the same words, written earlier)
+        GSR_HIP(hipEventRecord(ev, stream), "record");
         // partial: lists beyond GSR_NEAR_CAP take the fixed-LDS prefix sort whatever the hint says
         GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, geom, image, bin, stream),
                   "tile sort");

@@ -175,11 +175,19 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
 // ---------------------------------------------------------------------------------------------
 // GLOBAL = true (more tiles than LDS holds): the per-tile cursors are a global array initialised to the segment
 // starts (`table` then points at it), claimed with agent-scope atomics.
+// When the tile scan is folded into this kernel (the one-call forward: the host does not need R before stage 2 is enqueued):
+// every workgroup scans the tile totals for its own cursors, workgroup 0 also writes what gsr_tile_scan_kernel writes.
+struct GsrFusedScan {
+    const uint32_t* tile_count;  // null = not folded in: `ranges` was written by gsr_tile_scan_kernel
+    uint2* ranges;
+    uint32_t *info, *tile_work, *sorted_len, *need_full, *info_host;
+};
 template <bool GLOBAL>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ depthkey, const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum,
-    const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity, uint32_t stage_cap)
+    const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity, uint32_t stage_cap,
+    const GsrFusedScan fs)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor_lds[];
     uint32_t* cursor = GLOBAL ? const_cast<uint32_t*>(table) : cursor_lds;
@@ -206,6 +214,46 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     uint16_t* stile = reinterpret_cast<uint16_t*>(skey + stage_cap);
     const uint32_t chunk_total = GLOBAL ? 0u : chunk_sum[chunk];
     const bool staged = !GLOBAL && stage_cap > 0u && chunk_total <= stage_cap && T <= 65535;  // block-uniform
+    const bool fused = !GLOBAL && fs.tile_count != nullptr;  // block-uniform
+    if (fused) {
+        // tile starts = exclusive scan of the tile totals, left in cursor[] for the initialisation below (thread i owns
+        // ceil(T / blockDim) consecutive tiles, like the staged scan further down)
+        const int per = (T + (int)blockDim.x - 1) / (int)blockDim.x, t0 = (int)threadIdx.x * per;
+        uint32_t sum = 0, mx = 0;
+        for (int i = 0; i < per; i++) {
+            const uint32_t v = t0 + i < T ? fs.tile_count[t0 + i] : 0u;
+            sum += v;
+            mx = max(mx, v);
+        }
+        const uint32_t incl = gsr_wave_scan_add(sum);
+        mx = gsr_wave_scan_max(mx);
+        if (lane == 63) { wsum[wave] = incl; wsum4[0][wave] = mx; }
+        __syncthreads();
+        uint32_t run = incl - sum, total = 0, gmax = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+            const uint32_t sw = wsum[w];
+            run += w < wave ? sw : 0u;
+            total += sw;
+            gmax = max(gmax, wsum4[0][w]);
+        }
+        for (int i = 0; i < per; i++) {
+            if (t0 + i >= T) break;
+            const uint32_t v = fs.tile_count[t0 + i];
+            cursor[t0 + i] = run;
+            if (blockIdx.x == 0) {  // what gsr_tile_scan_kernel writes
+                fs.ranges[t0 + i] = make_uint2(run, run + v);
+                fs.tile_work[t0 + i] = 0u;
+                fs.sorted_len[t0 + i] = v;
+                fs.need_full[t0 + i] = 0u;
+            }
+            run += v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            fs.info[0] = total; fs.info[1] = gmax;
+            if (fs.info_host) { fs.info_host[0] = total; fs.info_host[1] = gmax; }
+        }
+        __syncthreads();
+    }
     if (!GLOBAL) {
         // cursor = tile start + this chunk's offset inside the tile; eight entries per thread per trip with all loads
         // issued before the first LDS store (one memory round trip per trip instead of one per entry)
@@ -217,7 +265,11 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int t = t0 + k * (int)blockDim.x;
-                const uint2 rg = t < T ? ranges[t] : make_uint2(0u, 0u);
+                uint2 rg = make_uint2(0u, 0u);
+                if (t < T) {
+                    if (fused) { rg.x = cursor[t]; rg.y = rg.x + fs.tile_count[t]; }  // (read before the stores below overwrite it)
+                    else rg = ranges[t];
+                }
                 a[k] = rg.x;
                 b[k] = t < T ? row[t] : 0u;
                 c[k] = !staged ? 0u : last_chunk ? rg.y - rg.x : (t < T ? nrow[t] : 0u);
@@ -765,7 +817,7 @@ static hipError_t gsr_allow_big_lds()
 }
 
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
-                            hipStream_t stream)
+                            bool defer_tile_scan, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
     hipError_t e;
@@ -785,21 +837,26 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
         hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + GSR_COLSCAN_TILES - 1) / GSR_COLSCAN_TILES), dim3(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
                            image.tile_count);
     }
-    // (3) tile scan -> ranges, info
-    hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
-                       image.info, image.tile_work, image.sorted_len, image.need_full, info_host_mapped);
+    // (3) tile scan -> ranges, info.  The one-call forward folds it into the scatter kernel (gsr_launch_scatter with
+    // fused_info_host): one launch less on the critical path; the host then learns R when the scatter has started.
+    if (!(defer_tile_scan && T <= GSR_MAX_TILES_LDS))
+        hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
+                           image.info, image.tile_work, image.sorted_len, image.need_full, info_host_mapped);
     return hipGetLastError();
 }
 
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              int capacity, hipStream_t stream)
+                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
+    GsrFusedScan fs = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (fused_tile_scan && T <= GSR_MAX_TILES_LDS)
+        fs = GsrFusedScan{ image.tile_count, image.ranges, image.info, image.tile_work, image.sorted_len, image.need_full, fused_info_host };
     if (T > GSR_MAX_TILES_LDS) {
         hipLaunchKernelGGL(gsr_cursor_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, image.ranges, image.table);
         hipLaunchKernelGGL(gsr_scatter_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
                            geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
-                           bin.seg_keys, (uint32_t)capacity, 0u);
+                           bin.seg_keys, (uint32_t)capacity, 0u, fs);
         return hipGetLastError();
     }
     hipError_t e = gsr_allow_big_lds();
@@ -816,7 +873,7 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
     const size_t lds = stage_cap ? fixed + stage_cap * 10 : (size_t)T * 4;
     hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
                        geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
-                       bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap);
+                       bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs);
     return hipGetLastError();
 }
 
