@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsraster.so")  #
 
 #: every symbol include/gsraster.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
-    "gsr_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
+    "gsr_version", "gsr_abi_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
     "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
     "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward", "gsr_rgb_loss_forward_window",
@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows",
 )
 NUM_STAGES = 7
+ABI_VERSION = 4  # include/gsraster.h GSR_ABI_VERSION this binding was written against
 
 
 class Stage1Result(ctypes.Structure):
@@ -31,7 +32,7 @@ class Stage1Result(ctypes.Structure):
 
 class Tuning(ctypes.Structure):
     _fields_ = [("disable_tile_cull", ctypes.c_int32), ("disable_speculation", ctypes.c_int32),
-                ("disable_partial_sort", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+                ("disable_partial_sort", ctypes.c_int32), ("inference", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 class Profile(ctypes.Structure):
@@ -53,6 +54,14 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gscream_amd/csrc`. "
             "There is no CPU fallback for the rasterizer.")
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        lib.gsr_abi_version.restype = _c_int
+        abi = int(lib.gsr_abi_version())
+    except AttributeError:
+        abi = None
+    if abi != ABI_VERSION and not os.environ.get("GSR_SKIP_ABI_CHECK"):  # (the knob: A/B runs against an older build, tools/)
+        raise RuntimeError(f"gscream_amd: {LIB_PATH} has C-ABI version {abi}, this binding needs {ABI_VERSION} "
+                           "(rebuild with `make -C gscream_amd/csrc`)")
     lib.gsr_version.restype = ctypes.c_char_p
     lib.gsr_last_error.restype = ctypes.c_char_p
     lib.gsr_device_count.restype = _c_int

@@ -102,7 +102,8 @@ extern "C" int gsr_profile_end(gsr_profile* out_host)
     return rc;
 }
 
-extern "C" const char* gsr_version(void) { return "gsraster 0.1 (gfx950)"; }
+extern "C" const char* gsr_version(void) { return "gsraster 0.4 (gfx950)"; }
+extern "C" int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 extern "C" const char* gsr_last_error(void) { return g_err; }
 
 extern "C" int gsr_device_count(void)
@@ -160,6 +161,9 @@ struct GsrThreadDeviceState {
     ~GsrThreadDeviceState()
     {
         for (int d = 0; d < GSR_MAX_DEVICES; d++) {
+            // kernels of this thread's last calls may still store into the block (the heavy-group hint is written without a
+            // host wait): drain the owning device before the block goes away
+            if (host[d] && hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
             if (host[d]) (void)hipHostFree(host[d]);
             if (ev[d]) (void)hipEventDestroy(ev[d]);
         }
@@ -304,23 +308,24 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
 // tile asked for it; not enqueued at all when no list was long enough to be partially sorted.
 static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_count, const float* background, void* geom_ws,
                              void* image_ws, void* binning_ws, float* out_color, float* out_depth, float* out_feature,
-                             int debug, hipStream_t stream)
+                             bool inference, int debug, hipStream_t stream)
 {
     if (max_tile_count <= GSR_NEAR_CAP) return GSR_OK;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
-    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_sort_fixup(T, capacity, max_tile_count, image, bin, stream), "tile sort (fix-up)");
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_sort_fixup(T, capacity, max_tile_count, image, bin, inference, stream), "tile sort (fix-up)");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, true, stream),
+                                                            out_feature, capacity, max_tile_count, true, inference, stream),
               "forward blend (fix-up)");
     return GSR_OK;
 }
 
 static bool gsr_partial_sort(const gsr_tuning* tuning) { return !(tuning && tuning->disable_partial_sort); }
+static bool gsr_inference(const gsr_tuning* tuning) { return tuning && tuning->inference; }
 
-static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, const float* background,
+static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, bool inference, const float* background,
                               void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                               float* out_feature, int debug, hipStream_t stream)
 {
@@ -328,15 +333,15 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
-    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, false, nullptr, stream), "scatter");
-    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, geom, image, bin, stream), "tile sort");
+    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, false, nullptr, inference, stream), "scatter");
+    GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, inference, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, false, stream),
+                                                            out_feature, capacity, max_tile_count, false, inference, stream),
               "forward blend");
     // longest list known (two-stage form): the fix-up can follow at once; the one-call form enqueues it after the read-back
     if (partial && max_tile_count >= 0)
         return gsr_enqueue_fixup(P, W, H, capacity, max_tile_count, background, geom_ws, image_ws, binning_ws, out_color,
-                                 out_depth, out_feature, debug, stream);
+                                 out_depth, out_feature, inference, debug, stream);
     return GSR_OK;
 }
 
@@ -374,7 +379,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
                             image_ws, radii, &info, &info_dev, true, tuning, debug, stream);
     if (rc) return rc;
-    const bool partial = gsr_partial_sort(tuning);
+    const bool partial = gsr_partial_sort(tuning), inference = gsr_inference(tuning);
     // (speculative: the sort variants are chosen from the hint; with partial sorting the hint only sizes the LDS of the
     // lists up to GSR_NEAR_CAP)
     {
@@ -383,14 +388,14 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         const GsrImage image = gsr_carve_image(image_ws, P, W, H);
         const GsrBinning bin = gsr_carve_binning(binning_ws, binning_capacity);
         const int hint = max_tile_count_hint > 0 ? max_tile_count_hint : -1;
-        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, true, info_dev, stream), "scatter");
+        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, true, info_dev, inference, stream), "scatter");
         // (beyond the LDS tile limit stage 1 ran the stand-alone tile scan: the same words, written earlier)
         GSR_HIP(hipEventRecord(ev, stream), "record");
         // partial: lists beyond GSR_NEAR_CAP take the fixed-LDS prefix sort whatever the hint says
-        GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, geom, image, bin, stream),
+        GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, inference, geom, image, bin, stream),
                   "tile sort");
         GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                                out_feature, binning_capacity, hint, false, stream),
+                                                                out_feature, binning_capacity, hint, false, inference, stream),
                   "forward blend");
     }
     if (rc) return rc;
@@ -406,7 +411,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     if (!ok) return GSR_NEED_CAPACITY;
     if (partial)
         return gsr_enqueue_fixup(P, W, H, binning_capacity, result_host->max_tile_count, background, geom_ws, image_ws,
-                                 binning_ws, out_color, out_depth, out_feature, debug, stream);
+                                 binning_ws, out_color, out_depth, out_feature, inference, debug, stream);
     return GSR_OK;
 }
 
@@ -421,7 +426,7 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     if (!background || !geom_ws || !image_ws || !binning_ws || !out_color || !out_depth || !out_feature)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
-    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), background, geom_ws, image_ws, binning_ws,
+    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), gsr_inference(tuning), background, geom_ws, image_ws, binning_ws,
                               out_color, out_depth, out_feature, debug, stream);
 }
 

@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         // offsets[] = exclusive scan of the per-Gaussian instance counts in index order: the Gaussian's first gradient slot
         // (blend backward, gauss_bwd).  Same count as the enumeration below by construction.  The four sub-trips' block scans
         // share ONE pair of barriers (wave totals of all four in LDS at once) instead of taking a pair each.
-        {
+        if (offsets) {  // (block-uniform; NULL = inference forward: nobody will ask for gradient slots)
             uint32_t cnt[U], incl[U];
 #pragma unroll
             for (int k = 0; k < U; k++) {
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(NT) gsr_tile_sort_lds_kernel(const uint2* __re
     // true maximum after the fact and redoes stage 2
     if (n <= lo || n > hi || n > fits || rg.y > capacity) return;
     // the tile ranges partition [0, R): each block clears its share of the written-slot flags for the backward
-    for (uint32_t i = threadIdx.x; i < n; i += NT) slot_written[rg.x + i] = 0;
+    if (slot_written) for (uint32_t i = threadIdx.x; i < n; i += NT) slot_written[rg.x + i] = 0;
     // the scatter left the tile's 64-bit keys (depth bits, Gaussian id) in its segment of seg_keys
     if (n <= (uint32_t)(NT * KPT)) {
         u64 v[KPT];
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256) gsr_tile_sort_near_kernel(const uint2* __
     if (rg.y > capacity) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const u64* src = seg_keys + rg.x;
-    for (uint32_t i = t; i < n; i += 256) slot_written[rg.x + i] = 0;
+    if (slot_written) for (uint32_t i = t; i < n; i += 256) slot_written[rg.x + i] = 0;
     if (n <= GSR_NEAR_CAP) {
         // A list short enough for the complete LDS sort is done right here, in the same launch (this kernel's LDS covers it):
         // as a launch of their own behind this one these few tiles were a 90 us tail of single workgroups on a scene whose
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_sort_global_kernel(const uint2*
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n <= lo || rg.y > capacity) return;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) slot_written[rg.x + i] = 0;
+    if (slot_written) for (uint32_t i = threadIdx.x; i < n; i += 1024) slot_written[rg.x + i] = 0;
     u64* k = seg_keys + rg.x;  // the scatter's keys, sorted in place
     __syncthreads();
     gsr_bitonic(k, n, 1024);
@@ -846,16 +846,17 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
 }
 
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, hipStream_t stream)
+                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, bool inference, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
+    uint32_t* const offsets = inference ? nullptr : geom.offsets;  // gradient-slot numbering: only a backward reads it
     GsrFusedScan fs = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     if (fused_tile_scan && T <= GSR_MAX_TILES_LDS)
         fs = GsrFusedScan{ image.tile_count, image.ranges, image.info, image.tile_work, image.sorted_len, image.need_full, fused_info_host };
     if (T > GSR_MAX_TILES_LDS) {
         hipLaunchKernelGGL(gsr_cursor_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, image.ranges, image.table);
         hipLaunchKernelGGL(gsr_scatter_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
-                           geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
+                           geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
                            bin.seg_keys, (uint32_t)capacity, 0u, fs);
         return hipGetLastError();
     }
@@ -872,7 +873,7 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
 #endif
     const size_t lds = stage_cap ? fixed + stage_cap * 10 : (size_t)T * 4;
     hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, geom.offsets,
+                       geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
                        bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs);
     return hipGetLastError();
 }
@@ -882,9 +883,11 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
 // virtual padding is never stored: the dynamic LDS is sized for the longest list that exists (8.5 B per key), not for
 // the class limit -- 11 KiB instead of 34 KiB on the bench scene, twice the resident workgroups.
 static hipError_t gsr_launch_full_sorts(int T, int capacity, uint32_t lo0, uint32_t max_tile_count, const GsrImage& image,
-                                        const GsrBinning& bin, const uint32_t* only_flagged, uint32_t* sorted_len,
-                                        hipStream_t stream)
+                                        const GsrBinning& bin_in, const uint32_t* only_flagged, uint32_t* sorted_len,
+                                        bool inference, hipStream_t stream)
 {
+    GsrBinning bin = bin_in;
+    if (inference) bin.slot_written = nullptr;  // the written-slot flags belong to the backward
     const uint32_t caps[] = { (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)GSR_SORT_CAP_LARGE };
     uint32_t lo = lo0;
     for (uint32_t cap : caps) {
@@ -911,15 +914,17 @@ static hipError_t gsr_launch_full_sorts(int T, int capacity, uint32_t lo0, uint3
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, const GsrGeom& geom,
-                                const GsrImage& image, const GsrBinning& bin, hipStream_t stream)
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, bool inference, const GsrGeom& geom,
+                                const GsrImage& image, const GsrBinning& bin_in, hipStream_t stream)
 {
     (void)geom;
+    GsrBinning bin = bin_in;
+    if (inference) bin.slot_written = nullptr;
     // max_tile_count < 0: not known -> run every variant, blocks exit on mismatch.  speculative: max_tile_count is the
     // caller's guess (it sizes the LDS; the host checks it against the truth afterwards)
     if (capacity <= 0) return hipSuccess;
     const uint32_t mx = max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count;
-    if (!partial) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, stream);
+    if (!partial) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, inference, stream);
     // lists up to GSR_NEAR_CAP: full sort in LDS; longer ones: sorted prefix only (gsr_tile_sort_near_kernel)
     // (a guess below the cap that turns out too small fails the host's check anyway and stage 2 is redone)
     if (mx > GSR_NEAR_CAP) {  // long lists exist: one launch does both classes (fixed 21 KiB of LDS)
@@ -937,9 +942,9 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
 
 // After a forward over partially sorted lists: full sort of the tiles that ran off their sorted prefix (need_full).
 hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
-                                 hipStream_t stream)
+                                 bool inference, hipStream_t stream)
 {
     if (capacity <= 0 || max_tile_count <= GSR_NEAR_CAP) return hipSuccess;
     return gsr_launch_full_sorts(T, capacity, (uint32_t)GSR_NEAR_CAP, (uint32_t)max_tile_count, image, bin, image.need_full,
-                                 image.sorted_len, stream);
+                                 image.sorted_len, inference, stream);
 }

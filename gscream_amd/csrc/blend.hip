@@ -50,14 +50,38 @@
 // alpha = min(0.99, o * expf(power)) (DGR forward.cu:528-533, backward.cu:516-524), with libm-accurate expf and IEEE
 // division -- no pre-scaling, no v_exp_f32, no v_rcp_f32, no FMA contraction.  Used by tests/test_gpu_precise.py to show
 // that the outliers of the shipped build against the oracle are alpha = 1/255 / T = 1e-4 threshold flips.
+#define GSR_QSCALE(v) ((v) * GSR_LOG2E)     // raw conic entry -> entry of the base-2 quadratic form used by the box tests
 #ifdef GSR_PRECISE_MATH
 #define GSR_RCP(x) (1.0f / (x))
-#define GSR_QSCALE(v) ((v) * GSR_LOG2E)     // raw conic entry -> entry of the base-2 quadratic form used by the box tests
 __device__ __forceinline__ float gsr_power1(float cA, float cB, float cC, float dx, float dy) { return -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy; }
 __device__ __forceinline__ float gsr_gauss1(float power) { return expf(power); }
 #else
 #define GSR_RCP(x) __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float gsr_gauss1(float power) { return __builtin_amdgcn_exp2f(power); }
+// Raw conic of the records -> the pre-scaled quadratic form of the blend loops (once per staged instance)
+#define GSR_HA(conA) ((conA) * (-0.5f * GSR_LOG2E))
+#define GSR_HB(conB) ((conB) * (-GSR_LOG2E))
+#define GSR_HC(conC) ((conC) * (-0.5f * GSR_LOG2E))
+// GUARD BAND around the alpha >= 1/255 decision (round 4).  The fast form's alpha differs from the reference expression's by
+// a few 1e-7 relative (pre-scaled quadratic form, FMA contraction, v_exp_f32), so a (pixel, Gaussian) pair whose alpha lies
+// that close to 1/255 may be blended by one implementation and skipped by the other -- the "threshold flips" that were the
+// shipped build's only outliers against the oracle.  Both blend loops now accept candidates from
+// (1 - GSR_BAND)/255 on and, when a candidate lies below (1 + GSR_BAND)/255 -- a wave-uniform, rare branch: ~1e-5 of the
+// evaluated pairs -- decide it with the reference's own expression on the raw conic (gsr_blends_exact: forward.cu:528-534 /
+// backward.cu:516-524, no contraction, accurate expf).  Forward and backward evaluate alpha with the same instructions, so
+// they agree on band membership and on the decision.
+#ifndef GSR_BAND
+#define GSR_BAND 3.0e-5f
+#endif
+#define GSR_ALPHA_LO ((1.0f / 255.0f) * (1.0f - GSR_BAND))
+#define GSR_ALPHA_HI ((1.0f / 255.0f) * (1.0f + GSR_BAND))
+__device__ __forceinline__ bool gsr_blends_exact(const float cA, const float cB, const float cC, const float op, const float dx, const float dy)
+{
+#pragma clang fp contract(off)
+    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    const float alpha = fminf(0.99f, op * expf(power));
+    return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+}
 #endif
 
 // -DGSR_TRACE (diagnostic build `make trace`, not shipped): every wavefront of the backward blend records its start and
@@ -170,13 +194,8 @@ __device__ __forceinline__ void gsr_bank_reduce_dyf(float c0, float c1, float c2
 __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const float4 B, const float tau, int tx, int ty,
                                                       int W, int H)
 {
-    // records hold (hA, hB, hC) = -log2(e) (conA/2, conB, conC/2): q2 = log2(e) q = 0.5 (a dx^2 + c dy^2) + b dx dy with
-    // a = -2 hA, b = -hB, c = -2 hC; the threshold scales the same way
-#ifdef GSR_PRECISE_MATH
-    const float ca = GSR_QSCALE(A.z), cb = GSR_QSCALE(A.w), cc = GSR_QSCALE(B.x);
-#else
-    const float ca = -2.0f * A.z, cb = -A.w, cc = -2.0f * B.x;
-#endif
+    // q2 = log2(e) q = 0.5 (a dx^2 + c dy^2) + b dx dy with (a, b, c) = log2(e) conic; the threshold scales the same way
+    const float ca = GSR_QSCALE(A.z), cb = GSR_QSCALE(A.w), cc = GSR_QSCALE(B.x);  // A, B: the record's raw conic
     const float rA = GSR_RCP(ca), rC = GSR_RCP(cc);
     uint32_t m = 0;
 #pragma unroll
@@ -232,6 +251,35 @@ __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, si
 #if GSR_FWD_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES)))
 #endif
+// -DGSR_FWD_ORDER (experiment, round 4): quadrant tasks are dispatched deepest-walk-first inside each XCD's band, the depth
+// being what the SAME quadrant walked in the previous forward (library-global buffers: an experiment, not product state).
+#ifdef GSR_FWD_ORDER
+__device__ uint32_t gsr_qdepth_hint[4 * 36864];
+__device__ uint32_t gsr_qorder[4 * 36864];
+__global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int NT)
+{
+    // band x of the NT quadrant tasks (gsr_tile_of_block's split); counting sort by depth / 8 (256 buckets), deepest first
+    __shared__ uint32_t hist[256], start[256];
+    const int x = blockIdx.x, q = NT >> 3, r = NT & 7;
+    const int first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, size = q + (x < r ? 1 : 0);
+    for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < size; i += 1024) atomicAdd(&hist[255 - min(gsr_qdepth_hint[first + i] >> 3, 255u)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 256; i++) { start[i] = run; run += hist[i]; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < size; i += 1024) {
+        const uint32_t b = 255 - min(gsr_qdepth_hint[first + i] >> 3, 255u);
+        gsr_qorder[first + atomicAdd(&start[b], 1u)] = (uint32_t)(first + i);
+    }
+}
+#endif
+
+// TRAIN = false: the inference forward (gsr_tuning.inference; render under no_grad): no depth checkpoints are stored (the sums
+// still restart at the segment boundaries, so that they associate as in the training forward), and final T, the last
+// contributor and the running sums are stored only by a quadrant that ran off a partially sorted prefix (its resume state);
+// the tile's traversal depth is not recorded.  Same arithmetic in the same order: images bit-identical.
+template <bool TRAIN>
 __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -244,7 +292,11 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     __shared__ float4 sC[GSR_FWB];
 
     GSR_TRACE_BEGIN
+#ifdef GSR_FWD_ORDER
+    const int u = only_flagged ? gsr_tile_of_block(blockIdx.x, 4 * T) : (int)gsr_qorder[gsr_tile_of_block(blockIdx.x, 4 * T)];
+#else
     const int u = gsr_tile_of_block(blockIdx.x, 4 * T);  // quadrant tasks in tile order, one contiguous band per XCD
+#endif
     const int tile = u >> 2, quad = u & 3;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
@@ -293,7 +345,14 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             C0 = fa.y; C1 = fa.z; C2 = fa.w; Dp = fb.x; Uf = fb.y;
         }
         npass = __builtin_amdgcn_readfirstlane(npass);  // wave-uniform by construction; lane 0 (the quadrant's first pixel) is inside
-        if (inside)
+        if (!TRAIN) {
+            // the inference forward stores no checkpoints: a quadrant that ran off left the sum of its closed segments in slot 0
+            if (inside) {
+                const float4 sa = gsr_ckpt_a(ckpt, 0, HW)[pid];
+                const float2 sb = gsr_ckpt_b(ckpt, 0, HW)[pid];
+                A0 = sa.y; A1 = sa.z; A2 = sa.w; A3 = sb.x; A4 = sb.y;
+            }
+        } else if (inside)
             for (int k = 0; k < npass; k++) {
                 const float4 sa = gsr_ckpt_a(ckpt, k, HW)[pid];
                 const float2 sb = gsr_ckpt_b(ckpt, k, HW)[pid];
@@ -328,7 +387,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         // backward needs the sum BEHIND a position to a relative accuracy that final - prefix cannot give once T is
         // small: sums of small terms have to stay small.)
         if (base > 0 && (base & (seg_len - 1)) == 0 && npass < GSR_SEG_MAX - 1) {
-            if (inside) {
+            if (TRAIN && inside) {  // (inference: the same restarts, so that the sums associate identically, but nothing is stored)
                 gsr_ckpt_a(ckpt, npass, HW)[pid] = make_float4(Tr, C0, C1, C2);
                 gsr_ckpt_b(ckpt, npass, HW)[pid] = make_float2(Dp, Uf);
             }
@@ -339,11 +398,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         cnt = min(GSR_FWB - (base & (GSR_FWB - 1)), n - base);
         bool hit = false;
         if (lane < cnt) {
-#ifdef GSR_PRECISE_MATH
             const float ca = GSR_QSCALE(a.z), cb = GSR_QSCALE(a.w), cc = GSR_QSCALE(b.x);
-#else
-            const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;
-#endif
             hit = !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), bx0, bx1, by0, by1) >
                     gsr_cull_tau_fast(b.y) * GSR_LOG2E);
         }
@@ -352,7 +407,11 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         if (hit) {
             const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             float* dst = reinterpret_cast<float*>(&sPair[pos >> 1][0]) + (pos & 1);
+#ifdef GSR_PRECISE_MATH
             dst[0] = a.x; dst[2] = a.y; dst[4] = a.z; dst[6] = a.w; dst[8] = b.x; dst[10] = b.y;
+#else
+            dst[0] = a.x; dst[2] = a.y; dst[4] = GSR_HA(a.z); dst[6] = GSR_HB(a.w); dst[8] = GSR_HC(b.x); dst[10] = b.y;
+#endif
             dst[12] = __int_as_float(lane); dst[14] = b.w;
             sC[lane] = make_float4(c.x, c.y, c.z, b.z);
         }
@@ -389,8 +448,13 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             const gsr_f2 al = OP * G;
             // alpha >= 1/255 is tested on the unclamped product (0.99 > 1/255: same truth value); the clamp of
             // forward.cu:531 is applied only to instances that blend
+#ifdef GSR_PRECISE_MATH
             const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
             const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
+#else       // candidates from the lower edge of the guard band on; blend() settles the ones inside the band exactly
+            const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= GSR_ALPHA_LO);
+            const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= GSR_ALPHA_LO);
+#endif
             // colour / depth of both instances requested up front (addressed per lane, no scalar round trip): their LDS latency
             // passes behind the falloff arithmetic instead of sitting in the blend chain.  That chain is what a wave that has its
             // SIMD (nearly) to itself is bound by, and the second half of every launch is such waves (tools/wave_trace.py,
@@ -398,7 +462,23 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             const int ja = __float_as_int(P3.x), jb = __float_as_int(P3.y);
             float4 Ca = sC[ja];
             const float4 Cb = sC[jb];
-            auto blend = [&](const unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
+            auto blend = [&](unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
+#ifndef GSR_PRECISE_MATH
+                const unsigned long long bandm = __builtin_amdgcn_ballot_w64(alu < GSR_ALPHA_HI) & okm;
+                if (bandm != 0ull) {  // rare: some pixel's alpha lies inside the guard band -> the reference's own expression decides
+                    // (the list index as an opaque per-lane value: with a scalar address here the compiler moves `j` -- and the
+                    // whole {i_a, i_b, f_a, f_b} record -- to SGPRs with four v_readfirstlane IN THE HOT PATH and waits early for
+                    // the next iteration's LDS reads: forward 86 -> 101 us)
+                    int jv = j;
+                    asm volatile("" : "+v"(jv));
+                    const GsrRec* r = rec + ids[base + jv];
+                    const float4 ra = r->a;
+                    const float2 rb = *reinterpret_cast<const float2*>(&r->b);
+                    const bool keep = gsr_blends_exact(ra.z, ra.w, rb.x, rb.y, ra.x - pxf, ra.y - pyf);
+                    okm &= ~bandm | __builtin_amdgcn_ballot_w64(keep);
+                    GSR_COUNT_ADD(7, 1);
+                }
+#endif
                 const float al1 = __builtin_amdgcn_fmed3f(alu, 0.99f, -3.0e38f);  // = min(0.99, alu), one instruction (no NaN canonicalisation in front)
                 const float test_T = Tr * (1.0f - al1);
                 const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
@@ -434,6 +514,9 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         __syncthreads();
     }
 
+#ifdef GSR_FWD_ORDER
+    if (lane == 0 && !only_flagged) gsr_qdepth_hint[u] = (uint32_t)min(base + GSR_FWB, n);  // list positions this walk covered
+#endif
     // ran off the sorted prefix with pixels still blending: the tile is sorted completely and this quadrant resumes at n
     const bool ran_off = nsort < nlist && rg.y <= capacity && donem != full;
     if (lane == 0) {
@@ -445,15 +528,21 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     uint32_t wl = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
-    if (lane == 0 && wl) atomicMax(&tile_work[tile], wl);  // zeroed by gsr_tile_scan_kernel
+    if (TRAIN && lane == 0 && wl) atomicMax(&tile_work[tile], wl);  // zeroed by gsr_tile_scan_kernel
 
     if (inside) {
-        // sums behind the last checkpoint + how many checkpoints were passed
-        gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float4(__int_as_float(npass), C0, C1, C2);
-        gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float2(Dp, Uf);
+        if (TRAIN || ran_off) {  // (ran_off is wave-uniform)
+            // sums behind the last checkpoint + how many checkpoints were passed
+            gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float4(__int_as_float(npass), C0, C1, C2);
+            gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float2(Dp, Uf);
+            final_T[pid] = Tr;
+            n_contrib[pid] = last | ((ran_off && __builtin_amdgcn_inverse_ballot_w64(donem)) ? 0x80000000u : 0u);  // top bit: for the resume only
+            if (!TRAIN) {  // + the closed segments' sums, which the training forward keeps in its checkpoint slots
+                gsr_ckpt_a(ckpt, 0, HW)[pid] = make_float4(0.f, A0, A1, A2);
+                gsr_ckpt_b(ckpt, 0, HW)[pid] = make_float2(A3, A4);
+            }
+        }
         C0 += A0; C1 += A1; C2 += A2; Dp += A3; Uf += A4;  // image sums = sum of the segment sums
-        final_T[pid] = Tr;
-        n_contrib[pid] = last | ((ran_off && __builtin_amdgcn_inverse_ballot_w64(donem)) ? 0x80000000u : 0u);  // top bit: for the resume only
         out_color[pid] = C0 + Tr * bg[0];
         out_color[HW + pid] = C1 + Tr * bg[1];
         out_color[2 * (size_t)HW + pid] = C2 + Tr * bg[2];
@@ -563,7 +652,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const size_t pa = ina ? (size_t)py * W + pxa : 0, pb = inb ? (size_t)py * W + pxb : 0;
 
     const gsr_f2 Tf = {ina ? final_T[pa] : 0.f, inb ? final_T[pb] : 0.f};
-    const int lastca = ina ? (int)n_contrib[pa] : 0, lastcb = inb ? (int)n_contrib[pb] : 0;
+    // (bit 31 is the forward's resume flag: cleared by its fix-up pass, masked here in case the caller skipped that pass)
+    const int lastca = ina ? (int)(n_contrib[pa] & 0x7fffffffu) : 0, lastcb = inb ? (int)(n_contrib[pb] & 0x7fffffffu) : 0;
     const gsr_f2 g0 = {ina ? dL_dcolor[pa] : 0.f, inb ? dL_dcolor[pb] : 0.f};
     const gsr_f2 g1 = {ina ? dL_dcolor[HW + pa] : 0.f, inb ? dL_dcolor[HW + pb] : 0.f};
     const gsr_f2 g2 = {ina ? dL_dcolor[2 * HW + pa] : 0.f, inb ? dL_dcolor[2 * HW + pb] : 0.f};
@@ -671,7 +761,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                 const uint32_t id = point_list[rg.x + (hi - 1 - lane)];
                 const GsrRec* r = rec + id;
                 if (wave == 0) {
+#ifdef GSR_PRECISE_MATH
                     sA[lane] = r->a; sB[lane] = r->b;
+#else
+                    const float4 a = r->a, b = r->b;  // raw conic -> the pre-scaled form the loop evaluates
+                    sA[lane] = make_float4(a.x, a.y, GSR_HA(a.z), GSR_HB(a.w)); sB[lane] = make_float4(GSR_HC(b.x), b.y, b.z, b.w);
+#endif
                 } else {
                     const uint32_t slot0 = offsets[id];
                     const uint4 d = r->d;
@@ -696,8 +791,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
             const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
             sSlot[t] = slot0 + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
             const float4 a = r->a, b = r->b;
-            sA[t] = a; sB[t] = b; sC[t] = c;
             sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
+#ifdef GSR_PRECISE_MATH
+            sA[t] = a; sB[t] = b; sC[t] = c;
+#else
+            sA[t] = make_float4(a.x, a.y, GSR_HA(a.z), GSR_HB(a.w)); sB[t] = make_float4(GSR_HC(b.x), b.y, b.z, b.w); sC[t] = c;
+#endif
         }
         __syncthreads();
         {
@@ -749,12 +848,32 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                     const gsr_f2 al = B.y * G;
                     // alpha >= 1/255 tested on the unclamped product (0.99 > 1/255: same truth value, as in the forward); the
                     // clamp of backward.cu:524 is applied only in iterations that blend something
-                    const unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
-                                                    __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
-                    const unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
-                                                    __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
+#ifdef GSR_PRECISE_MATH
+                    const float alpha_min = 1.0f / 255.0f;
+#else
+                    const float alpha_min = GSR_ALPHA_LO;  // candidates from the lower edge of the guard band on (settled below)
+#endif
+                    unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
+                                              __builtin_amdgcn_ballot_w64(al.x >= alpha_min);
+                    unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
+                                              __builtin_amdgcn_ballot_w64(al.y >= alpha_min);
                     GSR_COUNT_ADD(0, 1);
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
+#ifndef GSR_PRECISE_MATH
+                        const unsigned long long banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & okma;
+                        const unsigned long long bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & okmb;
+                        if ((banda | bandb) != 0ull) {  // rare: inside the guard band -> the reference's own expression decides (as in the forward)
+                            const GsrRec* r = rec + point_list[rg.x + p];
+                            const float4 ra = r->a;
+                            const float2 rb = *reinterpret_cast<const float2*>(&r->b);
+                            const float ey = ra.y - pyf;
+                            const bool ka = gsr_blends_exact(ra.z, ra.w, rb.x, rb.y, ra.x - pxf.x, ey);
+                            const bool kb = gsr_blends_exact(ra.z, ra.w, rb.x, rb.y, ra.x - pxf.y, ey);
+                            okma &= ~banda | __builtin_amdgcn_ballot_w64(ka);
+                            okmb &= ~bandb | __builtin_amdgcn_ballot_w64(kb);
+                            GSR_COUNT_ADD(7, 1);
+                        }
+#endif
                         GSR_COUNT_ADD(1, 1);
                         GSR_COUNT_ADD(2, __popcll(okma) + __popcll(okmb));
                         GSR_COUNT_ADD(3, (okma != 0ull) != (okmb != 0ull));  // only one 8x8 half of the strip blends
@@ -852,13 +971,20 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, hipStream_t stream)
+                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel, dim3(4 * T), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H,
-                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,
-                       gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,
-                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume);
+#define GSR_FWD_LAUNCH(TR)                                                                                                             \
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel<TR>, dim3(4 * T), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H, \
+                       gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
+                       gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
+                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume)
+#ifdef GSR_FWD_ORDER
+    if (!only_flagged) hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, 4 * T);
+#endif
+    if (inference) GSR_FWD_LAUNCH(false);
+    else GSR_FWD_LAUNCH(true);
+#undef GSR_FWD_LAUNCH
     return hipGetLastError();
 }
 

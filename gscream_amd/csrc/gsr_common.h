@@ -3,7 +3,8 @@
 // HBM layout (P Gaussians, T = gx*gy 16x16 tiles, N = W*H pixels, R instances):
 //
 //   geom  : rec[P]       64 B  one cache line per Gaussian, gathered by the blend kernels
-//                              a = {px, py, hA, hB}       b = {hC, opacity, depth, feature}
+//                              a = {px, py, conA, conB}   b = {conC, opacity, depth, feature}
+//                              the raw conic; the blend kernels scale it once per staged instance into
 //                              (hA,hB,hC) = -log2(e) * (conA/2, conB, conC/2): exponent of the Gaussian in
 //                              base 2 = dx (hA dx + hB dy) + hC dy^2, fed straight to v_exp_f32
 //                              c = {r, g, b, rect width}  d = {offset, x0|y0<<16, tile mask lo, hi}
@@ -195,14 +196,14 @@ hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
                             bool defer_tile_scan, hipStream_t stream);
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, hipStream_t stream);
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, const GsrGeom& geom, const GsrImage& image,
+                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, bool inference, hipStream_t stream);
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, bool inference, const GsrGeom& geom, const GsrImage& image,
                                 const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, hipStream_t stream);
+                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference, hipStream_t stream);
 hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
-                                 hipStream_t stream);
+                                 bool inference, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots,

@@ -212,13 +212,10 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         if (radius > 0) {
             float3 col = col_in;
             if (!colors_precomp) col = gsr_sh_to_rgb(idx, D, M, p, cam, shs, clamped);
-#ifdef GSR_PRECISE_MATH
+            // the RAW conic (round 4; both builds): the blend kernels scale it once per staged instance and need the raw
+            // values for the in-band re-check of the alpha = 1/255 decision (blend.hip, gsr_blends_exact)
             ra = make_float4(pix, piy, conx, cony);
             rb = make_float4(conz, op_in, viewz, feat_in);
-#else
-            ra = make_float4(pix, piy, conx * (-0.5f * GSR_LOG2E), cony * (-GSR_LOG2E));
-            rb = make_float4(conz * (-0.5f * GSR_LOG2E), op_in, viewz, feat_in);
-#endif
             rcc = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));
             rd = make_uint4(0u, (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
         }
@@ -234,14 +231,8 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         float3 col = col_in;
         if (!colors_precomp) col = gsr_sh_to_rgb(idx, D, M, p, cam, shs, clamped);
         GsrRec* r = rec + idx;
-        // quadratic form pre-scaled for the blend loops: log2(alpha/opacity) = dx (hA dx + hB dy) + hC dy^2
-#ifdef GSR_PRECISE_MATH  // parity build: the records keep the raw conic, the blend evaluates the reference's expression
         r->a = make_float4(pix, piy, conx, cony);
         r->b = make_float4(conz, op_in, viewz, feat_in);
-#else
-        r->a = make_float4(pix, piy, conx * (-0.5f * GSR_LOG2E), cony * (-GSR_LOG2E));
-        r->b = make_float4(conz * (-0.5f * GSR_LOG2E), op_in, viewz, feat_in);
-#endif
         r->c = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));  // .w = rectangle width
         r->d = make_uint4(0u, (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
     }

@@ -24,6 +24,8 @@ from . import _native
 
 _tuning = _native.Tuning()
 _tuning_ref = _native.ctypes.byref(_tuning)  # built once: the struct is mutated in place by set_tuning
+_tuning_inf = _native.Tuning(inference=1)     # the same knobs with `inference` set: forwards that no backward will follow
+_tuning_inf_ref = _native.ctypes.byref(_tuning_inf)
 _capacity_hint = {}  # per-device: (binning capacity, longest-list provision) for the next speculative forward
 _recent = {}         # per-device: (num_rendered, max_tile_count) of the last few forwards (training hops between views)
 _RECENT_FRAMES = 8
@@ -41,6 +43,8 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True):
     _tuning.disable_tile_cull = 0 if tile_cull else 1
     _tuning.disable_speculation = 0 if speculative else 1
     _tuning.disable_partial_sort = 0 if partial_sort else 1
+    _tuning_inf.disable_tile_cull, _tuning_inf.disable_speculation = _tuning.disable_tile_cull, _tuning.disable_speculation
+    _tuning_inf.disable_partial_sort = _tuning.disable_partial_sort
     _capacity_hint.clear()
     _recent.clear()
 
@@ -128,8 +132,9 @@ def _cam(rs, device):
     return (_f32c(rs.viewmatrix, device), _f32c(rs.projmatrix, device), _f32c(rs.campos, device))
 
 
-def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scales, rotations, cov3Ds_precomp, rs):
-    """The work of `_C.rasterize_gaussians` (DGR rasterize_points.cu:35-122)."""
+def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scales, rotations, cov3Ds_precomp, rs, inference=False):
+    """The work of `_C.rasterize_gaussians` (DGR rasterize_points.cu:35-122).  inference=True: no backward will follow
+    (gsr_tuning.inference) -- same images and radii, none of the state a backward would read."""
     lib = _native.load()
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
@@ -167,7 +172,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         pin = pins[idx] = (t, _native.ctypes.cast(t.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result)))
     res = pin[1]
     debug = 1 if rs.debug else 0
-    tuning = _tuning_ref
+    tuning = _tuning_inf_ref if inference else _tuning_ref
     common = (P, int(rs.sh_degree), M, W, H, means3D_c.data_ptr(), _p(scales_c), float(rs.scale_modifier),
               _p(rot_c), _p(opac_c), _p(unc_c), _p(sh_c), _p(cov_c), _p(colors_c), _p(view), _p(proj), _p(campos),
               float(rs.tanfovx), float(rs.tanfovy), 1 if rs.prefiltered else 0)
@@ -324,8 +329,32 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_unc.reshape(ctx.uncertainty_shape), g_scales, g_rot, g_cov, None)
 
 
+def _no_grad_needed(*tensors):
+    if not torch.is_grad_enabled():
+        return True
+    for t in tensors:
+        if t.requires_grad:
+            return False
+    return True
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, uncertainties, scales, rotations,
                         cov3Ds_precomp, raster_settings):
+    if _no_grad_needed(means3D, means2D, sh, colors_precomp, opacities, uncertainties, scales, rotations, cov3Ds_precomp):
+        # Evaluation (the reference renders under torch.no_grad() in its test / FPS loops, train.py:756-763,861-878): the
+        # inference forward, outside the autograd graph.  Debug snapshots as in the training path (DGR/__init__.py:87-95).
+        args = (means3D, sh, colors_precomp, opacities, uncertainties, scales, rotations, cov3Ds_precomp, raster_settings)
+        if raster_settings.debug:
+            saved = _snapshot(args)
+            try:
+                out = _forward_native(*args, inference=True)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _forward_native(*args, inference=True)
+        return out[1], out[2], out[3], out[4]
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, uncertainties, scales,
                                      rotations, cov3Ds_precomp, raster_settings)
 

@@ -69,7 +69,11 @@ typedef struct gsr_tuning {
                                   than 2048 entries are put in depth order only for their nearest <= 2048 instances first
                                   (the blend stops where the tile's pixels saturate); a tile whose pixels are still
                                   blending at the end of that prefix is sorted completely and blended again */
-    int32_t reserved[5];
+    int32_t inference; /* 1 = no backward will follow this forward (render under no_grad, the reference's eval loops
+                                  train.py:756-763,861-878): the forward writes no depth checkpoints, contributor counts,
+                                  per-tile traversal depths or gradient-slot offsets and clears no slot flags.  Images and
+                                  radii are bit-identical to the training forward; gsr_backward on that state is undefined */
+    int32_t reserved[4];
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */
@@ -82,6 +86,10 @@ typedef struct gsr_profile {
 } gsr_profile;
 
 const char* gsr_version(void);
+/* Integer version of this header's binary interface: bumped whenever an entry point's argument list, a struct layout or a
+ * workspace size formula changes incompatibly.  Bindings compare it with GSR_ABI_VERSION at load time. */
+#define GSR_ABI_VERSION 4
+int gsr_abi_version(void);
 const char* gsr_last_error(void);
 /* Number of visible HIP devices, or a negative gsr_status. */
 int gsr_device_count(void);

@@ -348,6 +348,52 @@ void gso_render_forward(int W, int H, const uint32_t *ranges, const uint32_t *po
         }
 }
 
+/* Diagnostic twin of gso_render_forward (same walk, forward.cu:493-554): how close did each pixel come to flipping one
+ * of the walk's three discontinuous decisions?  Used by tools/flip_report.py / full_size_oracle_check.py and bench.py's
+ * parity_check to CLASSIFY a build's outlier pixels (alpha = 1/255 flips vs T = 1e-4 flips).  Per pixel:
+ *   m_alpha = min over evaluated instances of |alpha * 255 - 1| (alpha unclamped: opacity * exp(power)), g_alpha = that Gaussian
+ *   m_T     = min over instances that reach the transmittance test of |test_T / 1e-4 - 1|,               g_T     = that Gaussian
+ *   m_pow   = min |power| over the instances walked (the `power > 0` skip, forward.cu:529)
+ * (1e30 / 0xffffffff where the pixel never reaches the test). */
+void gso_render_margins(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *means2D,
+                        const float *conic_opacity, float *m_alpha, uint32_t *g_alpha, float *m_T, uint32_t *g_T,
+                        float *m_pow, int nthreads)
+{
+    const int gx = (W + TILE - 1) / TILE;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / TILE) * gx + (px / TILE);
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            const float pixfx = (float)px, pixfy = (float)py;
+            float T = 1.0f, ma = 1e30f, mt = 1e30f, mp = 1e30f;
+            uint32_t ga = 0xffffffffu, gt = 0xffffffffu;
+            for (uint32_t k = r0; k < r1; k++) {
+                const uint32_t g = point_list[k];
+                float dx = means2D[2 * g] - pixfx, dy = means2D[2 * g + 1] - pixfy;
+                const float *co = conic_opacity + 4 * g;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (fabsf(power) < mp) mp = fabsf(power);
+                if (power > 0.0f) continue;
+                const float raw = co[3] * expf(power);
+                const float da = fabsf(raw * 255.0f - 1.0f);
+                if (da < ma) { ma = da; ga = g; }
+                float alpha = fminf(0.99f, raw);
+                if (alpha < 1.0f / 255.0f) continue;
+                float test_T = T * (1 - alpha);
+                const float dt = fabsf(test_T * 10000.0f - 1.0f);
+                if (dt < mt) { mt = dt; gt = g; }
+                if (test_T < 0.0001f) break;
+                T = test_T;
+            }
+            const size_t pid = (size_t)py * W + px;
+            m_alpha[pid] = ma; g_alpha[pid] = ga; m_T[pid] = mt; g_T[pid] = gt; m_pow[pid] = mp;
+        }
+}
+
 /* backward.cu:409-604 renderCUDA (bwd), restated per pixel.  Outputs are double accumulators
  * (P-sized, caller zero-fills): mean2D[2P] (x,y), conic[3P] (the .x,.y,.w slots of the
  * reference float4), opacity[P], colors[3P], depth[P], unc[P]. */

@@ -130,6 +130,20 @@ def forward(means3D, scales, rotations, opacities, uncertainties, *, W, H, tanfo
     return st
 
 
+def margins(st, nthreads=1):
+    """Per pixel, how close the forward walk came to flipping a decision (gso_render_margins): dict of m_alpha, g_alpha,
+    m_T, g_T, m_pow, each [H, W].  Diagnostic: classifies a build's outlier pixels into alpha = 1/255 and T = 1e-4 flips."""
+    L = lib()
+    W, H = st["W"], st["H"]
+    out = dict(m_alpha=np.zeros((H, W), np.float32), g_alpha=np.zeros((H, W), np.uint32), m_T=np.zeros((H, W), np.float32),
+               g_T=np.zeros((H, W), np.uint32), m_pow=np.zeros((H, W), np.float32))
+    L.gso_render_margins(ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32p), _p(st["point_list"], _u32p),
+                         _p(st["means2D"], _f32p), _p(st["conic_opacity"], _f32p), _p(out["m_alpha"], _f32p),
+                         _p(out["g_alpha"], _u32p), _p(out["m_T"], _f32p), _p(out["g_T"], _u32p), _p(out["m_pow"], _f32p),
+                         ctypes.c_int(nthreads))
+    return out
+
+
 def backward(st, means3D, scales, rotations, dL_dcolor, dL_ddepth, dL_dunc, *, tanfovx, tanfovy, viewmatrix,
              projmatrix, campos=None, scale_modifier=1.0, shs=None, sh_degree=0, nthreads=1):
     """Full backward (rasterizer_impl.cu:536-643) given the forward state `st`.  Returns the nine

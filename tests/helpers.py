@@ -180,3 +180,57 @@ def assert_grads_nearly_equal(a, b, keys=GRAD_KEYS, context=""):
         if k in a and k in b:
             rep = grad_report(a[k], b[k], tol=1e-4)
             assert rep["p999"] < 1e-4 and rep["max"] < 5e-3, f"{context} {k}: {rep}"
+
+
+# Decision bands used to CLASSIFY an outlier: the oracle's walk of that pixel came within this relative distance of the
+# alpha = 1/255 threshold (forward.cu:534) / the T = 1e-4 stop (forward.cu:537).  Far wider than any arithmetic difference
+# between two fp32 evaluations of the same expression (~1e-6), far narrower than where a random pixel lands.
+ALPHA_BAND, T_BAND = 1e-4, 1e-3
+
+
+def parity_report(got, st, ref=None, nthreads=1):
+    """Element-wise parity of HIP outputs `got` against the oracle state `st` (+ gradients `ref`), with every outlier
+    classified by the decision its pixel / Gaussian sits next to in the ORACLE's walk (oracle.margins):
+      alpha = only the alpha >= 1/255 test is within ALPHA_BAND, T = only the T < 1e-4 stop is within T_BAND, both, neither.
+    A gradient element (row = Gaussian) is classified by whether its Gaussian is the near-threshold instance of some pixel."""
+    from oracle import oracle as O
+    mg = O.margins(st, nthreads=nthreads)
+    near_a, near_t = mg["m_alpha"] < ALPHA_BAND, mg["m_T"] < T_BAND
+    H, W = near_a.shape
+    bad = np.zeros((H, W), bool)
+    out = {"px_gt_1e-4": 0, "max_abs": 0.0, "images": {}}
+    for k in ("out_color", "out_depth", "out_unc"):
+        d = np.abs(got[k].astype(np.float64) - st[k].astype(np.float64)).reshape(-1, H, W)
+        out["images"][k] = {"gt_1e-4": int((d > IMG_ABS_TOL).sum()), "max": float(d.max())}
+        out["max_abs"] = max(out["max_abs"], float(d.max()))
+        bad |= (d > IMG_ABS_TOL).any(axis=0)
+    out["px_gt_1e-4"] = int(bad.sum())
+    out["px_by_cause"] = {"alpha": int((bad & near_a & ~near_t).sum()), "T": int((bad & near_t & ~near_a).sum()),
+                          "both": int((bad & near_a & near_t).sum()), "neither": int((bad & ~near_a & ~near_t).sum())}
+    out["pixels_at_risk"] = {"alpha": int(near_a.sum()), "T": int(near_t.sum()), "power_sign(|power|<1e-6)": int((mg["m_pow"] < 1e-6).sum())}
+    out["n_contrib_differs"] = int((got["n_contrib"] != st["n_contrib"]).sum()) if "n_contrib" in got else None
+    if ref is not None:
+        P = st["radii"].shape[0]
+        ga = np.zeros(P, bool); gt = np.zeros(P, bool)
+        ga[mg["g_alpha"][near_a]] = True
+        gt[mg["g_T"][near_t]] = True
+        out["grad_elems_gt_1e-3"], out["worst_rel"], out["grads"] = 0, 0.0, {}
+        cause = {"alpha": 0, "T": 0, "both": 0, "neither": 0}
+        for k in GRAD_KEYS:
+            if k in ref and k in got:
+                g64 = np.asarray(got[k], np.float64)
+                r64 = np.asarray(ref[k], np.float64).reshape(g64.shape)
+                if r64.size == 0:
+                    continue
+                r = np.abs(g64 - r64) / (np.abs(r64) + 1e-3 * max(np.abs(r64).max(), 1e-30))
+                badrows = (r > GRAD_REL_TOL).reshape(P, -1)
+                nb = int(badrows.sum())
+                out["grads"][k] = {"n_bad": nb, "max": float(r.max()) if r.size else 0.0}
+                out["grad_elems_gt_1e-3"] += nb
+                out["worst_rel"] = max(out["worst_rel"], out["grads"][k]["max"])
+                per_row = badrows.sum(axis=1)
+                cause["alpha"] += int(per_row[ga & ~gt].sum()); cause["T"] += int(per_row[gt & ~ga].sum())
+                cause["both"] += int(per_row[ga & gt].sum()); cause["neither"] += int(per_row[~ga & ~gt].sum())
+        out["grad_elems_by_cause"] = cause
+    out["bands"] = {"alpha_rel": ALPHA_BAND, "T_rel": T_BAND}
+    return out

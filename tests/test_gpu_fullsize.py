@@ -271,9 +271,13 @@ def _full_size_report(lib, seed, P, W, H, use):
 def test_full_size_element_wise_parity(seed, P, W, H, use, build):
     """Direct element-wise parity at BASELINE's size: the OpenMP oracle does 1M Gaussians @1008x567 in about a second
     per pass on the GPU box's host cores.  Radii bit-exact for every Gaussian.
-    shipped build (v_exp_f32 / v_rcp_f32 / pre-scaled quadratic form): images within 1e-4 except threshold flips (a pair at
-      alpha = 1/255 or T = 1e-4 to the ulp), bounded at 1e-4 of the pixels and 5e-3 in size; gradients: 99.9th percentile
-      inside 1e-3 and at most 1e-4 of the elements outside it (measured: p99.9 ~ 6e-6, ~3e-6 of the elements).
+    shipped build (v_exp_f32 / v_rcp_f32 / pre-scaled quadratic form + the alpha = 1/255 GUARD BAND of round 4: a pair whose
+      alpha lies within 3e-5 relative of the threshold is decided by the reference's own expression, blend.hip): since round 4 it
+      is held to the PARITY build's bounds -- at most 4 pixels beyond 1e-4 per map and 12 gradient elements beyond 1e-3 per
+      family; every outlier is classified by the decision its pixel / Gaussian sits next to in the oracle's walk (alpha = 1/255
+      vs T = 1e-4: helpers.parity_report) and the two kinds are printed separately.  Measured with the band: 0 pixels on all
+      three configs (max 3.3e-5); gradient elements 11 / 3 / 1, of which alpha-type 0 / 1 / 0 (without the band: 60 / 18 / 11,
+      alpha-type 32 / 15 / 10).  What is left are T = 1e-4 flips: the transmittance is accumulated state and differs by ulps.
     parity build (libgsraster_precise.so: the reference's own expression, libm expf, IEEE division, no contraction): the
       north-star's bar on EVERY element -- see the assertion below for what is left at this size."""
     r = _full_size_report("libgsraster_precise.so" if build == "precise" else None, seed, P, W, H, use)
@@ -281,13 +285,14 @@ def test_full_size_element_wise_parity(seed, P, W, H, use, build):
     assert r["radii_equal"]
     print(f"\n[{build}] P={P} {W}x{H}: " + ", ".join(f"{k}: {v['gt_1e-4']} px > 1e-4 (max {v['max']:.2e})" for k, v in r["images"].items()))
     print(f"[{build}] gradients: " + ", ".join(f"{k}: {v['n_bad']} > 1e-3 (max {v['max']:.2e})" for k, v in r["grads"].items()))
-    if build == "precise":
-        for k, v in r["images"].items():
-            assert v["gt_1e-4"] <= PRECISE_MAX_PIXELS and v["max"] < 5e-3, (k, v)
-        for k, v in r["grads"].items():
-            assert v["n_bad"] <= PRECISE_MAX_GRAD_ELEMS and v["p999"] <= 1e-4, (k, v)
-        return
+    pc = r["parity_check"]
+    print(f"[{build}] by cause: pixels {pc['px_by_cause']}, gradient elements {pc['grad_elems_by_cause']}; pixels at risk {pc['pixels_at_risk']}")
+    # both builds, the same bounds (the shipped build since the guard band of round 4)
     for k, v in r["images"].items():
-        assert v["gt_1e-4"] <= 1e-4 * v["n"] and v["max"] < 5e-3, (k, v)
+        assert v["gt_1e-4"] <= PRECISE_MAX_PIXELS and v["max"] < 5e-3, (k, v)
     for k, v in r["grads"].items():
-        assert v["p999"] <= 1e-3 and v["n_bad"] <= 1e-4 * v["n"], (k, v)
+        assert v["n_bad"] <= PRECISE_MAX_GRAD_ELEMS and v["p999"] <= 1e-4, (k, v)
+    # alpha = 1/255 flips are what the guard band (shipped) / the reference expression (parity build) remove: a handful at most
+    # (the two expf implementations differ in the last ulp on a small fraction of arguments)
+    assert pc["px_by_cause"]["alpha"] + pc["px_by_cause"]["both"] <= PRECISE_MAX_PIXELS, pc
+    assert pc["grad_elems_by_cause"]["alpha"] + pc["grad_elems_by_cause"]["both"] <= PRECISE_MAX_GRAD_ELEMS, pc

@@ -315,12 +315,9 @@ def test_preprocess_outputs_are_bit_exact():
     rec = gv["rec_f32"].cpu().numpy()
     assert (got["radii"] == st["radii"]).all()
     assert np.array_equal(rec[vis, 0:2], st["means2D"][vis]), "pixel centres"
-    # the record stores the conic pre-scaled for v_exp_f32: (hA, hB, hC) = -log2(e) * (conA/2, conB, conC/2), one fp32
-    # multiply each, so the expected bits follow from the oracle's conic
-    L2E = np.float32(1.4426950408889634)
-    con = st["conic_opacity"][vis, :3]
-    exp_h = np.stack([con[:, 0] * (np.float32(-0.5) * L2E), con[:, 1] * (-L2E), con[:, 2] * (np.float32(-0.5) * L2E)], 1)
-    assert np.array_equal(rec[vis, 2:5], exp_h.astype(np.float32)), "conic (pre-scaled)"
+    # the record keeps the RAW conic (round 4: the blend kernels scale it per staged instance and re-check decisions inside
+    # the alpha = 1/255 guard band with the reference's own expression on it): bit-equal to the oracle's
+    assert np.array_equal(rec[vis, 2:5], st["conic_opacity"][vis, :3]), "conic"
     assert np.array_equal(rec[vis, 5], st["conic_opacity"][vis, 3]) and np.array_equal(rec[vis, 6], st["depths"][vis])
     assert np.array_equal(rec[vis, 7], st["unc"][vis]) and np.array_equal(rec[vis, 8:11], s["colors"][vis])
     tiles = gv["tiles"].cpu().numpy().astype(np.int64)
@@ -658,3 +655,34 @@ def test_one_absent_auxiliary_gradient_equals_zeros(absent):
             assert (a is None or not a.any()) and (b is None or not b.any())
         else:
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["slab", "long_lists_resume", "beyond_lds_tiles"])
+def test_inference_forward_is_bit_identical_to_the_training_forward(case):
+    """Rendering under torch.no_grad() (the reference's eval / FPS loops, train.py:756-763,861-878) takes the inference
+    forward (gsr_tuning.inference: no checkpoints, contributor counts, traversal depths, slot offsets): images and radii
+    must equal the training forward bit for bit -- also when quadrants run off a partially sorted prefix and resume from
+    the state they left (the one case in which the inference kernel stores per-pixel state)."""
+    import torch
+    if case == "slab":
+        s = S.scene_slab(5, 60_000, 504, 284)
+    elif case == "long_lists_resume":
+        s = S.scene_config1(seed=33, P=14_000, W=32, H=32, lateral=0.3)
+        s["scales"] *= np.float32(0.15)
+    else:
+        s = S.scene_slab(6, 40_000, 3200, 3200)
+    train = Hh.hip_run(s, S.upstream_grads(1, s["W"], s["H"]))  # inputs require grad -> the autograd node
+    from gscream_amd import GaussianRasterizer
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    rast = GaussianRasterizer(raster_settings=Hh.hip_settings(s))
+    kw = dict(means3D=t(s["means3D"]), means2D=torch.zeros(s["means3D"].shape, device="cuda"), opacities=t(s["opacities"]),
+              uncertainties=t(s["uncertainties"]), colors_precomp=t(s["colors"]), scales=t(s["scales"]), rotations=t(s["rotations"]))
+    leaf = kw["means3D"].clone().requires_grad_(True)
+    with torch.no_grad():  # grad mode off, even with a leaf that requires grad
+        c0, d0, u0, r0 = rast(**dict(kw, means3D=leaf))
+    c1, d1, u1, r1 = rast(**kw)  # grad mode on, nothing requires grad
+    assert not c0.requires_grad and not c1.requires_grad
+    for (c, d, u, r) in ((c0, d0, u0, r0), (c1, d1, u1, r1)):
+        assert np.array_equal(c.cpu().numpy(), train["out_color"]) and np.array_equal(d.cpu().numpy(), train["out_depth"])
+        assert np.array_equal(u.cpu().numpy(), train["out_unc"]) and np.array_equal(r.cpu().numpy(), train["radii"])

@@ -21,6 +21,28 @@ def test_library_exports_every_declared_symbol(native_lib):
     for sym in declared:
         assert hasattr(native_lib, sym), sym
     assert native_lib.gsr_version().startswith(b"gsraster")
+    # the integer ABI version of the header == the library's == the binding's (a stale .so fails at load time, not in a kernel)
+    m = re.search(r"#define\s+GSR_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "gsraster.h")).read())
+    assert m and int(m.group(1)) == native_lib.gsr_abi_version() == _native.ABI_VERSION
+
+
+def test_tuning_struct_layout_and_the_inference_twin():
+    """gsr_tuning keeps its 32 bytes (the `inference` field took a reserved word); set_tuning keeps the inference twin of the
+    knobs in step; a forward whose inputs need no gradient is routed outside the autograd node."""
+    import ctypes
+    from gscream_amd import _native, rasterizer as RZ
+    assert ctypes.sizeof(_native.Tuning) == 32 and _native.Tuning.inference.offset == 12
+    RZ.set_tuning(tile_cull=False, partial_sort=False)
+    try:
+        assert RZ._tuning_inf.inference == 1 and RZ._tuning.inference == 0
+        assert RZ._tuning_inf.disable_tile_cull == 1 and RZ._tuning_inf.disable_partial_sort == 1
+    finally:
+        RZ.set_tuning()
+    assert RZ._tuning_inf.disable_tile_cull == 0
+    a, b = torch.zeros(3, 3), torch.zeros(3, 3, requires_grad=True)
+    assert RZ._no_grad_needed(a, a) and not RZ._no_grad_needed(a, b)
+    with torch.no_grad():
+        assert RZ._no_grad_needed(a, b)
 
 
 def test_workspace_sizes(native_lib):

@@ -26,8 +26,9 @@ lib.gsr_debug_counters(buf, 1)
 sb.step()
 torch.cuda.synchronize()
 lib.gsr_debug_counters(buf, 0)
-it, bl, px, half, fit, fbl, fpx = [int(buf[i]) for i in range(7)]
+it, bl, px, half, fit, fbl, fpx, band = [int(buf[i]) for i in range(8)]
 print(f"{wl}: backward (instance, 16x8 strip) iterations {it}, blending {bl} ({bl / max(it, 1):.3f}), blending pixels per blending iteration "
       f"{px / max(bl, 1):.1f} of 128 ({px / max(bl, 1) / 128:.3f}), single-half iterations {half} ({half / max(bl, 1):.3f})")
 print(f"{wl}: forward pair iterations {fit} (= {2 * fit} instance slots), blending instances {fbl} ({fbl / max(2 * fit, 1):.3f}), "
       f"blending pixels per blending instance {fpx / max(fbl, 1):.1f} of 64")
+print(f"{wl}: guard-band re-checks (wave-level, forward + backward of one iteration) {band} = {band / max(2 * fit + it, 1):.2e} of the evaluated (wave, instance) slots")
