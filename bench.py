@@ -413,7 +413,13 @@ def pipeline_row(dev, W=1008, H=567, N=200_000, K=10):
     ms = e0.elapsed_time(e1) / n
     kms, _top = gpu_kernel_ms(step, 5)  # GPU kernel time of the same iteration: what is left of the row is the GPU waiting for the host
     return {"what": f"decode ({N} anchors x {K}) -> rasterize {M} Gaussians @ {W}x{H} -> fused L1+SSIM loss -> backward to the MLP weights, all on the HIP rows",
-            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1), "gpu_kernel_ms_sum": None if kms is None else round(kms, 3)}
+            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1), "gpu_kernel_ms_sum": None if kms is None else round(kms, 3),
+            "roofline": (lambda alg: {"bound": "hbm", "algorithmic_GB": round(alg / 1e9, 4), "achieved": round(alg / 1e9 / (ms / 1e3), 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "note": "rasterizer 420 P + 304 R + 56 N at this scene's P and R + decode (41 + 3K floats per anchor in, 15 per "
+                                              "Gaussian out, mirrored in the backward) + RGB loss 44 B per pixel-channel"})(
+                420 * M + 304 * (_last_num_rendered() or 0) + 56 * W * H + 2 * (N * (41 + 3 * K) * 4 + M * 15 * 4) + 3 * W * H * 44),
+            "cpu_baseline": "see train_iteration.cpu_baseline (the same chain of CPU oracles plus the depth loss and the statistics)"}
 
 
 def gpu_kernel_ms(fn, iters):
@@ -442,7 +448,46 @@ def gpu_kernel_ms(fn, iters):
         return None, None
 
 
-def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0):
+def train_iteration_cpu_baseline(model, cam_np, vis, W, H, tfx, tfy, gt, midas, rgb_w, valid, fg_mask):
+    """The same training iteration on the host cores, restated with the CPU oracles chained the way train.py chains the
+    reference's pieces: float64 decode (oracle/decode_oracle.py, torch autograd on CPU) -> C oracle rasterizer forward ->
+    loss oracle (values + image gradients) -> C oracle backward -> autograd back to the model parameters.  ONE iteration
+    (a bounded sample: the whole thing is ~10-30 s of CPU work on this scene)."""
+    import copy
+    import helpers as Hh
+    from oracle import decode_oracle as DO
+    from oracle import loss_oracle as LO
+    from oracle import oracle as O
+    view, proj, campos = cam_np
+    threads = max(1, min(O.max_threads(), os.cpu_count() or 1, 64))
+    ref = copy.deepcopy(model).cpu().double()
+    ref.train()
+    t0 = time.perf_counter()
+    out = DO.generate_neural_gaussians(DO.Camera(torch.from_numpy(campos).double()), ref, vis.cpu(), True)
+    xyz, color, opacity, unc, scaling, rot = out[:6]
+    f = lambda t: np.ascontiguousarray(t.detach().float().numpy())  # noqa: E731
+    scene = dict(means3D=f(xyz), colors=f(color), opacities=f(opacity), uncertainties=f(unc), scales=f(scaling), rotations=f(rot),
+                 W=W, H=H, tanfovx=tfx, tanfovy=tfy, viewmatrix=view, projmatrix=proj, campos=campos,
+                 bg=np.zeros(3, np.float32), scale_modifier=1.0)
+    st = Hh.oracle_forward(scene, nthreads=threads)
+    img = torch.from_numpy(st["out_color"]).double().requires_grad_(True)
+    dep = torch.from_numpy(st["out_depth"]).double().requires_grad_(True)
+    c = lambda t: t.detach().cpu().double()  # noqa: E731
+    loss = LO.rgb_loss(img, c(gt), c(rgb_w), 0.2, 1.0) + LO.depth_loss(dep, c(midas), c(valid), None, None, 1.0, 1.0, c(fg_mask), 99.0)[0]
+    g_img, g_dep = torch.autograd.grad(loss, [img, dep])
+    grads = (g_img.float().numpy(), g_dep.float().numpy(), np.zeros((1, H, W), np.float32))
+    ref_g = Hh.oracle_backward(scene, st, grads, nthreads=threads)
+    tg = lambda k, like: torch.from_numpy(np.asarray(ref_g[k], np.float64).reshape(like.shape))  # noqa: E731
+    torch.autograd.backward([xyz, color, opacity, scaling, rot],
+                            [tg("dL_dmeans3D", xyz), tg("dL_dcolors", color), tg("dL_dopacity", opacity), tg("dL_dscales", scaling),
+                             tg("dL_drotations", rot)])
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"ONE iteration of the chained CPU oracles (float64 torch decode of {int(vis.sum())} visible anchors -> oracle/gs_oracle.c "
+                      f"fwd, R={st['num_rendered']} -> loss oracle -> gs_oracle.c bwd -> autograd to the model parameters): {dt:.1f} s"}
+
+
+def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0, with_cpu=False):
     """One complete training iteration of the renderer as train.py runs it on the reference view (train.py:433 anchor
     prefilter -> :527 render with the visible mask -> :535-561 RGB loss incl. the foreground term and the depth loss with
     its foreground term -> :575 backward -> :597-602 training_statis), minus the optimiser step, every piece on the HIP rows."""
@@ -514,7 +559,25 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     kms, top = gpu_kernel_ms(step, 5)
-    return {"what": f"train iteration on the HIP rows: prefilter_position2D ({N} anchors) -> decode the visible anchors ({sizes.get('visible_anchors')} x {K} "
+    # SURVEY 8(d)-style algorithmic bytes of the iteration: the rasterizer's 420 P + 304 R + 56 N at this scene's P and R, the
+    # decode (per visible anchor 41 + 3K floats in, per emitted Gaussian 15 floats out; the same again, mirrored, in the backward),
+    # the RGB loss (44 B per pixel-channel + the weight map) and the depth loss (5 planes in + 1 out, forward and backward)
+    Pg, R_it, Nv = sizes.get("gaussians", 0), _last_num_rendered() or 0, sizes.get("visible_anchors", 0)
+    alg = {"rasterizer": 420 * Pg + 304 * R_it + 56 * W * H, "decode": 2 * (Nv * (41 + 3 * K) * 4 + Pg * 15 * 4),
+           "rgb_loss": 3 * W * H * 44 + 2 * W * H * 4, "depth_loss": 2 * 6 * W * H * 4}
+    roof = {"bound": "hbm", "algorithmic_GB": {k: round(v / 1e9, 4) for k, v in alg.items()},
+            "achieved": round(sum(alg.values()) / 1e9 / (ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(sum(alg.values()) / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": None,
+            "note": "whole iteration (all kernels of all rows) against the HBM peak; the decode is matrix-core work (its own row has the MFMA roofline)"}
+    cpu = None
+    if with_cpu:
+        try:
+            cpu = train_iteration_cpu_baseline(model, (view, proj, campos), GR.prefilter_position2D(cam, model, Pipe, bg)[0], W, H, tfx, tfy,
+                                               gt, midas, rgb_w, valid, fg_mask)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)}
+    return {"roofline": roof, "cpu_baseline": cpu,
+            "what": f"train iteration on the HIP rows: prefilter_position2D ({N} anchors) -> decode the visible anchors ({sizes.get('visible_anchors')} x {K} "
                     f"-> {sizes.get('gaussians')} Gaussians) -> rasterize @ {W}x{H} -> RGB loss (fg-weighted L1 + SSIM) + depth loss (fit, L1 incl. the "
                     "foreground term, 4-scale gradient loss) -> backward to the MLP weights / anchor parameters -> training_statis; no optimiser step",
             "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1),
@@ -522,7 +585,7 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
             "host_ms_note": "wall time of the Python loop until the last iteration is enqueued (it contains the two host syncs a training iteration has: "
                             "the decode's row count and the rasterizer's num_rendered)",
             "gpu_kernel_ms_sum": None if kms is None else round(kms, 3), "gpu_top_kernels_us": top,
-            "log_scale_shift": float(log_scale_shift), "num_rendered": _last_num_rendered()}
+            "log_scale_shift": float(log_scale_shift), "num_rendered": _last_num_rendered(), "num_occluded": _last_num_occluded()}
 
 
 def render_fps_row(dev, sb, N=200_000, K=10):
@@ -614,6 +677,14 @@ def render_fps_row(dev, sb, N=200_000, K=10):
         "latency_ms_per_frame_reference_style": round(latency(view_eval), 4)}
     out["fps_definition"] = "fps = frames / GPU time of back-to-back frames (HIP events); latency_* = the reference's per-view wall clock between two device synchronisations (train.py:756-763)"
     return out
+
+
+def _last_num_occluded():
+    try:
+        from gscream_amd import rasterizer as RZ
+        return int(RZ._last_stage1.get("num_occluded", 0))
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def _last_num_rendered():
@@ -907,6 +978,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows (loss, knn) reported beside the north-star line")
     ap.add_argument("--no-tile-cull", action="store_true", help="bin every rectangle tile like the reference")
+    ap.add_argument("--scatter-bands", type=int, default=0, help="force the scatter launch to N bands of tile rows per chunk (0 = automatic)")
+    ap.add_argument("--occlusion", type=int, default=-1, help="occlusion cut-off: -1 automatic (default), 0 off, 1 on")
     ap.add_argument("--no-strict-parity", action="store_true", help="skip the strict_parity_build leg (the parity build on the same workload)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for the barriers (nccl == RCCL)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -932,7 +1005,7 @@ def main():
 
     from gscream_amd import _native, set_tuning
     _native.load()
-    set_tuning(tile_cull=not args.no_tile_cull)
+    set_tuning(tile_cull=not args.no_tile_cull, scatter_bands=args.scatter_bands, occlusion_cut=None if args.occlusion < 0 else bool(args.occlusion))
 
     if args.workload == "config5":
         run_config5(args, dist, dev, rank, world)
@@ -983,10 +1056,10 @@ def main():
     from gscream_amd import rasterizer as RZ
     R = RZ._last_stage1["num_rendered"]
     with torch.no_grad():
-        set_tuning(tile_cull=False)
+        set_tuning(tile_cull=False, scatter_bands=args.scatter_bands, occlusion_cut=False)
         e = torch.Tensor([])
         R_ref = RZ._forward_native(means3D, e, colors, opac, unc, scales, rots, e, rs)[0]
-        set_tuning(tile_cull=not args.no_tile_cull)
+        set_tuning(tile_cull=not args.no_tile_cull, scatter_bands=args.scatter_bands, occlusion_cut=None if args.occlusion < 0 else bool(args.occlusion))
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     visible = int((radii > 0).sum())
 
@@ -1061,7 +1134,7 @@ def main():
                     ("depth_loss", lambda: depth_loss_row(dev, H, W, not args.no_cpu_baseline)),
                     ("neural_gaussian_decode", lambda: decode_row(dev, not args.no_cpu_baseline)),
                     ("pipeline_decode_raster_loss", lambda: pipeline_row(dev)),
-                    ("train_iteration", lambda: train_iteration_row(dev)),
+                    ("train_iteration", lambda: train_iteration_row(dev, with_cpu=not args.no_cpu_baseline)),
                     ("render_fps", lambda: render_fps_row(dev, sb)),
                     ("simple_knn", lambda: knn_row(dev, not args.no_cpu_baseline)))
             out["next_rows"] = {}

@@ -35,6 +35,9 @@ def geom_views(buf, P):
     return {k: v[:P] for k, v in out.items()}
 
 
+OCC_BUCKETS = 160
+
+
 def image_views(buf, P, W, H):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T, N = max(gx * gy, 1), max(W * H, 1)
@@ -53,6 +56,11 @@ def image_views(buf, P, W, H):
     out["ckpt"] = _take(buf, off, CKPT_PLANES * Np * 4, torch.float32, (SEG_MAX, 6 * Np)); off += _align(CKPT_PLANES * Np * 4)
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
     out["qresume"] = _take(buf, off, 4 * T * 4, torch.int32, (4 * T,)); off += _align(4 * T * 4)
+    nocc = 8 * T * OCC_BUCKETS if T <= 8192 else 1   # occlusion cut-off (gsr_common.h: occ_mass x 8 XCD copies, occ_cut, occ_drop)
+    out["occ_mass"] = _take(buf, off, nocc * 4, torch.int32, (nocc,)); off += _align(nocc * 4)
+    out["occ_cut"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
+    out["occ_drop"] = _take(buf, off, 256 * 4, torch.int32, (256,)); off += _align(256 * 4)
+    out["tile_group"] = _take(buf, off, (T // 64 + 1) * 4, torch.int32, (T // 64 + 1,)); off += _align((T // 64 + 1) * 4)
     return out
 
 
@@ -62,6 +70,9 @@ def binning_views(buf, R, capacity=None):
     off = 0
     out = {}
     out["seg_keys"] = _take(buf, off, r * 8, torch.int64, (r,))[:R]; off += _align(r * 8)
-    out["point_list"] = _take(buf, off, r * 4, torch.int32, (r,))[:R]; off += _align(r * 4)
+    raw = _take(buf, off, r * 4, torch.int32, (r,))[:R]; off += _align(r * 4)
+    out["point_list_raw"] = raw
+    out["point_list"] = raw & 0x7fffffff   # Gaussian ids; bit 31 of an entry = the forward met it inside the alpha = 1/255 guard band
+    out["band_flag"] = raw < 0
     out["slot_written"] = _take(buf, off, r, torch.uint8, (r,))[:R]; off += _align(r)
     return out

@@ -27,12 +27,13 @@ ABI_VERSION = 4  # include/gsraster.h GSR_ABI_VERSION this binding was written a
 
 class Stage1Result(ctypes.Structure):
     _fields_ = [("num_rendered", ctypes.c_int32), ("max_tile_count", ctypes.c_int32),
-                ("num_slots", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("num_slots", ctypes.c_int32), ("num_occluded", ctypes.c_int32)]
 
 
 class Tuning(ctypes.Structure):
     _fields_ = [("disable_tile_cull", ctypes.c_int32), ("disable_speculation", ctypes.c_int32),
-                ("disable_partial_sort", ctypes.c_int32), ("inference", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                ("disable_partial_sort", ctypes.c_int32), ("inference", ctypes.c_int32), ("scatter_bands", ctypes.c_int32),
+                ("occlusion_cut", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
 
 
 class Profile(ctypes.Structure):

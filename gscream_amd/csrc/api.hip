@@ -124,6 +124,15 @@ extern "C" size_t gsr_backward_scratch_bytes(int P, int num_slots)
            gsr_align(((size_t)(P > 0 ? P : 1) / 64 + 18) * sizeof(uint32_t));
 }
 
+static bool gsr_partial_sort(const gsr_tuning* tuning) { return !(tuning && tuning->disable_partial_sort); }
+static bool gsr_inference(const gsr_tuning* tuning) { return tuning && tuning->inference; }
+static int gsr_forced_bands(const gsr_tuning* tuning) { return tuning ? tuning->scatter_bands : 0; }
+// the occlusion cut-off works on the tile-cull masks and keeps its table in LDS beside the histogram
+static bool gsr_occlusion(const gsr_tuning* tuning, int T)
+{
+    return tuning && tuning->occlusion_cut && !tuning->disable_tile_cull && T <= GSR_OCC_MAX_TILES;
+}
+
 static int gsr_make_cam(GsrCam& cam, int W, int H, const float* view_d, const float* proj_d, const float* campos_d,
                         float tan_fovx, float tan_fovy, float scale_modifier, hipStream_t stream)
 {
@@ -252,9 +261,11 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const int T = cam.gx * cam.gy;
+    const bool occlusion = gsr_occlusion(tuning, T);
+    if (occlusion) GSR_HIP(hipMemsetAsync(image.occ_mass, 0, (size_t)GSR_OCC_COPIES * T * GSR_OCC_BUCKETS * sizeof(uint32_t), stream), "clear occlusion masses");
     GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(0, P, D, M, cam, means3D, scales, rotations, opacities, features, shs,
                                     cov3D_precomp, colors_precomp, &geom, radii, nullptr, nullptr,
-                                    !(tuning && tuning->disable_tile_cull), stream),
+                                    !(tuning && tuning->disable_tile_cull), occlusion ? image.occ_mass : nullptr, stream),
               "preprocess");
     // {R, longest list} reach the host through a pinned, device-mapped word pair the scan kernel stores into (one per
     // host thread and device, 8 bytes, kept for the life of the thread): no copy kernel between the scan and the scatter.
@@ -262,7 +273,7 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
     rc = gsr_info_buffer(info_pinned, &mapped_dev);
     if (rc) return rc;
     if (info_mapped_dev) *info_mapped_dev = mapped_dev;
-    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, defer_tile_scan, stream), "tile count / scans");
+    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, defer_tile_scan, occlusion, stream), "tile count / scans");
     return GSR_OK;
 }
 
@@ -272,6 +283,7 @@ static int gsr_publish_stage1(const uint32_t* info, gsr_stage1_result* out)
     out->num_rendered = (int32_t)info[0];
     out->max_tile_count = (int32_t)info[1];
     out->num_slots = (int32_t)info[0];  // one gradient slot per binned instance
+    out->num_occluded = (int32_t)info[2];
     return GSR_OK;
 }
 
@@ -299,7 +311,7 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
                             image_ws, radii, &info, nullptr, false, tuning, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
-    uint32_t got[2] = { info[0], info[1] };
+    uint32_t got[3] = { info[0], info[1], info[2] };
     return gsr_publish_stage1(got, result_host);
 }
 
@@ -322,10 +334,7 @@ static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_cou
     return GSR_OK;
 }
 
-static bool gsr_partial_sort(const gsr_tuning* tuning) { return !(tuning && tuning->disable_partial_sort); }
-static bool gsr_inference(const gsr_tuning* tuning) { return tuning && tuning->inference; }
-
-static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, bool inference, const float* background,
+static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, bool inference, int forced_bands, const float* background,
                               void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                               float* out_feature, int debug, hipStream_t stream)
 {
@@ -333,7 +342,7 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
-    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, false, nullptr, inference, stream), "scatter");
+    GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, capacity, forced_bands, false, nullptr, inference, false, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, inference, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
                                                             out_feature, capacity, max_tile_count, false, inference, stream),
@@ -375,9 +384,13 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     uint32_t* info_dev = nullptr;
     // The tile scan (ranges, R, longest list) is folded into the scatter kernel here: nobody needs R before stage 2 is
     // enqueued, and the one-block launch cost as much as the whole column scan.  The event therefore follows the scatter.
+    // the caller provisions the workspace with slack over what it expects (gsraster.h: "e.g. 1.25 x the previous frame's
+    // num_rendered"): the scatter's staging (and its bands, binning.hip) is sized for the expectation, not for the provision
+    const int expected_R = (int)(0.8 * (double)binning_capacity);
+    const bool fold_tile_scan = true;
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, &info, &info_dev, true, tuning, debug, stream);
+                            image_ws, radii, &info, &info_dev, fold_tile_scan, tuning, debug, stream);
     if (rc) return rc;
     const bool partial = gsr_partial_sort(tuning), inference = gsr_inference(tuning);
     // (speculative: the sort variants are chosen from the hint; with partial sorting the hint only sizes the LDS of the
@@ -388,7 +401,8 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         const GsrImage image = gsr_carve_image(image_ws, P, W, H);
         const GsrBinning bin = gsr_carve_binning(binning_ws, binning_capacity);
         const int hint = max_tile_count_hint > 0 ? max_tile_count_hint : -1;
-        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, true, info_dev, inference, stream), "scatter");
+        GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, binning_capacity, expected_R, gsr_forced_bands(tuning), true, info_dev, inference,
+                                                        gsr_occlusion(tuning, T), stream), "scatter");
         // (beyond the LDS tile limit stage 1 ran the stand-alone tile scan: the same words, written earlier)
         GSR_HIP(hipEventRecord(ev, stream), "record");
         // partial: lists beyond GSR_NEAR_CAP take the fixed-LDS prefix sort whatever the hint says
@@ -400,7 +414,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     }
     if (rc) return rc;
     GSR_HIP(hipEventSynchronize(ev), "read num_rendered");
-    uint32_t got[2] = { info[0], info[1] };
+    uint32_t got[3] = { info[0], info[1], info[2] };
     rc = gsr_publish_stage1(got, result_host);
     if (rc) return rc;
     // the guesses hold iff every list fitted the workspace AND the sort variants that were launched cover the longest list
@@ -426,7 +440,7 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     if (!background || !geom_ws || !image_ws || !binning_ws || !out_color || !out_depth || !out_feature)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
-    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), gsr_inference(tuning), background, geom_ws, image_ws, binning_ws,
+    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), gsr_inference(tuning), gsr_forced_bands(tuning), background, geom_ws, image_ws, binning_ws,
                               out_color, out_depth, out_feature, debug, stream);
 }
 
@@ -515,7 +529,7 @@ extern "C" int gsr_filter(int P, int W, int H, const float* means3D, const float
     int rc = gsr_make_cam(cam, W, H, viewmatrix, projmatrix, nullptr, tan_fovx, tan_fovy, scale_modifier, stream);
     if (rc) return rc;
     GSR_STAGE(GSR_STAGE_PREPROCESS, gsr_launch_preprocess(px ? 2 : 1, P, 0, 0, cam, means3D, scales, rotations, nullptr, nullptr, nullptr,
-                                    cov3D_precomp, nullptr, nullptr, radii, px, py, 0, stream),
+                                    cov3D_precomp, nullptr, nullptr, radii, px, py, 0, nullptr, stream),
               "filter preprocess");
     return GSR_OK;
 }

@@ -29,19 +29,38 @@ __device__ __forceinline__ void gsr_chunk_bounds(int P, int nchunks, int chunk, 
 // GLOBAL = true: image with more tiles than one LDS allocation holds (> GSR_MAX_TILES_LDS, ~3000x3000 px): the
 // counters are the global tile_count[] (zeroed by the launcher), one agent-scope atomic per instance -- slow but
 // unbounded; no table is produced and the column scan is skipped.
-template <bool GLOBAL>
+// OCC (gsr_tuning.occlusion_cut): occ_cut[tile] = the last depth bucket whose instances can still blend in the tile
+// (gsr_occ_cut_kernel).  An instance behind it is not counted, and the Gaussian's survivor mask -- tmask[], the copy in its
+// record, its slot count tiles[] -- loses the bit, so that scatter, slot numbering and both backward kernels see the smaller
+// footprint without knowing why.  (Rectangle positions beyond 64 have no mask bit and stay.)
+struct GsrOcclusion {
+    const uint32_t* cut;        // [T]
+    const uint32_t* depthkey;   // [P]
+    u64* tmask_rw;              // [P]
+    uint32_t* tiles;            // [P]
+    GsrRec* rec;                // [P]
+    uint32_t* chunk_drop;       // [nchunks]
+};
+template <bool GLOBAL, bool OCC>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, int T, int gx, int nchunks,
                                                                         const uint2* __restrict__ rect,
                                                                         const u64* __restrict__ tmask,
                                                                         uint32_t* __restrict__ table,
-                                                                        uint32_t* __restrict__ chunk_sum)
+                                                                        uint32_t* __restrict__ chunk_sum, const GsrOcclusion oc)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist_lds[];
     uint32_t* hist = GLOBAL ? table /* = tile_count[T] */ : hist_lds;
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
+    __shared__ u64 drop_all[OCC ? GSR_HIST_THREADS : 1];
+    uint8_t* cutb = reinterpret_cast<uint8_t*>(hist_lds + T);  // OCC: the cut-off table, one byte per tile, behind the counters
     volatile uint32_t* heads = heads_all + (threadIdx.x & ~63u);
+    u64* drops = drop_all + (OCC ? (threadIdx.x & ~63u) : 0u);
+    uint32_t dropped = 0;
     if (!GLOBAL) {
-        for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0;
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            hist[t] = 0;
+            if (OCC) cutb[t] = (uint8_t)min(oc.cut[t], 255u);
+        }
         __syncthreads();
     }
     uint32_t mine = 0;
@@ -53,15 +72,38 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
         const int gb = gw + (int)(threadIdx.x & 63);
         uint2 rcs[U];
         u64 mks[U];
+        uint32_t bks[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
             rcs[k] = g < hi ? rect[g] : make_uint2(0u, 0u);
             mks[k] = g < hi ? tmask[g] : 0ull;
+            bks[k] = (OCC && g < hi) ? gsr_occ_bucket(oc.depthkey[g]) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < U; k++)
-            gsr_wave_for_each_instance(rcs[k], mks[k], 0u, heads, [&](int, int x, int y, uint32_t) { atomicAdd(&hist[y * gx + x], 1u); if (GLOBAL) mine++; });
+        for (int k = 0; k < U; k++) {
+            if (!OCC) {
+                gsr_wave_for_each_instance(rcs[k], mks[k], 0u, heads, [&](int, int x, int y, uint32_t) { atomicAdd(&hist[y * gx + x], 1u); if (GLOBAL) mine++; });
+            } else {
+                const int lane = (int)(threadIdx.x & 63u);
+                drops[lane] = 0ull;
+                gsr_wave_for_each_instance_t<true>(rcs[k], mks[k], bks[k], heads, [&](int owner, int x, int y, uint32_t obk, uint32_t pos) {
+                    const int t = y * gx + x;
+                    if (pos < 64u && obk > (uint32_t)cutb[t]) atomicOr(&drops[owner], 1ull << pos);  // behind the tile's cut-off: never binned
+                    else atomicAdd(&hist[t], 1u);
+                });
+                const u64 d = *reinterpret_cast<volatile u64*>(&drops[lane]);  // (wave-private LDS, program order: the atomics above are done)
+                if (d) {
+                    const int g = gb + k * blockDim.x;
+                    const u64 nm = mks[k] & ~d;
+                    oc.tmask_rw[g] = nm;
+                    oc.tiles[g] = gsr_rect_count(rcs[k], nm);
+                    uint2* rd = reinterpret_cast<uint2*>(&oc.rec[g].d.z);
+                    *rd = make_uint2((uint32_t)nm, (uint32_t)(nm >> 32));
+                    dropped += (uint32_t)__popcll(mks[k] & d);
+                }
+            }
+        }
     }
     __syncthreads();
     if (!GLOBAL) {
@@ -75,6 +117,38 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
     if ((threadIdx.x & 63) == 63) atomicAdd(&heads_all[0], mine);
     __syncthreads();
     if (threadIdx.x == 0) chunk_sum[blockIdx.x] = heads_all[0];
+    if (OCC) {  // instances this chunk dropped (reported to the caller: does the pass pay on this kind of frame?)
+        __syncthreads();
+        if (threadIdx.x == 0) heads_all[0] = 0u;
+        __syncthreads();
+        dropped = gsr_wave_scan_add(dropped);
+        if ((threadIdx.x & 63) == 63 && dropped) atomicAdd(&heads_all[0], dropped);
+        __syncthreads();
+        if (threadIdx.x == 0) oc.chunk_drop[blockIdx.x] = heads_all[0];
+    }
+}
+
+// Occlusion cut-off per tile: along the depth buckets, the first one at which the accumulated whole-tile masses say that every
+// pixel's transmittance is below 1e-4 (with a binade of margin): nothing behind that bucket can blend.  One wavefront per tile.
+__global__ void __launch_bounds__(256) gsr_occ_cut_kernel(int T, const uint32_t* __restrict__ mass, uint32_t* __restrict__ cut)
+{
+    const int tile = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    if (tile >= T) return;
+    const uint32_t thr = (uint32_t)((13.2877f + 1.0f) * GSR_OCC_FIXED);  // -log2(1e-4) + one binade
+    const uint32_t* m = mass + (size_t)tile * GSR_OCC_BUCKETS;
+    uint32_t run = 0, first = GSR_OCC_BUCKETS;
+    for (int b0 = 0; b0 < GSR_OCC_BUCKETS; b0 += 64) {
+        const int b = b0 + lane;
+        uint32_t v = 0u;
+        if (b < GSR_OCC_BUCKETS)
+#pragma unroll
+            for (int c = 0; c < GSR_OCC_COPIES; c++) v += m[(size_t)c * T * GSR_OCC_BUCKETS + b];  // the XCDs' copies
+        const uint32_t incl = gsr_wave_scan_add(v) + run;
+        const unsigned long long hit = __ballot(b < GSR_OCC_BUCKETS && incl >= thr);
+        if (hit) { first = (uint32_t)(b0 + __builtin_ctzll(hit)); break; }
+        run = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) cut[tile] = first;  // instances of buckets <= first stay; GSR_OCC_BUCKETS = no cut-off
 }
 
 // Column pass over table[nchunks][T]: for every tile, exclusive prefix over chunks (in place) and the
@@ -86,7 +160,8 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
 #define GSR_COLSCAN_TILES 64
 #endif
 __global__ void __launch_bounds__(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
-                                                                                    uint32_t* __restrict__ tile_count)
+                                                                                    uint32_t* __restrict__ tile_count,
+                                                                                    uint32_t* __restrict__ group_total)
 {
     __shared__ uint32_t part[GSR_COLSCAN_GROUPS][GSR_COLSCAN_TILES];
     const int tl = threadIdx.x % GSR_COLSCAN_TILES, grp = threadIdx.x / GSR_COLSCAN_TILES;
@@ -123,23 +198,47 @@ __global__ void __launch_bounds__(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS) gsr_ta
         }
         if (grp == 0) tile_count[tile] = total;
     }
+    // + the total of this workgroup's GSR_COLSCAN_TILES tiles (wave 0 = chunk group 0 holds one tile total per lane): lets a banded
+    // scatter workgroup find its band's first list position from T / 64 words instead of scanning all T tile totals
+    static_assert(GSR_COLSCAN_TILES == 64, "one wavefront per tile group");
+    if (grp == 0) {
+        const uint32_t incl = gsr_wave_scan_add(tile < T ? total : 0u);
+        if (tl == 63) group_total[blockIdx.x] = incl;
+    }
 }
 
 // Single block of 1024: exclusive scan of the tile totals -> ranges[t] = [start, end); info = {R, max count}.
-// Thread i owns ceil(T/1024) consecutive tiles; one DPP wave scan + 16 wave totals in LDS.
+// Thread i owns ceil(T/1024) consecutive tiles; one DPP wave scan + 16 wave totals in LDS.  The counts are loaded ONCE, all loads
+// in flight together (PER = compile-time bound on the tiles per thread): the first version read them in two dependent loops and
+// took 20 us at 8160 tiles -- a chain of memory round trips on a single workgroup (round 4: the banded scatter needs this kernel).
+// (PER = 0: no register copy, the counts are read again in the second loop -- images beyond the LDS tile limit, any T)
+template <int PER>
 __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                              uint2* __restrict__ ranges, uint32_t* __restrict__ info,
                                                              uint32_t* __restrict__ tile_work, uint32_t* __restrict__ sorted_len,
-                                                             uint32_t* __restrict__ need_full, uint32_t* __restrict__ info_host)
+                                                             uint32_t* __restrict__ need_full, uint32_t* __restrict__ info_host,
+                                                             const uint32_t* __restrict__ occ_drop, int ndrop)
 {
     __shared__ uint32_t wsum[16], wmax[16];
+    __shared__ uint32_t drop_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (T + 1023) / 1024, t0 = threadIdx.x * per;
+    if (threadIdx.x == 0) drop_total = 0u;
+    __syncthreads();
+    if (occ_drop && (int)threadIdx.x < ndrop) { const uint32_t d = occ_drop[threadIdx.x]; if (d) atomicAdd(&drop_total, d); }  // ndrop <= 256
+    const int per = (T + 1023) / 1024, t0 = threadIdx.x * per;  // per <= PER
+    uint32_t v[PER > 0 ? PER : 1];
     uint32_t sum = 0, mx = 0;
-    for (int i = 0; i < per; i++) {
-        const uint32_t v = t0 + i < T ? tile_count[t0 + i] : 0u;
-        sum += v;
-        mx = max(mx, v);
+    if (PER > 0) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) v[i] = (i < per && t0 + i < T) ? tile_count[t0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < PER; i++) { sum += v[i]; mx = max(mx, v[i]); }
+    } else {
+        for (int i = 0; i < per; i++) {
+            const uint32_t c = t0 + i < T ? tile_count[t0 + i] : 0u;
+            sum += c;
+            mx = max(mx, c);
+        }
     }
     const uint32_t incl = gsr_wave_scan_add(sum);
     mx = gsr_wave_scan_max(mx);
@@ -153,19 +252,24 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
         total += sw;
         gmax = max(gmax, wmax[w]);
     }
-    for (int i = 0; i < per; i++) {
-        if (t0 + i >= T) break;
-        const uint32_t v = tile_count[t0 + i];
-        ranges[t0 + i] = make_uint2(run, run + v);
-        tile_work[t0 + i] = 0u;  // the forward blend's quadrant wavefronts atomicMax their traversal depth into it
-        sorted_len[t0 + i] = v;  // fully sorted unless the partial sort of long lists says otherwise
-        need_full[t0 + i] = 0u;
-        run += v;
+    auto emit = [&](const int t, const uint32_t c) {
+        ranges[t] = make_uint2(run, run + c);
+        tile_work[t] = 0u;  // the forward blend's quadrant wavefronts atomicMax their traversal depth into it
+        sorted_len[t] = c;  // fully sorted unless the partial sort of long lists says otherwise
+        need_full[t] = 0u;
+        run += c;
+    };
+    if (PER > 0) {
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (i < per && t0 + i < T) emit(t0 + i, v[i]);
+    } else {
+        for (int i = 0; i < per && t0 + i < T; i++) emit(t0 + i, tile_count[t0 + i]);
     }
     if (threadIdx.x == 0) {
-        info[0] = total; info[1] = gmax;
+        info[0] = total; info[1] = gmax; info[2] = drop_total;  // (the barrier between the atomics and here: the scan's __syncthreads)
         // the host's copy, written straight into its pinned (device-mapped) buffer: no copy kernel in the stream
-        if (info_host) { info_host[0] = total; info_host[1] = gmax; }
+        if (info_host) { info_host[0] = total; info_host[1] = gmax; info_host[2] = drop_total; }
     }
 }
 
@@ -181,13 +285,15 @@ struct GsrFusedScan {
     const uint32_t* tile_count;  // null = not folded in: `ranges` was written by gsr_tile_scan_kernel
     uint2* ranges;
     uint32_t *info, *tile_work, *sorted_len, *need_full, *info_host;
+    const uint32_t* occ_drop;  // per-chunk counts of the occlusion cut-off's dropped instances (NULL = off): summed into info[2]
+    const uint32_t* tile_group;  // totals of the tile groups of GSR_COLSCAN_TILES tiles (column scan)
 };
 template <bool GLOBAL>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ depthkey, const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum,
     const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity, uint32_t stage_cap,
-    const GsrFusedScan fs)
+    const GsrFusedScan fs, int nbands, int gy)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor_lds[];
     uint32_t* cursor = GLOBAL ? const_cast<uint32_t*>(table) : cursor_lds;
@@ -199,7 +305,16 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // workgroup b runs on XCD b % 8: consecutive CHUNKS go to one XCD, so that the runs two neighbouring chunks write into a
     // tile segment (they share a 32-byte sector at their border) meet in the same L2
-    const int chunk = (nchunks & 7) == 0 ? (int)(blockIdx.x & 7u) * (nchunks >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // BANDED form (round 4; nbands > 1): images with so many tiles / instances that a chunk's keys do not fit the staging buffer
+    // (config 4: 8160 tiles x 12 B of cursors leave room for 5k keys, a chunk has 50k) wrote every key as a lone 32-byte sector
+    // (526 MB moved for 195 MB).  The launch then has nbands workgroups per chunk; workgroup (chunk, band) walks the chunk's
+    // Gaussians but emits only the instances of its band of tile rows: the per-tile arrays shrink nbands-fold, the band's share
+    // of the chunk fits the staging buffer, and the keys leave in runs again.  The (chunk, tile) table is unchanged.  All bands
+    // of a chunk run on the same XCD (the chunk's rect / mask / depth stream stays in that L2).
+    const int blk = (int)(blockIdx.x % (uint32_t)nchunks), band = (int)(blockIdx.x / (uint32_t)nchunks);
+    const int chunk = (nchunks & 7) == 0 ? (blk & 7) * (nchunks >> 3) + (blk >> 3) : blk;
+    const int by0 = GLOBAL ? 0 : (int)(((long long)band * gy) / nbands), by1 = GLOBAL ? gy : (int)(((long long)(band + 1) * gy) / nbands);
+    const int t_lo = by0 * gx, TB = GLOBAL ? T : (by1 - by0) * gx;  // this workgroup's tiles: [t_lo, t_lo + TB)
     // STAGED form (round 3).  Written straight to its tile segment, every 8-byte key costs a 32-byte sector write (86 MB of
     // write requests for 21 MB of keys; with the stores cut out the launch takes 24 instead of 38 us).  When the chunk's
     // instances fit the rest of the LDS they are first placed TILE-MAJOR in a staging buffer -- the chunk's own count per tile
@@ -208,14 +323,35 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     // runs (4.6 keys on the bench scene) instead of 64 lone sectors.  Which slot of its (chunk, tile) run a key gets is as
     // arbitrary as before; the per-tile sort does not care (keys are unique).
     //   dynamic LDS: cursor[T] | loff[T] | gbase[T] | keys[cap] (8 B) | tile[cap] (2 B)
-    uint32_t* loff = cursor_lds + T;
-    uint32_t* gbase = cursor_lds + 2 * (size_t)T;
-    u64* skey = reinterpret_cast<u64*>(cursor_lds + 3 * (size_t)T + ((3 * (size_t)T) & 1));
+    uint32_t* loff = cursor_lds + TB;
+    uint32_t* gbase = cursor_lds + 2 * (size_t)TB;
+    u64* skey = reinterpret_cast<u64*>(cursor_lds + 3 * (size_t)TB + ((3 * (size_t)TB) & 1));
     uint16_t* stile = reinterpret_cast<uint16_t*>(skey + stage_cap);
-    const uint32_t chunk_total = GLOBAL ? 0u : chunk_sum[chunk];
-    const bool staged = !GLOBAL && stage_cap > 0u && chunk_total <= stage_cap && T <= 65535;  // block-uniform
+    __shared__ uint32_t band_total;  // instances of this (chunk, band): known after the scan of the per-tile counts below
+    const bool may_stage = !GLOBAL && stage_cap > 0u && TB <= 65535;  // block-uniform
+    bool staged = false;
     const bool fused = !GLOBAL && fs.tile_count != nullptr;  // block-uniform
-    if (fused) {
+    if (fused && nbands > 1 && blockIdx.x != 0) {
+        // banded: only this band's tile starts are needed.  First list position of the band = the totals of the tile groups in front
+        // of it (T / 64 words from the column scan) + an exclusive scan over the tiles from the band's group boundary on.
+        const int g0 = t_lo / GSR_COLSCAN_TILES, ts = g0 * GSR_COLSCAN_TILES, n = t_lo + TB - ts;
+        uint32_t pv = 0u;
+        for (int g = threadIdx.x; g < g0; g += blockDim.x) pv += fs.tile_group[g];
+        const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x, t0 = ts + (int)threadIdx.x * per;
+        uint32_t sum = 0;
+        for (int i = 0; i < per; i++) sum += t0 + i < ts + n ? fs.tile_count[t0 + i] : 0u;
+        const uint32_t incl = gsr_wave_scan_add(sum), gincl = gsr_wave_scan_add(pv);
+        if (lane == 63) { wsum[wave] = incl; wsum4[0][wave] = gincl; }
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) run += (w < wave ? wsum[w] : 0u) + wsum4[0][w];
+        for (int i = 0; i < per; i++) {
+            if (t0 + i >= ts + n) break;
+            if (t0 + i >= t_lo) cursor[t0 + i - t_lo] = run;
+            run += fs.tile_count[t0 + i];
+        }
+        __syncthreads();
+    } else if (fused) {
         // tile starts = exclusive scan of the tile totals, left in cursor[] for the initialisation below (thread i owns
         // ceil(T / blockDim) consecutive tiles, like the staged scan further down)
         const int per = (T + (int)blockDim.x - 1) / (int)blockDim.x, t0 = (int)threadIdx.x * per;
@@ -239,7 +375,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         for (int i = 0; i < per; i++) {
             if (t0 + i >= T) break;
             const uint32_t v = fs.tile_count[t0 + i];
-            cursor[t0 + i] = run;
+            if (t0 + i >= t_lo && t0 + i < t_lo + TB) cursor[t0 + i - t_lo] = run;  // (this workgroup's band of tiles)
             if (blockIdx.x == 0) {  // what gsr_tile_scan_kernel writes
                 fs.ranges[t0 + i] = make_uint2(run, run + v);
                 fs.tile_work[t0 + i] = 0u;
@@ -248,9 +384,16 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             }
             run += v;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            fs.info[0] = total; fs.info[1] = gmax;
-            if (fs.info_host) { fs.info_host[0] = total; fs.info_host[1] = gmax; }
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) chunk_first = 0u;  // (borrowed: reset below before its real use)
+            __syncthreads();
+            if (fs.occ_drop && (int)threadIdx.x < nchunks) { const uint32_t d = fs.occ_drop[threadIdx.x]; if (d) atomicAdd(&chunk_first, d); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t dropped = chunk_first;
+                fs.info[0] = total; fs.info[1] = gmax; fs.info[2] = dropped;
+                if (fs.info_host) { fs.info_host[0] = total; fs.info_host[1] = gmax; fs.info_host[2] = dropped; }
+            }
         }
         __syncthreads();
     }
@@ -260,47 +403,50 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         const uint32_t* row = table + (size_t)chunk * T;
         const uint32_t* nrow = row + T;  // the next chunk's offsets (the last chunk ends at the tile's end)
         const bool last_chunk = chunk + 1 >= nchunks;
-        for (int t0 = threadIdx.x; t0 < T; t0 += blockDim.x * 8) {
+        for (int t0 = threadIdx.x; t0 < TB; t0 += blockDim.x * 8) {
             uint32_t a[8], b[8], c[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int t = t0 + k * (int)blockDim.x;
+                const int tl = t0 + k * (int)blockDim.x, t = t_lo + tl;  // local / global tile index
                 uint2 rg = make_uint2(0u, 0u);
-                if (t < T) {
-                    if (fused) { rg.x = cursor[t]; rg.y = rg.x + fs.tile_count[t]; }  // (read before the stores below overwrite it)
+                if (tl < TB) {
+                    if (fused) { rg.x = cursor[tl]; rg.y = rg.x + fs.tile_count[t]; }  // (read before the stores below overwrite it)
                     else rg = ranges[t];
                 }
                 a[k] = rg.x;
-                b[k] = t < T ? row[t] : 0u;
-                c[k] = !staged ? 0u : last_chunk ? rg.y - rg.x : (t < T ? nrow[t] : 0u);
+                b[k] = tl < TB ? row[t] : 0u;
+                c[k] = !may_stage ? 0u : last_chunk ? rg.y - rg.x : (tl < TB ? nrow[t] : 0u);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int t = t0 + k * (int)blockDim.x;
-                if (t < T) {
-                    if (staged) { gbase[t] = a[k] + b[k]; loff[t] = c[k] - b[k]; }  // loff: count for now, offset after the scan
-                    else cursor[t] = a[k] + b[k];
+                const int tl = t0 + k * (int)blockDim.x;
+                if (tl < TB) {
+                    if (may_stage) { gbase[tl] = a[k] + b[k]; loff[tl] = c[k] - b[k]; }  // loff: count for now, offset after the scan
+                    else cursor[tl] = a[k] + b[k];
                 }
             }
         }
     }
     if (threadIdx.x == 0) chunk_first = 0u;
     __syncthreads();
-    if (staged) {
-        // exclusive scan of the chunk's per-tile counts -> local offsets (thread i owns ceil(T / blockDim) consecutive tiles)
-        const int per = (T + (int)blockDim.x - 1) / (int)blockDim.x, t0 = (int)threadIdx.x * per;
+    if (may_stage) {
+        // exclusive scan of the (chunk, band)'s per-tile counts -> local offsets (thread i owns ceil(TB / blockDim) consecutive tiles);
+        // the total decides whether the keys fit the staging buffer
+        const int per = (TB + (int)blockDim.x - 1) / (int)blockDim.x, t0 = (int)threadIdx.x * per;
         uint32_t sum = 0;
-        for (int i = 0; i < per; i++) sum += t0 + i < T ? loff[t0 + i] : 0u;
+        for (int i = 0; i < per; i++) sum += t0 + i < TB ? loff[t0 + i] : 0u;
         const uint32_t incl = gsr_wave_scan_add(sum);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        uint32_t run = incl - sum;
-        for (int w = 0; w < wave; w++) run += wsum[w];
+        uint32_t run = incl - sum, tot = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { const uint32_t sw = wsum[w]; tot += sw; run += w < wave ? sw : 0u; }
+        if (threadIdx.x == 0) band_total = tot;
+        staged = tot <= stage_cap;  // block-uniform
         for (int i = 0; i < per; i++) {
-            if (t0 + i >= T) break;
+            if (t0 + i >= TB) break;
             const uint32_t v = loff[t0 + i];
             loff[t0 + i] = run;
-            cursor[t0 + i] = run;  // the staging cursor of the tile
+            cursor[t0 + i] = staged ? run : gbase[t0 + i];  // the staging cursor of the tile, or (too many keys) its global cursor
             run += v;
         }
         __syncthreads();
@@ -333,7 +479,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
         // offsets[] = exclusive scan of the per-Gaussian instance counts in index order: the Gaussian's first gradient slot
         // (blend backward, gauss_bwd).  Same count as the enumeration below by construction.  The four sub-trips' block scans
         // share ONE pair of barriers (wave totals of all four in LDS at once) instead of taking a pair each.
-        if (offsets) {  // (block-uniform; NULL = inference forward: nobody will ask for gradient slots)
+        if (offsets && band == 0) {  // (block-uniform; NULL = inference forward: nobody will ask for gradient slots)
             uint32_t cnt[U], incl[U];
 #pragma unroll
             for (int k = 0; k < U; k++) {
@@ -363,14 +509,26 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             // the instance's 64-bit sort key (depth bits, id) goes straight into its tile's segment: a scattered store
             // costs one 32-byte sector whether it carries 4 or 8 bytes, and the sort then reads its keys coalesced
             // instead of gathering 4-byte depths
-            gsr_wave_for_each_instance(rcs[k], mks[k], dks[k], heads, [&](int owner, int x, int y, uint32_t odk) {
-                const uint32_t slot = atomicAdd(&cursor[y * gx + x], 1u);
+            uint2 rcb = rcs[k];
+            u64 mkb = mks[k];
+            if (nbands > 1) {  // this band's rows of the rectangle; the survivor mask follows (positions >= 64 always survive)
+                const int ry0 = (int)(rcb.y & 0xffff), ry1 = (int)(rcb.y >> 16), rw = (int)(rcb.x >> 16) - (int)(rcb.x & 0xffff);
+                const int cy0 = max(ry0, by0), cy1 = min(ry1, by1);
+                if (cy0 >= cy1 || rw <= 0) { rcb = make_uint2(0u, 0u); mkb = 0ull; }
+                else {
+                    const long long sh = (long long)(cy0 - ry0) * rw;
+                    mkb = sh >= 64 ? ~0ull : sh == 0 ? mkb : ((mkb >> sh) | (~0ull << (64 - sh)));
+                    rcb.y = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
+                }
+            }
+            gsr_wave_for_each_instance(rcb, mkb, dks[k], heads, [&](int owner, int x, int y, uint32_t odk) {
+                const uint32_t slot = atomicAdd(&cursor[y * gx + x - t_lo], 1u);
 #ifdef GSR_SCATTER_NOSTORE  // diagnostic: everything but the key stores (are the 32-byte-sector writes what the kernel waits for?)
                 if (slot == 0xffffffffu) seg_keys[0] = odk;
 #else
                 const u64 key = ((u64)odk << 32) | (uint32_t)(g_lane0 + owner);
                 if (staged) {
-                    if (slot < stage_cap) { skey[slot] = key; stile[slot] = (uint16_t)(y * gx + x); }  // (always true: the counts are exact)
+                    if (slot < stage_cap) { skey[slot] = key; stile[slot] = (uint16_t)(y * gx + x - t_lo); }  // (always true: the counts are exact)
                 } else if (slot < capacity) seg_keys[slot] = key;  // capacity < R only in a speculative launch that is redone
 #endif
             });
@@ -378,6 +536,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     }
     if (staged) {
         __syncthreads();
+        const uint32_t chunk_total = band_total;
         for (uint32_t i = threadIdx.x; i < chunk_total; i += blockDim.x) {
             const uint32_t t = stile[i];
             const uint32_t dst = gbase[t] + (i - loff[t]);
@@ -809,7 +968,9 @@ static hipError_t gsr_allow_big_lds()
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1)) return hipSuccess;
     const int big = 160 * 1024 - 8192;  // static LDS: hist / scatter 2 KiB, tile sort 4.2 KiB (bucket offsets)
-    e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    // (the occlusion variant has 8 KiB more static LDS -- the per-lane dropped-tile masks -- and needs 5 B per tile up to GSR_OCC_MAX_TILES)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 17408);  // 16.9 KiB static: 4096 bucket offsets + scan scratch
     if (e == hipSuccess && dev >= 0 && dev < 64) done_mask |= 1ull << dev;
@@ -817,64 +978,110 @@ static hipError_t gsr_allow_big_lds()
 }
 
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
-                            bool defer_tile_scan, hipStream_t stream)
+                            bool defer_tile_scan, bool occlusion_cut, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
     hipError_t e;
+    const GsrOcclusion oc = { image.occ_cut, geom.depthkey, geom.tmask, geom.tiles, geom.rec, image.occ_drop };
     if (T > GSR_MAX_TILES_LDS) {
         // fallback for very large images: global counters (see gsr_tile_hist_kernel<true>)
         e = hipMemsetAsync(image.tile_count, 0, (size_t)T * 4, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gsr_tile_hist_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
-                           geom.rect, geom.tmask, image.tile_count, geom.scan_sums);
+        hipLaunchKernelGGL((gsr_tile_hist_kernel<true, false>), dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
+                           geom.rect, geom.tmask, image.tile_count, geom.scan_sums, oc);
     } else {
         // (1) per-chunk tile histogram -> table, per-chunk instance totals
         e = gsr_allow_big_lds();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gsr_tile_hist_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx,
-                           nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums);
+        if (occlusion_cut) {  // (api.hip enables it only up to GSR_OCC_MAX_TILES: the cut-off table sits behind the counters in LDS)
+            hipLaunchKernelGGL(gsr_occ_cut_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, T, image.occ_mass, image.occ_cut);
+            hipLaunchKernelGGL((gsr_tile_hist_kernel<false, true>), dim3(nchunks), dim3(GSR_HIST_THREADS), gsr_align((size_t)T * 5), stream, P, T, gx,
+                               nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums, oc);
+        } else
+        hipLaunchKernelGGL((gsr_tile_hist_kernel<false, false>), dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx,
+                           nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums, oc);
         // (2) column scan -> per-(chunk, tile) offsets + tile totals
         hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + GSR_COLSCAN_TILES - 1) / GSR_COLSCAN_TILES), dim3(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
-                           image.tile_count);
+                           image.tile_count, image.tile_group);
     }
     // (3) tile scan -> ranges, info.  The one-call forward folds it into the scatter kernel (gsr_launch_scatter with
     // fused_info_host): one launch less on the critical path; the host then learns R when the scatter has started.
     if (!(defer_tile_scan && T <= GSR_MAX_TILES_LDS))
-        hipLaunchKernelGGL(gsr_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges,
-                           image.info, image.tile_work, image.sorted_len, image.need_full, info_host_mapped);
+    {
+        const int per = (T + 1023) / 1024;
+#define GSR_TILE_SCAN(N)                                                                                                       \
+        hipLaunchKernelGGL(gsr_tile_scan_kernel<N>, dim3(1), dim3(1024), 0, stream, T, image.tile_count, image.ranges, image.info, \
+                           image.tile_work, image.sorted_len, image.need_full, info_host_mapped,                                   \
+                           occlusion_cut ? (const uint32_t*)image.occ_drop : (const uint32_t*)nullptr, nchunks)
+        if (per <= 4) GSR_TILE_SCAN(4);
+        else if (per <= 12) GSR_TILE_SCAN(12);
+        else if (per <= 36) GSR_TILE_SCAN(36);
+        else GSR_TILE_SCAN(0);  // (images beyond the LDS tile limit: <= 2^24 tiles)
+#undef GSR_TILE_SCAN
+    }
     return hipGetLastError();
 }
 
+// Bands of tile rows per chunk in the scatter launch (1 = the plain form).  More than one when a chunk's expected keys
+// (expected instances / chunks; = R, or what the speculative forward expects it to be) exceed what the LDS left beside the per-tile
+// arrays can stage: the smallest power of two whose average (chunk, band) share fits beside the band's own arrays.
+int gsr_scatter_bands(int P, int T, int gx, int expected_instances, int forced)
+{
+    if (T > GSR_MAX_TILES_LDS || T > 65535 * 8 || gx <= 0) return 1;
+    const int nchunks = gsr_num_chunks(P), gy = T / gx;
+    if (forced > 0) return forced < gy ? forced : (gy > 0 ? gy : 1);  // gsr_tuning.scatter_bands
+    const double per_chunk = (double)(expected_instances > 0 ? expected_instances : 0) / nchunks;
+    const size_t budget = 160 * 1024 - 8192 - 1024;
+    for (int nb = 1; nb <= 16 && nb <= gy; nb *= 2) {
+        const size_t tb = (size_t)((gy + nb - 1) / nb) * gx, fixed = gsr_align(tb * 12 + 8);
+        // (the AVERAGE share has to fit: a workgroup whose share does not takes the direct path on its own.  Measured at config 4,
+        // 2M Gaussians @1920x1080, scatter launch: 1 band 203 us, 2: 185, 4: 125, 8: 172, 16: 269 -- every band walks all the
+        // chunk's Gaussians again, so more bands than needed cost more than they save; config 2 with 2 forced bands: 34 -> 42 us)
+        if (budget > fixed + 4096 && per_chunk / nb <= (double)((budget - fixed) / 10)) return nb;
+    }
+    return 1;  // nothing fits (huge image): the plain form with its direct stores
+}
+
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, bool inference, hipStream_t stream)
+                              int capacity, int expected_instances, int forced_bands, bool fused_tile_scan, uint32_t* fused_info_host, bool inference,
+                              bool occlusion_cut, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
     uint32_t* const offsets = inference ? nullptr : geom.offsets;  // gradient-slot numbering: only a backward reads it
-    GsrFusedScan fs = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    const int gy = gx > 0 ? T / gx : 0;
+    const int nbands = gsr_scatter_bands(P, T, gx, expected_instances, forced_bands);
+    GsrFusedScan fs = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     if (fused_tile_scan && T <= GSR_MAX_TILES_LDS)
-        fs = GsrFusedScan{ image.tile_count, image.ranges, image.info, image.tile_work, image.sorted_len, image.need_full, fused_info_host };
+        fs = GsrFusedScan{ image.tile_count, image.ranges, image.info, image.tile_work, image.sorted_len, image.need_full, fused_info_host,
+                           occlusion_cut ? (const uint32_t*)image.occ_drop : (const uint32_t*)nullptr, image.tile_group };
     if (T > GSR_MAX_TILES_LDS) {
         hipLaunchKernelGGL(gsr_cursor_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, image.ranges, image.table);
         hipLaunchKernelGGL(gsr_scatter_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
                            geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
-                           bin.seg_keys, (uint32_t)capacity, 0u, fs);
+                           bin.seg_keys, (uint32_t)capacity, 0u, fs, 1, gy);
         return hipGetLastError();
     }
     hipError_t e = gsr_allow_big_lds();
     if (e != hipSuccess) return e;
-    // dynamic LDS: the three T-entry arrays + as much staging (10 B per instance) as the CU has left; a chunk with more
-    // instances than that takes the direct path inside the same launch
+    // dynamic LDS: the three per-tile arrays of the workgroup's band of tile rows + the staging buffer (10 B per instance).  Plain
+    // form: as much staging as the CU has left (a chunk with more instances takes the direct path inside the same launch).  Banded
+    // form: 1.3 x the expected (chunk, band) share -- a smaller footprint lets two workgroups share a CU.
     const size_t budget = 160 * 1024 - 8192 - 1024;  // static arrays of the kernel: ~4.3 KiB
-    const size_t fixed = gsr_align((size_t)T * 12 + 8);
+    const size_t tb = (size_t)((gy + nbands - 1) / nbands) * gx;
+    const size_t fixed = gsr_align(tb * 12 + 8);
     size_t stage_cap = budget > fixed + 4096 ? (budget - fixed) / 10 : 0;
+    if (nbands > 1) {
+        const size_t want = (size_t)(1.3 * (double)(expected_instances > 0 ? expected_instances : 0) / nchunks / nbands) + 256;
+        if (want < stage_cap) stage_cap = want;
+    }
     stage_cap &= ~(size_t)63;
 #ifdef GSR_SCATTER_NO_STAGING
     stage_cap = 0;
 #endif
-    const size_t lds = stage_cap ? fixed + stage_cap * 10 : (size_t)T * 4;
-    hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
+    const size_t lds = stage_cap ? fixed + stage_cap * 10 : tb * 4;
+    hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks * nbands), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
                        geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
-                       bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs);
+                       bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs, nbands, gy);
     return hipGetLastError();
 }
 

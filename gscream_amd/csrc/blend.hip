@@ -249,30 +249,9 @@ __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, si
 #define GSR_FWD_WAVES 0
 #endif
 #if GSR_FWD_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES)))
-#endif
-// -DGSR_FWD_ORDER (experiment, round 4): quadrant tasks are dispatched deepest-walk-first inside each XCD's band, the depth
-// being what the SAME quadrant walked in the previous forward (library-global buffers: an experiment, not product state).
-#ifdef GSR_FWD_ORDER
-__device__ uint32_t gsr_qdepth_hint[4 * 36864];
-__device__ uint32_t gsr_qorder[4 * 36864];
-__global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int NT)
-{
-    // band x of the NT quadrant tasks (gsr_tile_of_block's split); counting sort by depth / 8 (256 buckets), deepest first
-    __shared__ uint32_t hist[256], start[256];
-    const int x = blockIdx.x, q = NT >> 3, r = NT & 7;
-    const int first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, size = q + (x < r ? 1 : 0);
-    for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < size; i += 1024) atomicAdd(&hist[255 - min(gsr_qdepth_hint[first + i] >> 3, 255u)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 256; i++) { start[i] = run; run += hist[i]; } }
-    __syncthreads();
-    for (int i = threadIdx.x; i < size; i += 1024) {
-        const uint32_t b = 255 - min(gsr_qdepth_hint[first + i] >> 3, 255u);
-        gsr_qorder[first + atomicAdd(&start[b], 1u)] = (uint32_t)(first + i);
-    }
-}
+#define GSR_FWD_ATTR __attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES)))
+#else
+#define GSR_FWD_ATTR
 #endif
 
 // TRAIN = false: the inference forward (gsr_tuning.inference; render under no_grad): no depth checkpoints are stored (the sums
@@ -280,8 +259,8 @@ __global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int NT)
 // contributor and the running sums are stored only by a quadrant that ran off a partially sorted prefix (its resume state);
 // the tile's traversal depth is not recorded.  Same arithmetic in the same order: images bit-identical.
 template <bool TRAIN>
-__global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const GsrRec* __restrict__ rec, int W,
+__global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
+    const uint2* __restrict__ ranges, uint32_t* point_list /* bit 31 of an entry: guard-band flag, set here */, const GsrRec* __restrict__ rec, int W,
     int H, int gx, int T, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted,
@@ -292,11 +271,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     __shared__ float4 sC[GSR_FWB];
 
     GSR_TRACE_BEGIN
-#ifdef GSR_FWD_ORDER
-    const int u = only_flagged ? gsr_tile_of_block(blockIdx.x, 4 * T) : (int)gsr_qorder[gsr_tile_of_block(blockIdx.x, 4 * T)];
-#else
     const int u = gsr_tile_of_block(blockIdx.x, 4 * T);  // quadrant tasks in tile order, one contiguous band per XCD
-#endif
     const int tile = u >> 2, quad = u & 3;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
@@ -321,8 +296,11 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Uf = 0.f;
     uint32_t last = 0;
     int npass = 0;  // checkpoints passed (wave-uniform)
-    float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, A4 = 0.f;  // sums of the segments closed so far
-    const uint32_t* ids = point_list + rg.x;
+    // sums of the segments closed so far: touched once per 64 / 128 list positions, so they live in LDS (one word per lane and
+    // sum), not in five registers -- the walk loop stays at 6 waves per SIMD with the guard band's re-check in it (round 4)
+    __shared__ float sAcc[5][64];
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, A4 = 0.f;  // (prologue only: the resumed walk's sums before they go to sAcc)
+    uint32_t* ids = point_list + rg.x;  // entries: Gaussian id | (guard-band flag << 31)
     // Fix-up pass (the tile's list has been sorted completely since): a quadrant that ran off the sorted prefix at list
     // position m RESUMES there instead of starting over -- the first m entries of the complete order are the prefix it
     // walked, and what it left behind when it finished is its whole state: T (final_T), the last contributor and whether the
@@ -364,11 +342,12 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
 
+    sAcc[0][lane] = A0; sAcc[1][lane] = A1; sAcc[2][lane] = A2; sAcc[3][lane] = A3; sAcc[4][lane] = A4;  // (a lane reads only its own words)
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
     {
         const int cnt0 = min(GSR_FWB - (start & (GSR_FWB - 1)), n - start);  // batches end at multiples of 64 list positions
         if (lane < cnt0) {
-            const float4* r = reinterpret_cast<const float4*>(rec + ids[start + lane]);
+            const float4* r = reinterpret_cast<const float4*>(rec + (ids[start + lane] & 0x7fffffffu));
             a = r[0]; b = r[1]; c = r[2];
         }
     }
@@ -392,7 +371,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
                 gsr_ckpt_b(ckpt, npass, HW)[pid] = make_float2(Dp, Uf);
             }
             npass++;
-            A0 += C0; A1 += C1; A2 += C2; A3 += Dp; A4 += Uf;
+            sAcc[0][lane] += C0; sAcc[1][lane] += C1; sAcc[2][lane] += C2; sAcc[3][lane] += Dp; sAcc[4][lane] += Uf;
             C0 = 0.f; C1 = 0.f; C2 = 0.f; Dp = 0.f; Uf = 0.f;
         }
         cnt = min(GSR_FWB - (base & (GSR_FWB - 1)), n - base);
@@ -422,7 +401,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         {  // next batch's records: in flight during the blend loop
             const int i = base + cnt + lane;  // (the next batch is a full one, or the list's tail)
             if (i < n) {
-                const float4* r = reinterpret_cast<const float4*>(rec + ids[i]);
+                const float4* r = reinterpret_cast<const float4*>(rec + (ids[i] & 0x7fffffffu));
                 a = r[0]; b = r[1]; c = r[2];
             }
         }
@@ -451,9 +430,47 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
 #ifdef GSR_PRECISE_MATH
             const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= (1.0f / 255.0f));
             const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= (1.0f / 255.0f));
-#else       // candidates from the lower edge of the guard band on; blend() settles the ones inside the band exactly
-            const unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= GSR_ALPHA_LO);
-            const unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= GSR_ALPHA_LO);
+#else       // candidates from the lower edge of the guard band on; the ones inside the band are settled exactly, for BOTH instances of
+            // the pair in front of the first blend: one rarely taken branch per pair iteration whose compares issue with the others,
+            // instead of a compare -> scalar test -> branch in the dependency chain of every blend (a wave with its SIMD to itself,
+            // i.e. the second half of every launch, runs at the speed of that chain: per-blend checks cost the launch 9 %, this 2 %)
+            unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= GSR_ALPHA_LO);
+            unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= GSR_ALPHA_LO);
+            // (|alpha - 1/255| of both instances -> one minimum -> ONE compare whose result is branched on directly: the test adds
+            // three VALU instructions and no scalar logic to the chain in front of the blends)
+            const gsr_f2 dband = al - gsr_splat(1.0f / 255.0f);
+#ifdef GSR_NO_BAND  // diagnostic: the band test compiled out (what the check costs)
+            if (false) {
+#else
+            if (__builtin_amdgcn_ballot_w64(fminf(fabsf(dband.x), fabsf(dband.y)) < (1.0f / 255.0f) * GSR_BAND) != 0ull) {  // rare: inside the guard band
+#endif
+                const unsigned long long banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & cma;
+                const unsigned long long bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & cmb;
+                // -> the reference's own expression decides
+                auto settle = [&](const unsigned long long bandm, unsigned long long& cm, const int j) {
+                    if (bandm == 0ull) return;
+                    // (the list index as an opaque per-lane value, made scalar again INSIDE the branch: with a plain scalar use here the
+                    // compiler moves `j` -- and the whole {i_a, i_b, f_a, f_b} record -- to SGPRs with four v_readfirstlane in the hot
+                    // path and waits early for the next iteration's LDS reads (forward 86 -> 101 us); with per-lane loads the kernel
+                    // needs 88 VGPRs instead of 80: one wave per SIMD less)
+                    int jv = j;
+                    asm volatile("" : "+v"(jv));
+                    // The list entry is FLAGGED (bit 31): the backward, whose pixels are a subset of the ones that met this instance
+                    // here, runs its own band check only on flagged instances -- everywhere else alpha >= lower edge is the
+                    // decision (no pixel of the tile is inside the band) and the two compares per iteration are saved.
+                    const int pos = base + __builtin_amdgcn_readfirstlane(jv);
+                    const uint32_t gid = ids[pos] & 0x7fffffffu;
+                    if (lane == 0) ids[pos] = gid | 0x80000000u;  // (the four quadrant waves of a tile may all store this same word)
+                    const GsrRec* r = rec + gid;
+                    const float4 ra = r->a;
+                    const float2 rb = *reinterpret_cast<const float2*>(&r->b);
+                    const bool keep = gsr_blends_exact(ra.z, ra.w, rb.x, rb.y, ra.x - pxf, ra.y - pyf);
+                    cm &= ~bandm | __builtin_amdgcn_ballot_w64(keep);
+                    GSR_COUNT_ADD(7, 1);
+                };
+                settle(banda, cma, __float_as_int(P3.x));
+                settle(bandb, cmb, __float_as_int(P3.y));
+            }
 #endif
             // colour / depth of both instances requested up front (addressed per lane, no scalar round trip): their LDS latency
             // passes behind the falloff arithmetic instead of sitting in the blend chain.  That chain is what a wave that has its
@@ -462,23 +479,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             const int ja = __float_as_int(P3.x), jb = __float_as_int(P3.y);
             float4 Ca = sC[ja];
             const float4 Cb = sC[jb];
-            auto blend = [&](unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
-#ifndef GSR_PRECISE_MATH
-                const unsigned long long bandm = __builtin_amdgcn_ballot_w64(alu < GSR_ALPHA_HI) & okm;
-                if (bandm != 0ull) {  // rare: some pixel's alpha lies inside the guard band -> the reference's own expression decides
-                    // (the list index as an opaque per-lane value: with a scalar address here the compiler moves `j` -- and the
-                    // whole {i_a, i_b, f_a, f_b} record -- to SGPRs with four v_readfirstlane IN THE HOT PATH and waits early for
-                    // the next iteration's LDS reads: forward 86 -> 101 us)
-                    int jv = j;
-                    asm volatile("" : "+v"(jv));
-                    const GsrRec* r = rec + ids[base + jv];
-                    const float4 ra = r->a;
-                    const float2 rb = *reinterpret_cast<const float2*>(&r->b);
-                    const bool keep = gsr_blends_exact(ra.z, ra.w, rb.x, rb.y, ra.x - pxf, ra.y - pyf);
-                    okm &= ~bandm | __builtin_amdgcn_ballot_w64(keep);
-                    GSR_COUNT_ADD(7, 1);
-                }
-#endif
+            auto blend = [&](const unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
                 const float al1 = __builtin_amdgcn_fmed3f(alu, 0.99f, -3.0e38f);  // = min(0.99, alu), one instruction (no NaN canonicalisation in front)
                 const float test_T = Tr * (1.0f - al1);
                 const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
@@ -514,9 +515,6 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
         __syncthreads();
     }
 
-#ifdef GSR_FWD_ORDER
-    if (lane == 0 && !only_flagged) gsr_qdepth_hint[u] = (uint32_t)min(base + GSR_FWB, n);  // list positions this walk covered
-#endif
     // ran off the sorted prefix with pixels still blending: the tile is sorted completely and this quadrant resumes at n
     const bool ran_off = nsort < nlist && rg.y <= capacity && donem != full;
     if (lane == 0) {
@@ -531,6 +529,7 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
     if (TRAIN && lane == 0 && wl) atomicMax(&tile_work[tile], wl);  // zeroed by gsr_tile_scan_kernel
 
     if (inside) {
+        const float E0 = sAcc[0][lane], E1 = sAcc[1][lane], E2 = sAcc[2][lane], E3 = sAcc[3][lane], E4 = sAcc[4][lane];
         if (TRAIN || ran_off) {  // (ran_off is wave-uniform)
             // sums behind the last checkpoint + how many checkpoints were passed
             gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float4(__int_as_float(npass), C0, C1, C2);
@@ -538,11 +537,11 @@ __global__ void __launch_bounds__(64) gsr_blend_fwd_kernel(
             final_T[pid] = Tr;
             n_contrib[pid] = last | ((ran_off && __builtin_amdgcn_inverse_ballot_w64(donem)) ? 0x80000000u : 0u);  // top bit: for the resume only
             if (!TRAIN) {  // + the closed segments' sums, which the training forward keeps in its checkpoint slots
-                gsr_ckpt_a(ckpt, 0, HW)[pid] = make_float4(0.f, A0, A1, A2);
-                gsr_ckpt_b(ckpt, 0, HW)[pid] = make_float2(A3, A4);
+                gsr_ckpt_a(ckpt, 0, HW)[pid] = make_float4(0.f, E0, E1, E2);
+                gsr_ckpt_b(ckpt, 0, HW)[pid] = make_float2(E3, E4);
             }
         }
-        C0 += A0; C1 += A1; C2 += A2; Dp += A3; Uf += A4;  // image sums = sum of the segment sums
+        C0 += E0; C1 += E1; C2 += E2; Dp += E3; Uf += E4;  // image sums = sum of the segment sums
         out_color[pid] = C0 + Tr * bg[0];
         out_color[HW + pid] = C1 + Tr * bg[1];
         out_color[2 * (size_t)HW + pid] = C2 + Tr * bg[2];
@@ -603,7 +602,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
     int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots,
-    uint32_t* __restrict__ heavy_groups)
+    uint32_t* __restrict__ heavy_groups, const uint32_t* __restrict__ need_full)
 {
     // the per-Gaussian backward that follows appends its heavy groups to a list: this launch, which always precedes it, resets
     // the counter (gauss_bwd.hip)
@@ -752,13 +751,23 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     // back to front, in batches of GSR_SEG_LEN instances (one batch, except in a tile's last segment); local j = 0 is
     // the backmost instance of the batch
     // (SL = the batch length the LDS arrays are sized for; the segment, i.e. the checkpoint spacing seg_len, may be longer)
+    unsigned long long bandm64 = ~0ull;  // (the 128-entry form checks every instance)
+    // a tile whose list was sorted a second time (it ran off its partially sorted prefix) lost the flags of its first pass: there
+    // every instance is checked
+    const bool band_flags_valid = need_full[tile] == 0u;
+    (void)bandm64; (void)band_flags_valid;  // (unused in the parity build)
     for (int hi = seg_hi; hi > seg_lo; hi -= SL) {
         const int lo = max(seg_lo, hi - SL), cnt = hi - lo;
         if (SL == 64) {
             // both wavefronts stage: wave 0 fetches {a, b} of instance `lane`, wave 1 {c, d} + the slot offset; the strip
             // test below then runs on both (one box test per wave and instance instead of four quadrant tests on wave 0)
+            uint32_t idf = 0u;
+            if (lane < cnt) idf = point_list[rg.x + (hi - 1 - lane)];
+#ifndef GSR_PRECISE_MATH
+            bandm64 = band_flags_valid ? __ballot((idf >> 31) != 0u) : ~0ull;  // batch slots the forward met inside the guard band (see gsr_blend_fwd_kernel)
+#endif
             if (lane < cnt) {
-                const uint32_t id = point_list[rg.x + (hi - 1 - lane)];
+                const uint32_t id = idf & 0x7fffffffu;
                 const GsrRec* r = rec + id;
                 if (wave == 0) {
 #ifdef GSR_PRECISE_MATH
@@ -780,7 +789,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
             }
         } else
         if (t < cnt) {
-            const uint32_t id = point_list[rg.x + (hi - 1 - t)];
+            const uint32_t id = point_list[rg.x + (hi - 1 - t)] & 0x7fffffffu;
             const GsrRec* r = rec + id;
             const uint32_t slot0 = offsets[id];  // first gradient slot of the Gaussian (exclusive scan of tiles[])
             const uint4 d = r->d;
@@ -860,10 +869,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                     GSR_COUNT_ADD(0, 1);
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
 #ifndef GSR_PRECISE_MATH
-                        const unsigned long long banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & okma;
-                        const unsigned long long bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & okmb;
+                        unsigned long long banda = 0ull, bandb = 0ull;
+                        if ((bandm64 >> j) & 1ull) {  // wave-uniform (j is scalar): the forward flagged this instance
+                            banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & okma;
+                            bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & okmb;
+                        }
                         if ((banda | bandb) != 0ull) {  // rare: inside the guard band -> the reference's own expression decides (as in the forward)
-                            const GsrRec* r = rec + point_list[rg.x + p];
+                            const GsrRec* r = rec + (point_list[rg.x + p] & 0x7fffffffu);
                             const float4 ra = r->a;
                             const float2 rb = *reinterpret_cast<const float2*>(&r->b);
                             const float ey = ra.y - pyf;
@@ -979,9 +991,6 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
                        image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume)
-#ifdef GSR_FWD_ORDER
-    if (!only_flagged) hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, 4 * T);
-#endif
     if (inference) GSR_FWD_LAUNCH(false);
     else GSR_FWD_LAUNCH(true);
 #undef GSR_FWD_LAUNCH
@@ -1001,7 +1010,7 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 #define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
-                       geom.offsets, slot_written, s4, heavy_groups)
+                       geom.offsets, slot_written, s4, heavy_groups, image.need_full)
 #ifdef GSR_BWD_BATCH128  // long segments staged 128 instances at a time (19.5 KB of LDS: 4 waves per SIMD)
     const bool b64 = sl == 64;
 #else                    // long segments in two batches of 64 (9.7 KB: 5 waves per SIMD)

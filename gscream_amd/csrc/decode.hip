@@ -699,10 +699,12 @@ __global__ void __launch_bounds__(GSD_FB_THREADS) __attribute__((amdgpu_waves_pe
             up_r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 3; c++) up_s[q][c] = 0.f;
-            if (on[q]) {
-                up_r[q] = reinterpret_cast<const float4*>(g_rot)[row[q]];
+            if (on[q]) {  // (a NULL upstream tensor = no gradient flows into that output: zeros, no fill kernel on the host side)
+                if (g_rot) up_r[q] = reinterpret_cast<const float4*>(g_rot)[row[q]];
+                if (g_scaling) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) up_s[q][c] = g_scaling[3 * row[q] + c];
+                    for (int c = 0; c < 3; c++) up_s[q][c] = g_scaling[3 * row[q] + c];
+                }
             }
         }
         auto load_upstream_rest = [&]() {
@@ -713,9 +715,13 @@ __global__ void __launch_bounds__(GSD_FB_THREADS) __attribute__((amdgpu_waves_pe
                 for (int c = 0; c < 3; c++) { up_c[q][c] = 0.f; up_x[q][c] = 0.f; }
                 if (on[q]) {
                     const size_t r = row[q];
-                    up_o[q] = g_opacity[r]; up_u[q] = g_unc[r];
+                    if (g_opacity) up_o[q] = g_opacity[r];
+                    if (g_unc) up_u[q] = g_unc[r];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) { up_c[q][c] = g_color[3 * r + c]; up_x[q][c] = g_xyz[3 * r + c]; }
+                    for (int c = 0; c < 3; c++) {
+                        if (g_color) up_c[q][c] = g_color[3 * r + c];
+                        if (g_xyz) up_x[q][c] = g_xyz[3 * r + c];
+                    }
                 }
             }
         };

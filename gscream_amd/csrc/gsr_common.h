@@ -27,7 +27,8 @@
 //                              last one}.  Lets the backward start in the middle of a list (independent depth segments)
 //           info           16 B {R, max tile count}
 //           qresume[4T]    4 B  forward blend: where a quadrant ran off its tile's sorted prefix (resume point of the fix-up)
-//   binning: point_list[R] 4 B Gaussian ids per tile segment (unsorted after the scatter, sorted in place by the
+//   binning: point_list[R] 4 B Gaussian ids per tile segment; bit 31 = "a pixel met this instance inside the alpha = 1/255 guard
+//            band" (set by the forward blend, read by the backward blend) (unsorted after the scatter, sorted in place by the
 //            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
 //   scratch (backward): slots[R] 48 B  per-instance partial gradients (12 floats)
 #pragma once
@@ -97,8 +98,24 @@ struct GsrImage {
     size_t N;
     uint32_t* info;  // [0] = R, [1] = max tile count
     uint32_t* qresume;  // [4 T] per 8x8 quadrant: list position at which the forward ran off the sorted prefix (0 = it did not)
+    // conservative occlusion cut-off (gsr_tuning.occlusion_cut; preprocess.hip / binning.hip)
+    uint32_t* occ_mass;  // [GSR_OCC_COPIES][T][GSR_OCC_BUCKETS] fixed-point (2^-12) sums of -log2(1 - alpha_min) of the whole-tile
+                         // instances, one copy per XCD (its workgroups add with L2-local atomics), summed by the cut-off kernel
+    uint32_t* occ_cut;   // [T] last depth bucket whose instances are binned (GSR_OCC_BUCKETS = no cut-off)
+    uint32_t* occ_drop;  // [GSR_MAX_CHUNKS] instances each histogram chunk dropped
+    uint32_t* tile_group;  // [ceil(T / 64)] totals of the column scan's tile groups (banded scatter: a band's first list position)
     size_t bytes;
 };
+#define GSR_OCC_BUCKETS 160           // 16 per octave of view depth from 2^-3 on (10 octaves; deeper: the last bucket)
+#define GSR_OCC_FIXED 4096.0f         // fixed-point scale of the masses
+#define GSR_OCC_MAX_TILES 8192        // (8 copies of the mass table: 42 MB at this size; the histogram keeps the cut-off table in LDS)
+#define GSR_OCC_COPIES 8              // one mass table per XCD
+// depth bucket of a Gaussian from the float bits of its view depth (> 0.2): exponent + 4 mantissa bits, monotone in the depth
+__host__ __device__ static inline uint32_t gsr_occ_bucket(uint32_t depth_bits)
+{
+    const int b = (int)(depth_bits >> 19) - ((127 - 3) << 4);
+    return (uint32_t)(b < 0 ? 0 : b >= GSR_OCC_BUCKETS ? GSR_OCC_BUCKETS - 1 : b);
+}
 
 struct GsrBinning {
     uint32_t* point_list;
@@ -157,6 +174,10 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * ((N + 3) & ~(size_t)3) * 4);
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.qresume = (uint32_t*)(b + off); off += gsr_align(4 * T * 4);
+    im.occ_mass = (uint32_t*)(b + off); off += gsr_align(T <= GSR_OCC_MAX_TILES ? (size_t)GSR_OCC_COPIES * T * GSR_OCC_BUCKETS * 4 : 4);
+    im.occ_cut = (uint32_t*)(b + off); off += gsr_align(T * 4);
+    im.occ_drop = (uint32_t*)(b + off); off += gsr_align((size_t)GSR_MAX_CHUNKS * 4);
+    im.tile_group = (uint32_t*)(b + off); off += gsr_align((T / 64 + 1) * 4);
     im.bytes = off;
     return im;
 }
@@ -189,14 +210,16 @@ hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& ca
                                  const float* scales, const float* rotations, const float* opacities,
                                  const float* features, const float* shs, const float* cov3D_precomp,
                                  const float* colors_precomp, const GsrGeom* geom, int32_t* radii, float* px, float* py,
-                                 int tile_cull, hipStream_t stream);
+                                 int tile_cull, uint32_t* occ_mass /* NULL = no occlusion masses */, hipStream_t stream);
 hipError_t gsr_launch_prefiltered_check(int P, const float* means3D, const float* viewmatrix, uint32_t* culled, hipStream_t stream);
 hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                    hipStream_t stream);
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
-                            bool defer_tile_scan, hipStream_t stream);
+                            bool defer_tile_scan, bool occlusion_cut, hipStream_t stream);
+int gsr_scatter_bands(int P, int T, int gx, int expected_instances, int forced);  // bands of tile rows per chunk in the scatter launch (binning.hip)
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
-                              int capacity, bool fused_tile_scan, uint32_t* fused_info_host, bool inference, hipStream_t stream);
+                              int capacity, int expected_instances, int forced_bands, bool fused_tile_scan, uint32_t* fused_info_host, bool inference,
+                              bool occlusion_cut, hipStream_t stream);
 hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, bool inference, const GsrGeom& geom, const GsrImage& image,
                                 const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,

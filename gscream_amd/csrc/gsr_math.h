@@ -142,6 +142,23 @@ __device__ __forceinline__ bool gsr_tile_survives(float mx, float my, float A, f
     const float bx1 = (float)min(tx * 16 + 15, W - 1), by1 = (float)min(ty * 16 + 15, H - 1);
     return !(gsr_box_min_q(mx, my, A, B, C, rA, rC, bx0, bx1, by0, by1) > tau);
 }
+// Occlusion mass of a (Gaussian, tile) instance (gsr_tuning.occlusion_cut): -log2(1 - alpha_min) in fixed point, alpha_min the
+// SMALLEST alpha the Gaussian has at any pixel of the tile, 0 unless that is safely above 1/255 (every pixel of the tile then
+// blends the instance -- power <= 0 holds wherever alpha <= opacity -- with at least this alpha: DGR forward.cu:528-537).  q is
+// convex, so its maximum over the tile's pixel box is at a corner.  tau_exact = ln(255 opacity).  Floors: never over-estimates.
+__device__ __forceinline__ uint32_t gsr_tile_occlusion_mass(float mx, float my, float A, float B, float C, float tau_exact, int tx, int ty,
+                                                            int W, int H)
+{
+    const float dx0 = mx - (float)(tx * 16), dx1 = mx - (float)min(tx * 16 + 15, W - 1);
+    const float dy0 = my - (float)(ty * 16), dy1 = my - (float)min(ty * 16 + 15, H - 1);
+    auto q = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
+    const float qmax = fmaxf(fmaxf(q(dx0, dy0), q(dx1, dy0)), fmaxf(q(dx0, dy1), q(dx1, dy1)));
+    if (!(qmax <= tau_exact - 2.0f * GSR_CULL_MARGIN)) return 0u;  // (NaN-safe) not a whole-tile instance
+    // alpha_min = exp(tau_exact - qmax) / 255, a hair low (1e-3 relative) against the rounding of q; clamp as the blend does
+    const float amin = fminf(0.99f, __expf(tau_exact - qmax - 0.001f) * (1.0f / 255.0f));
+    return (uint32_t)(-__log2f(1.0f - amin) * GSR_OCC_FIXED);
+}
+
 // survivor bit of rectangle position i (row-major); rectangles larger than 64 tiles keep their tail
 __device__ __forceinline__ bool gsr_mask_bit(unsigned long long mask, int i) { return i >= 64 || ((mask >> i) & 1ull); }
 // Calls f(x, y) for every surviving tile of the rectangle, in row-major order.  Walks the SET BITS of the
@@ -247,10 +264,10 @@ __device__ __forceinline__ void gsr_wave_dense(const uint32_t cnt, volatile uint
 // The per-Gaussian walk has as many rounds as the LARGEST footprint in the wave (~18 for a mean of 2.7), and every
 // round costs one LDS atomic instruction whose latency does not depend on the number of active lanes; the dense form
 // needs total/64 rounds.  Must be called by all 64 lanes (no divergence around the call).
-template <typename F>
-__device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const unsigned long long mask,
-                                                           const uint32_t payload /* handed to f as the owner's value */,
-                                                           volatile uint32_t* heads /* LDS, 64 words private to the wave */, F f)
+template <bool WITH_POS, typename F>
+__device__ __forceinline__ void gsr_wave_for_each_instance_t(const uint2 rc, const unsigned long long mask,
+                                                             const uint32_t payload /* handed to f as the owner's value */,
+                                                             volatile uint32_t* heads /* LDS, 64 words private to the wave */, F f)
 {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int x0 = rc.x & 0xffff, w = (int)(rc.x >> 16) - x0, y0 = rc.y & 0xffff, h = (int)(rc.y >> 16) - y0;
@@ -282,9 +299,16 @@ __device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const
             int col = (int)pos - row * ow;
             if (col < 0) { row--; col += ow; }
             if (col >= ow) { row++; col -= ow; }
-            f(lo, ox0 + col, oy0 + row, opay);
+            if constexpr (WITH_POS) f(lo, ox0 + col, oy0 + row, opay, pos);  // + the instance's position in the owner's rectangle
+            else f(lo, ox0 + col, oy0 + row, opay);
         }
     }
+}
+template <typename F>
+__device__ __forceinline__ void gsr_wave_for_each_instance(const uint2 rc, const unsigned long long mask, const uint32_t payload,
+                                                           volatile uint32_t* heads, F f)
+{
+    gsr_wave_for_each_instance_t<false>(rc, mask, payload, heads, f);
 }
 
 // number of surviving tiles of a rectangle with `area` tiles

@@ -8,7 +8,11 @@
 //
 // The reference sorts the points along a Morton curve, boxes them in runs of 1024 and lets every thread scan all boxes
 // with an exact prune.  Same idea here, shaped for CDNA4:
-//   * Morton order by rocPRIM's radix sort (a plain library sort; keys + permutation, 8 B per point),
+//   * Morton order WITHOUT a library (round 4; rocPRIM's radix sort before): the 30-bit codes are counted into 4096 buckets by
+//     their top 12 bits, a one-block scan turns the counts into segments, the 64-bit keys (code << 32 | index) are dropped into
+//     their bucket's segment, and every segment is put in order by the rasterizer's own per-segment sort (binning.hip:
+//     gsr_launch_tile_sort -- LDS bucket / bitonic sort up to 16384 keys, the global network beyond, so a cloud that
+//     collapses into one Morton cell is slow, not wrong).  Keys are unique, so the order is the stable order of the codes.
 //   * the sorted coordinates are GATHERED once into a contiguous float4 array, so the search streams coalesced
 //     16-byte loads instead of chasing `points[indices[i]]`,
 //   * boxes of 64 points (one wavefront's worth: finer pruning than 1024) under super-boxes of 64 boxes,
@@ -19,11 +23,10 @@
 // the group, which bounds every member's own test.
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <float.h>
 #include <stdint.h>
 
-#include "gsr_common.h"
+#include "gsr_math.h"
 
 #define GSK_BOX 64
 #define GSK_GROUP 256
@@ -63,9 +66,11 @@ __device__ __forceinline__ uint32_t gsk_prep_morton(uint32_t x)  // simple_knn.c
     return x;
 }
 
+#define GSK_BUCKET_BITS 12
+#define GSK_BUCKETS (1 << GSK_BUCKET_BITS)
 __global__ void __launch_bounds__(256) gsk_morton_kernel(int P, int nparts, const float* __restrict__ pts,
                                                          const float* __restrict__ part, uint32_t* __restrict__ codes,
-                                                         uint32_t* __restrict__ ids)
+                                                         uint32_t* __restrict__ bucket_count)
 {
     __shared__ float bb[6];
     if (threadIdx.x < 6) {
@@ -80,8 +85,42 @@ __global__ void __launch_bounds__(256) gsk_morton_kernel(int P, int nparts, cons
 #pragma unroll
     for (int k = 0; k < 3; k++)  // simple_knn.cu:49-61
         c[k] = gsk_prep_morton((uint32_t)(((pts[3 * (size_t)i + k] - bb[k]) / (bb[3 + k] - bb[k])) * ((1 << 10) - 1)));
-    codes[i] = c[0] | (c[1] << 1) | (c[2] << 2);
-    ids[i] = (uint32_t)i;
+    const uint32_t code = c[0] | (c[1] << 1) | (c[2] << 2);
+    codes[i] = code;
+    // (a degenerate axis gives NaN -> 0 or garbage bits above bit 29: the bucket index is masked, the order stays total)
+    atomicAdd(&bucket_count[(code >> (30 - GSK_BUCKET_BITS)) & (GSK_BUCKETS - 1)], 1u);
+}
+
+// one block: exclusive scan of the 4096 bucket counts -> segments [start, end) + the scatter cursors
+__global__ void __launch_bounds__(1024) gsk_bucket_scan_kernel(const uint32_t* __restrict__ bucket_count, uint2* __restrict__ ranges,
+                                                               uint32_t* __restrict__ cursor)
+{
+    __shared__ uint32_t wsum[16];
+    constexpr int PER = GSK_BUCKETS / 1024;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { v[k] = bucket_count[threadIdx.x * PER + k]; sum += v[k]; }
+    const uint32_t incl = gsr_wave_scan_add(sum);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        ranges[threadIdx.x * PER + k] = make_uint2(run, run + v[k]);
+        cursor[threadIdx.x * PER + k] = run;
+        run += v[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) gsk_bucket_scatter_kernel(int P, const uint32_t* __restrict__ codes, uint32_t* __restrict__ cursor,
+                                                                 unsigned long long* __restrict__ seg_keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t code = codes[i];
+    const uint32_t slot = atomicAdd(&cursor[(code >> (30 - GSK_BUCKET_BITS)) & (GSK_BUCKETS - 1)], 1u);
+    seg_keys[slot] = ((unsigned long long)code << 32) | (uint32_t)i;  // unique: ties of the code -> ascending index
 }
 
 // sorted coordinates, contiguous: sp[i] = {x, y, z, original index}
@@ -239,12 +278,13 @@ __global__ void __launch_bounds__(GSK_GROUP) gsk_search_kernel(int P, int nboxes
 
 // ---- host side -------------------------------------------------------------------------------------------------
 struct GskWorkspace {
-    uint32_t *codes, *codes_sorted, *ids, *ids_sorted;
+    uint32_t *codes, *ids_sorted, *bucket_count, *cursor;
+    unsigned long long* seg_keys;
+    uint2* ranges;
     float4* sp;
     GskBox *boxes, *sboxes;
     float* part;
-    void* sort_temp;
-    size_t sort_temp_bytes, bytes;
+    size_t bytes;
 };
 #define GSK_MINMAX_BLOCKS 256
 
@@ -255,18 +295,15 @@ static GskWorkspace gsk_carve(void* base, int P)
     size_t off = 0;
     const size_t p = (size_t)(P > 0 ? P : 1);
     w.codes = (uint32_t*)(b + off); off += gsr_align(p * 4);
-    w.codes_sorted = (uint32_t*)(b + off); off += gsr_align(p * 4);
-    w.ids = (uint32_t*)(b + off); off += gsr_align(p * 4);
     w.ids_sorted = (uint32_t*)(b + off); off += gsr_align(p * 4);
+    w.seg_keys = (unsigned long long*)(b + off); off += gsr_align(p * 8);
+    w.ranges = (uint2*)(b + off); off += gsr_align((size_t)GSK_BUCKETS * sizeof(uint2));
+    w.bucket_count = (uint32_t*)(b + off); off += gsr_align((size_t)GSK_BUCKETS * 4);
+    w.cursor = (uint32_t*)(b + off); off += gsr_align((size_t)GSK_BUCKETS * 4);
     w.sp = (float4*)(b + off); off += gsr_align(p * 16);
     w.boxes = (GskBox*)(b + off); off += gsr_align(((p + GSK_BOX - 1) / GSK_BOX) * sizeof(GskBox));
     w.sboxes = (GskBox*)(b + off); off += gsr_align(((p + GSK_BOX * GSK_BOX - 1) / (GSK_BOX * GSK_BOX)) * sizeof(GskBox));
     w.part = (float*)(b + off); off += gsr_align(GSK_MINMAX_BLOCKS * 6 * 4);
-    // rocPRIM's radix sort scratch (histograms / block offsets; the key + value buffers above are ours): provisioned
-    // generously and verified against rocPRIM's own figure at call time
-    w.sort_temp = (void*)(b + off);
-    w.sort_temp_bytes = gsr_align(p * 16 + (1u << 20));
-    off += w.sort_temp_bytes;
     w.bytes = off;
     return w;
 }
@@ -280,14 +317,22 @@ hipError_t gsk_launch(int P, const float* points, float* mean_dist2, void* works
     const GskWorkspace w = gsk_carve(workspace, P);
     const int nb256 = (P + 255) / 256, nparts = nb256 < GSK_MINMAX_BLOCKS ? nb256 : GSK_MINMAX_BLOCKS;
     hipLaunchKernelGGL(gsk_minmax_kernel, dim3(nparts), dim3(256), 0, stream, P, points, w.part);
-    hipLaunchKernelGGL(gsk_morton_kernel, dim3(nb256), dim3(256), 0, stream, P, nparts, points, w.part, w.codes, w.ids);
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, w.codes, w.codes_sorted, w.ids, w.ids_sorted, (unsigned)P, 0, 32, stream);
+    hipError_t e = hipMemsetAsync(w.bucket_count, 0, (size_t)GSK_BUCKETS * 4, stream);
     if (e != hipSuccess) return e;
-    if (need > w.sort_temp_bytes) { *why = "radix sort scratch larger than provisioned"; return hipErrorOutOfMemory; }
-    size_t have = w.sort_temp_bytes;
-    e = rocprim::radix_sort_pairs(w.sort_temp, have, w.codes, w.codes_sorted, w.ids, w.ids_sorted, (unsigned)P, 0, 32, stream);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gsk_morton_kernel, dim3(nb256), dim3(256), 0, stream, P, nparts, points, w.part, w.codes, w.bucket_count);
+    hipLaunchKernelGGL(gsk_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, w.bucket_count, w.ranges, w.cursor);
+    hipLaunchKernelGGL(gsk_bucket_scatter_kernel, dim3(nb256), dim3(256), 0, stream, P, w.codes, w.cursor, w.seg_keys);
+    {   // every bucket's segment in key order, by the rasterizer's per-segment sort (longest segment unknown on the host: all
+        // size classes are launched, workgroups of the wrong class leave at once); ids_sorted = the keys' low words in order
+        GsrGeom geom{};
+        GsrImage image{};
+        GsrBinning bin{};
+        image.ranges = w.ranges;
+        bin.seg_keys = w.seg_keys;
+        bin.point_list = w.ids_sorted;
+        e = gsr_launch_tile_sort(GSK_BUCKETS, P, -1, false, false, true, geom, image, bin, stream);
+        if (e != hipSuccess) { *why = "bucket sort"; return e; }
+    }
     const int nboxes = (P + GSK_BOX - 1) / GSK_BOX;
     hipLaunchKernelGGL(gsk_gather_kernel, dim3(nb256), dim3(256), 0, stream, P, points, w.ids_sorted, w.sp);
     hipLaunchKernelGGL(gsk_box_kernel, dim3(nboxes), dim3(GSK_BOX), 0, stream, P, w.sp, w.boxes);

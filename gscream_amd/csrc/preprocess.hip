@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ features,
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     GsrRec* __restrict__ rec, uint2* __restrict__ rect, uint32_t* __restrict__ depthkey, uint32_t* __restrict__ tiles,
-    unsigned long long* __restrict__ tmask, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, float* __restrict__ out_px, float* __restrict__ out_py)
+    unsigned long long* __restrict__ tmask, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, float* __restrict__ out_px, float* __restrict__ out_py,
+    uint32_t* __restrict__ occ_mass)
 {
     __shared__ uint32_t s_heads[MODE == 0 ? 256 : 1];
     __shared__ unsigned long long s_mask[MODE == 0 ? 256 : 1];
@@ -177,6 +178,9 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
                 const float o_rA = __shfl(rA, owner, 64), o_rC = __shfl(rC, owner, 64), o_tau = __shfl(tau, owner, 64);
                 const int o_bx0 = __shfl(cull_box.x, owner, 64), o_by0 = __shfl(cull_box.y, owner, 64), o_bw = __shfl(cull_box.z, owner, 64);
                 const int o_x0 = __shfl(x0, owner, 64), o_y0 = __shfl(y0, owner, 64), o_wd = __shfl(wd, owner, 64);
+                const uint32_t o_bkt = occ_mass ? (uint32_t)__shfl((int)gsr_occ_bucket(__float_as_uint(viewz)), owner, 64) : 0u;
+                uint32_t* const occ_xcd = occ_mass ? occ_mass + (size_t)(__builtin_amdgcn_s_getreg(63508) & 7u) * (size_t)(cam.gx * cam.gy) * GSR_OCC_BUCKETS
+                                                   : nullptr;  // (XCC_ID of the hardware slot this wave runs on)
                 if (act) {
                     int row = (int)((float)r * __frcp_rn((float)o_bw));  // off by at most one, fixed below
                     int col = (int)r - row * o_bw;
@@ -184,8 +188,17 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
                     if (col >= o_bw) { row++; col -= o_bw; }
                     const int x = o_bx0 + col, y = o_by0 + row;
                     const int i = (y - o_y0) * o_wd + (x - o_x0);
-                    if (i < 64 && gsr_tile_survives(o_pix, o_piy, o_cx, o_cy, o_cz, o_rA, o_rC, o_tau, x, y, cam.W, cam.H))
+                    if (i < 64 && gsr_tile_survives(o_pix, o_piy, o_cx, o_cy, o_cz, o_rA, o_rC, o_tau, x, y, cam.W, cam.H)) {
                         atomicOr(&wmask[owner], 1ull << i);
+                        if (occ_mass) {  // (wave-uniform) occlusion cut-off: the instance's whole-tile mass into its (tile, depth bucket) sum
+                            const uint32_t m = gsr_tile_occlusion_mass(o_pix, o_piy, o_cx, o_cy, o_cz, o_tau - GSR_CULL_MARGIN, x, y, cam.W, cam.H);
+                            // integer adds: order-free.  Into THIS XCD's copy of the table with an L2-local (workgroup-scope)
+                            // atomic: every workgroup that touches the copy runs on this XCD, i.e. behind the same L2; device-scope
+                            // atomics go to memory and cost this kernel 63 us on a large-splat frame
+                            if (m) __hip_atomic_fetch_add(&occ_xcd[(size_t)(y * cam.gx + x) * GSR_OCC_BUCKETS + o_bkt], m, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
                 }
             });
             if (cull_box.z * cull_box.w > 0) mask = wmask[lane];
@@ -271,22 +284,22 @@ hipError_t gsr_launch_preprocess(int mode, int P, int D, int M, const GsrCam& ca
                                  const float* scales, const float* rotations, const float* opacities,
                                  const float* features, const float* shs, const float* cov3D_precomp,
                                  const float* colors_precomp, const GsrGeom* g, int32_t* radii, float* px, float* py,
-                                 int tile_cull, hipStream_t stream)
+                                 int tile_cull, uint32_t* occ_mass, hipStream_t stream)
 {
     if (P <= 0) return hipSuccess;
     const dim3 grid((P + 255) / 256), block(256);
     if (mode == 0)
         hipLaunchKernelGGL(gsr_preprocess_kernel<0>, grid, block, 0, stream, P, D, M, tile_cull, cam, means3D, scales, rotations,
                            opacities, features, shs, cov3D_precomp, colors_precomp, g->rec, g->rect, g->depthkey,
-                           g->tiles, g->tmask, g->clamped, radii, nullptr, nullptr);
+                           g->tiles, g->tmask, g->clamped, radii, nullptr, nullptr, tile_cull ? occ_mass : nullptr);
     else if (mode == 1)
         hipLaunchKernelGGL(gsr_preprocess_kernel<1>, grid, block, 0, stream, P, D, M, 0, cam, means3D, scales, rotations,
                            nullptr, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, radii, nullptr, nullptr);
+                           nullptr, nullptr, radii, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL(gsr_preprocess_kernel<2>, grid, block, 0, stream, P, D, M, 0, cam, means3D, scales, rotations,
                            nullptr, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, radii, px, py);
+                           nullptr, nullptr, radii, px, py, nullptr);
     return hipGetLastError();
 }
 

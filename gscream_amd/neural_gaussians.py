@@ -46,6 +46,10 @@ class _Decode(torch.autograd.Function):
         # after the emit pass is enqueued: no host round trip in front of the decode (torch.nonzero, like the reference's
         # x[visible_mask], drains the stream first, and that was the one point of a training iteration where the GPU ran dry).
         device_rows = vis_idx is None and vis_mask is not None
+        if vis_mask is not None and vis_mask.numel() != anchor.shape[0]:
+            # the reference's x[visible_mask] raises an indexing error here; the row-compaction kernel would read past the mask
+            raise IndexError(f"The shape of the mask {list(vis_mask.shape)} at index 0 does not match the shape of the indexed "
+                             f"tensor {list(anchor.shape)} at index 0")
         N = int(anchor.shape[0]) if vis_idx is None else int(vis_idx.shape[0])  # anchors decoded (device_rows: the upper bound)
         vis = None if vis_idx is None else vis_idx.detach().contiguous().int()
         if feat.shape[1] != 32:
@@ -103,6 +107,7 @@ class _Decode(torch.autograd.Function):
         ctx.dims = (N, K, M)
         ctx.in_shapes = [tuple(t.shape) for t in (feat, anchor, offsets, gscale)] + [tuple(w.shape) for w in weights]
         bmask = mask.bool()
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(nop, bmask)
         _last_decode.update(vis=vis, first=first, N=N, K=K, M=M)  # handed to densify_stats through the selection mask (see decode)
         return xyz, color, opacity, unc, scaling, rot, nop, bmask
@@ -114,7 +119,8 @@ class _Decode(torch.autograd.Function):
         vis_mask8 = ws.pop() if ctx.has_vis_mask else None
         N, K, M = ctx.dims
         dev = feat_c.device
-        z = lambda g, c: (torch.zeros((M, c), dtype=torch.float32, device=dev) if g is None else g.detach().contiguous().float())
+        # an output the loss never touched arrives as None (set_materialize_grads(False)) and travels as NULL: the kernel reads zeros
+        z = lambda g, c: (None if g is None else g.detach().contiguous().float())  # noqa: E731
         g_xyz, g_color, g_opacity, g_unc, g_scaling, g_rot = z(g_xyz, 3), z(g_color, 3), z(g_opacity, 1), z(g_unc, 1), z(g_scaling, 3), z(g_rot, 4)
         warr = _weight_array(ws)
         with torch.cuda.device(dev):

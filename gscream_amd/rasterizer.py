@@ -29,11 +29,16 @@ _tuning_inf_ref = _native.ctypes.byref(_tuning_inf)
 _capacity_hint = {}  # per-device: (binning capacity, longest-list provision) for the next speculative forward
 _recent = {}         # per-device: (num_rendered, max_tile_count) of the last few forwards (training hops between views)
 _RECENT_FRAMES = 8
+_OCC_OFF = {"on": False, "hold": 0}
 _pinned_tls = threading.local()  # per host thread and device: (pinned int32[4] that receives gsr_stage1_result, its ctypes pointer)
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
-def set_tuning(tile_cull=True, speculative=True, partial_sort=True):
+_occlusion_mode = [None]  # None = automatic (per device, from the previous frames), True / False = forced
+_occlusion_state = {}     # per device: {"on": bool, "hold": frames left before the next probe}
+
+
+def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_bands=0, occlusion_cut=None):
     """Performance knobs.  Images, radii and gradients do not depend on them.
     partial_sort=False sorts every per-tile list completely (the reference's lists); by default lists longer than 2048
     entries are depth-sorted only as far as the blend is expected to walk, with a complete sort as fall-back.
@@ -43,6 +48,12 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True):
     _tuning.disable_tile_cull = 0 if tile_cull else 1
     _tuning.disable_speculation = 0 if speculative else 1
     _tuning.disable_partial_sort = 0 if partial_sort else 1
+    _tuning.scatter_bands = _tuning_inf.scatter_bands = int(scatter_bands)  # 0 = automatic (bands of tile rows per chunk in the scatter)
+    # occlusion_cut: conservative per-tile occlusion cut-off in front of the binning (gsr_tuning.occlusion_cut).  None = automatic:
+    # switched on for frames of large splats (>= 4 binned instances per Gaussian in the previous frame), kept while it removes at least
+    # a quarter of the instances, probed again every 64 frames otherwise.  Results do not depend on it; num_rendered does.
+    _occlusion_mode[0] = occlusion_cut
+    _occlusion_state.clear()
     _tuning_inf.disable_tile_cull, _tuning_inf.disable_speculation = _tuning.disable_tile_cull, _tuning.disable_speculation
     _tuning_inf.disable_partial_sort = _tuning.disable_partial_sort
     _capacity_hint.clear()
@@ -173,6 +184,10 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     res = pin[1]
     debug = 1 if rs.debug else 0
     tuning = _tuning_inf_ref if inference else _tuning_ref
+    occ = _occlusion_mode[0]
+    if occ is None:
+        occ = _occlusion_state.get(idx, _OCC_OFF)["on"]
+    (_tuning_inf if inference else _tuning).occlusion_cut = 1 if occ else 0
     common = (P, int(rs.sh_degree), M, W, H, means3D_c.data_ptr(), _p(scales_c), float(rs.scale_modifier),
               _p(rot_c), _p(opac_c), _p(unc_c), _p(sh_c), _p(cov_c), _p(colors_c), _p(view), _p(proj), _p(campos),
               float(rs.tanfovx), float(rs.tanfovy), 1 if rs.prefiltered else 0)
@@ -196,7 +211,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
             if rc != 0:
                 _native.check(rc, "gsr_forward_stage1")
         r = res.contents
-        R, longest, nslots = int(r.num_rendered), int(r.max_tile_count), int(r.num_slots)
+        R, longest, nslots, occluded = int(r.num_rendered), int(r.max_tile_count), int(r.num_slots), int(r.num_occluded)
         if not done:
             cap = R
             binning = empty((lib.gsr_binning_bytes(cap),), dtype=torch.uint8, device=dev)
@@ -220,8 +235,20 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         if h[1] > maxL:
             maxL = h[1]
     _capacity_hint[idx] = (int(1.25 * maxR) + 65536, max(1024, int(1.25 * maxL) + 64))
+    if _occlusion_mode[0] is None:  # automatic occlusion cut-off: decide for the NEXT frame on this device
+        st = _occlusion_state.get(idx)
+        if st is None:
+            st = _occlusion_state[idx] = {"on": False, "hold": 0}
+        if st["on"]:
+            if occluded * 4 < R + occluded:   # removed less than a quarter: not worth its passes on this kind of frame
+                st["on"], st["hold"] = False, 64
+        elif st["hold"] > 0:
+            st["hold"] -= 1
+        elif R >= 4 * P:
+            st["on"] = True
     ls = _last_stage1
     ls["num_rendered"], ls["max_tile_count"], ls["num_slots"], ls["binning_capacity"], ls["speculative"] = R, longest, nslots, cap, done
+    ls["num_occluded"] = occluded
     return R, color, depth, unc, radii, geom, binning, img, cap
 
 

@@ -54,7 +54,8 @@ typedef struct gsr_stage1_result {
     int32_t max_tile_count; /* longest per-tile list; selects the per-tile sort variant */
     int32_t num_slots;      /* sum of tiles_touched over all Gaussians (every tile of every rectangle):
                                the number of gradient slots the backward scratch must hold */
-    int32_t reserved;
+    int32_t num_occluded;   /* instances the conservative occlusion cut-off removed before binning (gsr_tuning.occlusion_cut;
+                               0 when it is off): lets the caller judge whether the pass pays on this kind of frame */
 } gsr_stage1_result;
 
 /* Tunables; zero-initialise for defaults.  Pure performance knobs: images, radii and gradients do not
@@ -73,7 +74,15 @@ typedef struct gsr_tuning {
                                   train.py:756-763,861-878): the forward writes no depth checkpoints, contributor counts,
                                   per-tile traversal depths or gradient-slot offsets and clears no slot flags.  Images and
                                   radii are bit-identical to the training forward; gsr_backward on that state is undefined */
-    int32_t reserved[4];
+    int32_t scatter_bands; /* 0 = automatic.  n > 0 forces the scatter launch to n bands of tile rows per chunk (binning.hip: large images /
+                                  instance counts stage their keys per band so that they leave in runs; a test / tuning knob) */
+    int32_t occlusion_cut; /* 1 = conservative per-tile occlusion cut-off in front of the binning (frames of large splats: lists of
+                                  thousands of instances of which the blend walks a tenth).  Every (Gaussian, tile) instance that covers
+                                  its whole tile with alpha >= 1/255 adds -log2(1 - its smallest alpha in the tile) to a fixed-point sum per
+                                  (tile, depth bucket; 16 buckets per octave of view depth); behind the bucket at which a tile's sum says
+                                  "every pixel's transmittance is below 1e-4" nothing can blend (DGR forward.cu:537), and those instances
+                                  are never binned.  Images, radii, gradients unchanged bit for bit; num_rendered and the lists shrink */
+    int32_t reserved[2];
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */
@@ -217,7 +226,8 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *                      block_scratch: ceil(N/256) u32 of scratch
  *   gsr_decode_emit  : the total[0] surviving rows, in boolean-mask order: xyz[M,3], color[M,3], opacity[M], uncertainty[M],
  *                      scaling[M,3], rot[M,4]
- *   gsr_decode_backward : upstream gradients of those rows -> d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3],
+ *   gsr_decode_backward : upstream gradients of those rows (each of the six may be NULL = no gradient flows into that
+ *                      output: read as zeros) -> d_feat[N,32], d_anchor[N,3], d_offsets[N,K,3],
  *                      d_grid_scaling[N,6] AND the 16 weight / bias gradients grads16 = { gw1[4] [32,36], gb1[4] [32],
  *                      gw2[4] [out,32], gb2[4] [out] } in the order of `weights` (every element written; bit-reproducible),
  *                      in one pass on the f32 matrix cores; workspace of gsr_decode_weight_grad_workspace_bytes() bytes

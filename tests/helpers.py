@@ -124,14 +124,16 @@ def image_report(got, ref, tol=IMG_ABS_TOL):
     return dict(max_abs=float(d.max()) if d.size else 0.0, outliers=int((d > tol).sum()), n=int(d.size))
 
 
-def assert_images_close(got, ref, name, max_outlier_frac=2e-4, hard_cap=5e-3):
-    """<= 1e-4 abs on (almost) every pixel; a bounded handful of threshold-flip pixels is tolerated
-    and reported, none may exceed hard_cap (times the map's range)."""
+def assert_images_close(got, ref, name, max_outlier_frac=2e-5, hard_cap=5e-3):
+    """<= 1e-4 abs on every pixel, except that ONE threshold-flip pixel (or 2e-5 of the pixels, whichever is more) is tolerated
+    and reported, and none may exceed hard_cap (times the map's range).  Since the alpha = 1/255 guard band of round 4 the GPU
+    suite shows no pixel beyond 1e-4 in any test (`pytest -s | grep "threshold flips"`); what can still flip is a pair at
+    T = 1e-4 (accumulated state: the transmittances differ by ulps), measured 0 pixels at 1M / 2M Gaussians -- the allowance is
+    one such pixel, not a tolerance for arithmetic differences (was 2e-4 of the pixels before the guard band)."""
     rep = image_report(got, ref)
     if rep["outliers"]:
         print(f"[threshold flips] {name}: {rep['outliers']} of {rep['n']} pixels beyond {IMG_ABS_TOL} (max {rep['max_abs']:.2e})")
-    frac = rep["outliers"] / max(rep["n"], 1)
-    assert frac <= max_outlier_frac, f"{name}: {rep['outliers']}/{rep['n']} pixels differ by > {IMG_ABS_TOL} (max {rep['max_abs']:.3e})"
+    assert rep["outliers"] <= max(1, max_outlier_frac * rep["n"]), f"{name}: {rep['outliers']}/{rep['n']} pixels differ by > {IMG_ABS_TOL} (max {rep['max_abs']:.3e})"
     # the cap is relative to the map's range: colour and feature maps live in [0, 1], a depth map holds view-space depths (a single
     # threshold-flipped pair at alpha = 1/255 moves a depth pixel by up to depth / 255)
     cap = hard_cap * max(1.0, float(np.abs(np.asarray(ref)).max()) if np.asarray(ref).size else 1.0)
@@ -147,7 +149,7 @@ def grad_report(got, ref, tol=GRAD_REL_TOL):
     return dict(max=float(rel.max()), p999=float(np.quantile(rel, 0.999)), n_bad=int((rel > tol).sum()), n=int(rel.size))
 
 
-def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-4, min_bad_allowed=4, max_rel=0.05):
+def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-5, min_bad_allowed=4, max_rel=0.02):
     """Every gradient family within `tol` rel (denominator |ref| + 1e-3 max|ref|) on all but a bounded
     handful of elements.  The handful exists because a (pixel, Gaussian) pair whose alpha sits within an
     ulp of 1/255 (or whose T sits at 1e-4) can be blended by one implementation and skipped by the other
@@ -155,8 +157,10 @@ def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", m
     Measured on the GPU box: 0-9 such elements out of 240k (tools/grad_diag.py).  One flipped pair moves ALL components
     of that Gaussian's gradient (4 for the quaternion), hence at least 4 elements are tolerated per family.  The 99.9th
     percentile must be inside `tol` regardless (families of >= 1000 x the handful).  No element may be off by more than
-    `max_rel` (0.05: one flipped pixel of one Gaussian; the parity build libgsraster_precise.so, which evaluates the
-    reference's own expression, has NO element beyond `tol` on the same cases -- tests/test_gpu_precise.py)."""
+    `max_rel` (0.02: one flipped pixel of one Gaussian; the parity build libgsraster_precise.so, which evaluates the
+    reference's own expression, has NO element beyond `tol` on the same cases -- tests/test_gpu_precise.py).
+    Round 4 (guard band around alpha = 1/255 in both blend loops): the whole GPU suite prints ONE such element (1.1e-3, dL/drot);
+    bounds tightened from 2e-4 of the elements / 0.05 to 2e-5 / 0.02 -- what remains are T = 1e-4 flips."""
     rep = {}
     for k in keys:
         if k not in ref or k not in got:

@@ -127,6 +127,10 @@ def test_eval_path_empty_and_errors():
     assert all(g is not None and g.abs().sum().item() == 0.0 for g in grads)
     with pytest.raises(RuntimeError):
         generate_neural_gaussians(DO.Camera(torch.tensor(CAM)), copy.deepcopy(ref).float(), None, False)
+    # a visibility mask of the wrong length: the reference's x[visible_mask] raises an IndexError; so does the mirror (the
+    # device-side row compaction must never be handed a mask shorter than the anchor table)
+    with pytest.raises(IndexError):
+        generate_neural_gaussians(cam_d, dut, torch.ones(499, dtype=torch.bool, device="cuda"), True)
 
 
 def test_feeds_the_rasterizer_at_scale():
@@ -211,3 +215,22 @@ def test_visible_rows_on_the_device_match_nonzero(N):
         assert n == want.numel()
         assert torch.equal(rows[:n], want)
         assert bool((rows[n:] == -7).all()), "nothing is written behind the count"
+
+
+def test_absent_upstream_gradients_travel_as_null():
+    """A loss that touches only some decode outputs: the others' upstream gradients are None (set_materialize_grads(False)) and
+    reach the kernel as NULL pointers instead of zero tensors -- same parameter gradients, bit for bit, as explicit zeros."""
+    from gscream_amd.neural_gaussians import generate_neural_gaussians
+    _ref, dut = _pair(700, 10, 13)
+    cam_d = DO.Camera(torch.tensor(CAM, device="cuda"))
+    params = list(dut.parameters())
+    out = generate_neural_gaussians(cam_d, dut, None, True)
+    w = torch.rand(out[0].shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    sparse = torch.autograd.grad((out[0] * w).sum() + out[4].sum(), params, allow_unused=True)               # xyz + scaling only
+    out = generate_neural_gaussians(cam_d, dut, None, True)
+    dense = torch.autograd.grad((out[0] * w).sum() + out[4].sum() + sum((o * 0.0).sum() for o in (out[1], out[2], out[3], out[5])),
+                                params, allow_unused=True)                                                      # explicit zero gradients
+    for a, b in zip(sparse, dense):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)

@@ -59,7 +59,7 @@ def test_workspace_sizes(native_lib):
     v = _layout.image_views(buf, 5000, 112, 71)
     assert v["ranges"].shape == (35, 2) and v["table"].shape == (5, 35)  # 5 = ceil(5000 / 1024) binning chunks (gsr_num_chunks)
     # the last field of the mirror ends inside the buffer the library asked for (the C carve and the mirror agree on every size)
-    last = v["qresume"]
+    last = v["tile_group"]
     assert last.data_ptr() + last.numel() * 4 <= buf.data_ptr() + buf.numel()
     assert _layout.num_chunks(1_000_000) == 256 and _layout.num_chunks(100_000) == 98 and _layout.num_chunks(1) == 1
 

@@ -57,7 +57,9 @@ order = o1[o2]
 keys, tile_of = keys[order], tile_of[order]
 gid = (keys & 0xffffffff).long()
 rec = gv["rec_f32"]
-px, py, hA, hB, hC, op = (rec[gid, i] for i in (0, 1, 2, 3, 4, 5))
+px, py, cA, cB, cC, op = (rec[gid, i] for i in (0, 1, 2, 3, 4, 5))   # the records hold the raw conic (round 4)
+L2E = 1.4426950408889634
+hA, hB, hC = cA * (-0.5 * L2E), cB * (-L2E), cC * (-0.5 * L2E)          # the blend loops' pre-scaled form
 tx, ty = (tile_of % gx).float() * 16, (tile_of // gx).float() * 16
 x0, x1 = tx, torch.clamp(tx + 15, max=W - 1)
 y0, y1 = ty, torch.clamp(ty + 15, max=H - 1)
@@ -88,3 +90,27 @@ for nb in (16, 32, 64):                               # bucketed cut-off: depth 
     first = torch.clamp(seg_start[tile_of] + bstart, max=R - 1)   # bound in front of its BUCKET is still alive
     alive_b = (cs[first] - lg[first] - base[tile_of]) >= np.log2(1e-4)
     print(f"  ... with {nb:3d} buckets per tile                  {int(alive_b.sum()):10d}  = {100.0 * int(alive_b.sum()) / R:5.1f} % of R")
+
+# ---- round 4: what a BUILDABLE version keeps.  Depth buckets of equal WIDTH in view depth between the frame's nearest and farthest
+# binned instance (the same for every tile: any monotone map is conservative), and the per-instance mass quantised to a few fixed
+# levels (an instance whose whole-tile alpha is >= a level counts with that level: conservative).  An instance survives if the
+# bound accumulated over all buckets STRICTLY in front of its bucket is still >= 1e-4.
+depth = (keys >> 32).int().view(torch.float32)        # depth bits are the key's high word
+zmin, zmax = float(depth.min()), float(depth.max())
+print(f"  depth of the binned instances: {zmin:.3f} .. {zmax:.3f}")
+for levels in ((0.05,), (0.02, 0.1, 0.4), None):
+    if levels is None:
+        q = amin.double()
+        name = "exact alpha_min"
+    else:
+        q = torch.zeros_like(amin, dtype=torch.float64)
+        for lv in sorted(levels):
+            q = torch.where(amin >= lv, torch.full_like(q, lv), q)
+        name = "levels " + "/".join(str(v) for v in levels)
+    lgq = torch.log2(1.0 - q)
+    for nb in (4, 8, 16, 32):
+        b = torch.clamp(((depth - zmin) / max(zmax - zmin, 1e-20) * nb).long(), 0, nb - 1)
+        mass = torch.zeros(T * nb, device=dev, dtype=torch.float64).scatter_add_(0, tile_of * nb + b, lgq).view(T, nb)
+        front = torch.cumsum(mass, 1) - mass          # log2 of the bound in front of each bucket
+        alive_q = front[tile_of, b] >= np.log2(1e-4) + 0.5      # (half a binade of safety margin, like the kernel would keep)
+        print(f"  {name:22s} {nb:3d} equal-width depth buckets: keep {int(alive_q.sum()):10d} = {100.0 * int(alive_q.sum()) / R:5.1f} % of R")
