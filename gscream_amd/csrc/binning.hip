@@ -288,13 +288,16 @@ struct GsrFusedScan {
     const uint32_t* occ_drop;  // per-chunk counts of the occlusion cut-off's dropped instances (NULL = off): summed into info[2]
     const uint32_t* tile_group;  // totals of the tile groups of GSR_COLSCAN_TILES tiles (column scan)
 };
-template <bool GLOBAL>
+// BANDED = false compiles the band arithmetic away (nbands = 1: the plain launch, e.g. config 2, keeps its round-3 code: with the
+// run-time form it was 2 us slower).
+template <bool GLOBAL, bool BANDED>
 __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     int P, int T, int gx, int nchunks, const uint2* __restrict__ rect, const u64* __restrict__ tmask,
     const uint32_t* __restrict__ depthkey, const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sum,
     const uint2* __restrict__ ranges, uint32_t* __restrict__ offsets, u64* __restrict__ seg_keys, uint32_t capacity, uint32_t stage_cap,
-    const GsrFusedScan fs, int nbands, int gy)
+    const GsrFusedScan fs, int nbands_arg, int gy)
 {
+    const int nbands = BANDED ? nbands_arg : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t cursor_lds[];
     uint32_t* cursor = GLOBAL ? const_cast<uint32_t*>(table) : cursor_lds;
     __shared__ uint32_t heads_all[GSR_HIST_THREADS];
@@ -311,10 +314,10 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     // Gaussians but emits only the instances of its band of tile rows: the per-tile arrays shrink nbands-fold, the band's share
     // of the chunk fits the staging buffer, and the keys leave in runs again.  The (chunk, tile) table is unchanged.  All bands
     // of a chunk run on the same XCD (the chunk's rect / mask / depth stream stays in that L2).
-    const int blk = (int)(blockIdx.x % (uint32_t)nchunks), band = (int)(blockIdx.x / (uint32_t)nchunks);
+    const int blk = BANDED ? (int)(blockIdx.x % (uint32_t)nchunks) : (int)blockIdx.x, band = BANDED ? (int)(blockIdx.x / (uint32_t)nchunks) : 0;
     const int chunk = (nchunks & 7) == 0 ? (blk & 7) * (nchunks >> 3) + (blk >> 3) : blk;
-    const int by0 = GLOBAL ? 0 : (int)(((long long)band * gy) / nbands), by1 = GLOBAL ? gy : (int)(((long long)(band + 1) * gy) / nbands);
-    const int t_lo = by0 * gx, TB = GLOBAL ? T : (by1 - by0) * gx;  // this workgroup's tiles: [t_lo, t_lo + TB)
+    const int by0 = BANDED ? (int)(((long long)band * gy) / nbands) : 0, by1 = BANDED ? (int)(((long long)(band + 1) * gy) / nbands) : gy;
+    const int t_lo = BANDED ? by0 * gx : 0, TB = BANDED ? (by1 - by0) * gx : T;  // this workgroup's tiles: [t_lo, t_lo + TB)
     // STAGED form (round 3).  Written straight to its tile segment, every 8-byte key costs a 32-byte sector write (86 MB of
     // write requests for 21 MB of keys; with the stores cut out the launch takes 24 instead of 38 us).  When the chunk's
     // instances fit the rest of the LDS they are first placed TILE-MAJOR in a staging buffer -- the chunk's own count per tile
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
     const bool may_stage = !GLOBAL && stage_cap > 0u && TB <= 65535;  // block-uniform
     bool staged = false;
     const bool fused = !GLOBAL && fs.tile_count != nullptr;  // block-uniform
-    if (fused && nbands > 1 && blockIdx.x != 0) {
+    if (BANDED && fused && blockIdx.x != 0) {
         // banded: only this band's tile starts are needed.  First list position of the band = the totals of the tile groups in front
         // of it (T / 64 words from the column scan) + an exclusive scan over the tiles from the band's group boundary on.
         const int g0 = t_lo / GSR_COLSCAN_TILES, ts = g0 * GSR_COLSCAN_TILES, n = t_lo + TB - ts;
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             // instead of gathering 4-byte depths
             uint2 rcb = rcs[k];
             u64 mkb = mks[k];
-            if (nbands > 1) {  // this band's rows of the rectangle; the survivor mask follows (positions >= 64 always survive)
+            if (BANDED) {  // this band's rows of the rectangle; the survivor mask follows (positions >= 64 always survive)
                 const int ry0 = (int)(rcb.y & 0xffff), ry1 = (int)(rcb.y >> 16), rw = (int)(rcb.x >> 16) - (int)(rcb.x & 0xffff);
                 const int cy0 = max(ry0, by0), cy1 = min(ry1, by1);
                 if (cy0 >= cy1 || rw <= 0) { rcb = make_uint2(0u, 0u); mkb = 0ull; }
@@ -971,7 +974,8 @@ static hipError_t gsr_allow_big_lds()
     e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     // (the occlusion variant has 8 KiB more static LDS -- the per-lane dropped-tile masks -- and needs 5 B per tile up to GSR_OCC_MAX_TILES)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_hist_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_scatter_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gsr_tile_sort_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 17408);  // 16.9 KiB static: 4096 bucket offsets + scan scratch
     if (e == hipSuccess && dev >= 0 && dev < 64) done_mask |= 1ull << dev;
     return e;
@@ -1056,7 +1060,7 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
                            occlusion_cut ? (const uint32_t*)image.occ_drop : (const uint32_t*)nullptr, image.tile_group };
     if (T > GSR_MAX_TILES_LDS) {
         hipLaunchKernelGGL(gsr_cursor_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, image.ranges, image.table);
-        hipLaunchKernelGGL(gsr_scatter_kernel<true>, dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
+        hipLaunchKernelGGL((gsr_scatter_kernel<true, false>), dim3(nchunks), dim3(GSR_HIST_THREADS), 0, stream, P, T, gx, nchunks,
                            geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
                            bin.seg_keys, (uint32_t)capacity, 0u, fs, 1, gy);
         return hipGetLastError();
@@ -1079,9 +1083,14 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
     stage_cap = 0;
 #endif
     const size_t lds = stage_cap ? fixed + stage_cap * 10 : tb * 4;
-    hipLaunchKernelGGL(gsr_scatter_kernel<false>, dim3(nchunks * nbands), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
-                       geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
-                       bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs, nbands, gy);
+    if (nbands > 1)
+        hipLaunchKernelGGL((gsr_scatter_kernel<false, true>), dim3(nchunks * nbands), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
+                           geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
+                           bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs, nbands, gy);
+    else
+        hipLaunchKernelGGL((gsr_scatter_kernel<false, false>), dim3(nchunks), dim3(GSR_HIST_THREADS), lds, stream, P, T, gx, nchunks,
+                           geom.rect, geom.tmask, geom.depthkey, image.table, geom.scan_sums, image.ranges, offsets,
+                           bin.seg_keys, (uint32_t)capacity, (uint32_t)stage_cap, fs, 1, gy);
     return hipGetLastError();
 }
 
@@ -1134,6 +1143,9 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
     if (!partial) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, inference, stream);
     // lists up to GSR_NEAR_CAP: full sort in LDS; longer ones: sorted prefix only (gsr_tile_sort_near_kernel)
     // (a guess below the cap that turns out too small fails the host's check anyway and stage 2 is redone)
+    // (round 4 measured the alternative for frames whose longest list is in (2048, 4096] -- complete sorts, 256-thread kernel for the
+    // lists up to 2048 + 1024-thread kernel for the longer ones: config 4 108 -> 122 us, large-splat frame after the occlusion
+    // cut-off 133 -> 239 us: the prefix-sort kernel is not the slower one, the cost follows the number of keys)
     if (mx > GSR_NEAR_CAP) {  // long lists exist: one launch does both classes (fixed 21 KiB of LDS)
         hipLaunchKernelGGL(gsr_tile_sort_near_kernel, dim3(T), dim3(256), 0, stream, image.ranges, bin.seg_keys, bin.point_list,
                            bin.slot_written, image.sorted_len, (uint32_t)capacity);

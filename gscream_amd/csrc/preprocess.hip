@@ -188,8 +188,9 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
                     if (col >= o_bw) { row++; col -= o_bw; }
                     const int x = o_bx0 + col, y = o_by0 + row;
                     const int i = (y - o_y0) * o_wd + (x - o_x0);
-                    if (i < 64 && gsr_tile_survives(o_pix, o_piy, o_cx, o_cy, o_cz, o_rA, o_rC, o_tau, x, y, cam.W, cam.H)) {
-                        atomicOr(&wmask[owner], 1ull << i);
+                    // (rectangle positions beyond 64 have no mask bit: always binned -- and, being binned, they count as occluders too)
+                    if (i >= 64 ? occ_mass != nullptr : gsr_tile_survives(o_pix, o_piy, o_cx, o_cy, o_cz, o_rA, o_rC, o_tau, x, y, cam.W, cam.H)) {
+                        if (i < 64) atomicOr(&wmask[owner], 1ull << i);
                         if (occ_mass) {  // (wave-uniform) occlusion cut-off: the instance's whole-tile mass into its (tile, depth bucket) sum
                             const uint32_t m = gsr_tile_occlusion_mass(o_pix, o_piy, o_cx, o_cy, o_cz, o_tau - GSR_CULL_MARGIN, x, y, cam.W, cam.H);
                             // integer adds: order-free.  Into THIS XCD's copy of the table with an L2-local (workgroup-scope)

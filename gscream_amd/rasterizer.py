@@ -239,13 +239,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         st = _occlusion_state.get(idx)
         if st is None:
             st = _occlusion_state[idx] = {"on": False, "hold": 0}
-        if st["on"]:
-            if occluded * 4 < R + occluded:   # removed less than a quarter: not worth its passes on this kind of frame
-                st["on"], st["hold"] = False, 64
-        elif st["hold"] > 0:
-            st["hold"] -= 1
-        elif R >= 4 * P:
-            st["on"] = True
+        _occlusion_next(st, P, R, occluded)
     ls = _last_stage1
     ls["num_rendered"], ls["max_tile_count"], ls["num_slots"], ls["binning_capacity"], ls["speculative"] = R, longest, nslots, cap, done
     ls["num_occluded"] = occluded
@@ -354,6 +348,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         # scales, rotations, cov3Ds_precomp, raster_settings        (DGR/__init__.py:174-185)
         return (g_means3D, g_means2D, g_sh, g_colors, g_opac.reshape(ctx.opacity_shape),
                 g_unc.reshape(ctx.uncertainty_shape), g_scales, g_rot, g_cov, None)
+
+
+def _occlusion_next(st, P, R, occluded):
+    """Automatic switch of the occlusion cut-off (gsr_tuning.occlusion_cut), per device, from the frame that was just rendered:
+    P Gaussians, R binned instances, `occluded` instances the pass removed (0 when it was off).  Off -> on when the frame had at
+    least 4 instances per Gaussian (large splats: long lists of which the blend walks a fraction); on -> off when the pass removed
+    less than a quarter of the instances, and then not probed again for 64 frames (it costs 3-4 % where nothing covers a tile)."""
+    if st["on"]:
+        if occluded * 4 < R + occluded:
+            st["on"], st["hold"] = False, 64
+    elif st["hold"] > 0:
+        st["hold"] -= 1
+    elif R >= 4 * P:
+        st["on"] = True
+    return st
 
 
 def _no_grad_needed(*tensors):

@@ -106,7 +106,9 @@ int gsr_device_count(void);
 /* ---- workspace sizes (replace the obtain()/required<T>() carving of rasterizer_impl.h:21-74) ---- */
 size_t gsr_geom_bytes(int P);                 /* per-Gaussian state kept from forward to backward   */
 size_t gsr_image_bytes(int P, int W, int H);  /* per-pixel / per-tile state kept forward -> backward (16 B + 192 B of
-                                                 depth checkpoints per pixel, of which only the reached ones are touched) */
+                                                 depth checkpoints per pixel, of which only the reached ones are touched;
+                                                 + 5 KiB per tile, up to 8192 tiles, for the occlusion cut-off's mass tables,
+                                                 touched only when gsr_tuning.occlusion_cut is set) */
 size_t gsr_binning_bytes(int R);              /* per-instance state: sorted point list (+ sort keys)  */
 size_t gsr_backward_scratch_bytes(int P, int num_slots); /* per-instance gradient slots + the heavy-group list of the per-Gaussian backward */
 
@@ -153,6 +155,8 @@ int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count, const flo
  * max_tile_count <= hint (outputs valid; keep `binning_capacity` for gsr_backward).  Returns GSR_NEED_CAPACITY (> 0)
  * otherwise: nothing was written out of bounds, but the images are invalid -- allocate
  * gsr_binning_bytes(result_host->num_rendered) and call gsr_forward_stage2 to redo stage 2.
+ * (Performance only: the instance scatter sizes its staging -- and decides whether to split its launch into bands of tile
+ * rows -- for 0.8 x binning_capacity instances, i.e. it assumes the provision carries the 25 % of slack suggested above.)
  */
 int gsr_forward(int P, int D, int M, int W, int H,
                 const float* means3D, const float* scales, float scale_modifier, const float* rotations,

@@ -160,3 +160,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _native.load()
+
+
+def test_occlusion_cutoff_switches_itself_from_what_the_frames_look_like():
+    """The host side of gsr_tuning.occlusion_cut in automatic mode (rasterizer._occlusion_next): large-splat frames turn it on, it
+    stays on while it removes at least a quarter of the instances, an ineffective probe turns it off for 64 frames."""
+    from gscream_amd import rasterizer as RZ
+    st = {"on": False, "hold": 0}
+    RZ._occlusion_next(st, P=1_000_000, R=2_700_000, occluded=0)          # bench-like frame: 2.7 instances per Gaussian
+    assert st == {"on": False, "hold": 0}
+    RZ._occlusion_next(st, P=950_000, R=13_500_000, occluded=0)           # large splats: on for the next frame
+    assert st["on"]
+    RZ._occlusion_next(st, P=950_000, R=3_500_000, occluded=10_000_000)   # removes 74 %: stays on
+    assert st["on"] and st["hold"] == 0
+    RZ._occlusion_next(st, P=2_000_000, R=12_900_000, occluded=100)       # config-4-like: many small splats, nothing to remove
+    assert not st["on"] and st["hold"] == 64
+    for _ in range(64):
+        RZ._occlusion_next(st, P=2_000_000, R=12_900_000, occluded=0)
+        assert not st["on"]
+    RZ._occlusion_next(st, P=2_000_000, R=12_900_000, occluded=0)         # probed again after the hold
+    assert st["on"]
+    # forcing it through set_tuning overrides the automatic switch and clears its state
+    RZ._occlusion_state[0] = {"on": True, "hold": 0}
+    RZ.set_tuning(occlusion_cut=False)
+    assert RZ._occlusion_mode[0] is False and not RZ._occlusion_state
+    RZ.set_tuning()
+    assert RZ._occlusion_mode[0] is None
