@@ -1048,6 +1048,16 @@ def main():
     barrier()
     prof = _native.profile_end()
     prof[dom_stage] = dom_prof[dom_stage]  # the roofline kernel's duration is the one measured in the timed region
+    # spread (reported beside `value`, never instead of it): three more blocks of K steps, timed the same way.  The driver's
+    # K = 20 makes the official region 9 ms long; this says how much such a sample moves from block to block on this box.
+    spread_ms = []
+    for _ in range(3):
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        spread_ms.append((time.perf_counter() - tb) / args.steps * 1e3)
 
     total_steps, elapsed, rate = multi.aggregate_throughput(dist, args.steps, elapsed, dev)
 
@@ -1086,6 +1096,8 @@ def main():
             "metric": "train iters/sec (fwd+bwd raster) @ 1M Gaussians, 1008x567",
             "value": round(rate, 3), "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_spread": {"note": "three further blocks of `steps` steps on this rank, timed like the official region (which `value` comes from)",
+                                   "blocks_ms": [round(v, 4) for v in spread_ms], "min": round(min(spread_ms), 4), "max": round(max(spread_ms), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,
                        "visible": visible, "tile_cull": not args.no_tile_cull,

@@ -23,13 +23,25 @@ __global__ void __launch_bounds__(256) gst_training_stats_kernel(
     float* __restrict__ offset_gradient_accum, float* __restrict__ offset_denom)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)Nv * K) return;
-    const int n = (int)(i / (size_t)K), k = (int)(i - (size_t)n * K);
+    const bool live = i < (size_t)Nv * K;
+    // (32-bit division wherever the index fits: the 64-bit one is a ~100-instruction routine, and this kernel is otherwise a stream)
+    const int n = !live ? 0 : (size_t)Nv * K <= 0xffffffffull ? (int)((uint32_t)i / (uint32_t)K) : (int)(i / (size_t)K);
+    const int k = (int)(i - (size_t)n * K);
+    const bool kept = live && selection[i] != 0;
+    // rank of k among the offsets the decode kept: the anchor's offsets sit in consecutive lanes, so it is a population count over
+    // the wave's ballot -- except for the offsets an anchor has in the previous wavefront, which are counted from memory
+    const unsigned long long bal = __ballot(kept);
+    if (!live) return;
     const int a = visible ? visible[n] : n;
     const uint8_t* sel = selection + (size_t)n * K;
-    if (sel[k]) {
-        uint32_t row = first[n];  // + rank of k among the offsets the decode kept
-        for (int j = 0; j < k; j++) row += sel[j] ? 1u : 0u;
+    if (kept) {
+        const int lane = (int)(threadIdx.x & 63u), lane0 = lane - k;  // lane of the anchor's offset 0 (negative: in the previous wave)
+        uint32_t row = first[n];
+        if (lane0 >= 0) row += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull) & ~((1ull << lane0) - 1ull));
+        else {
+            for (int j = 0; j < -lane0; j++) row += sel[j] ? 1u : 0u;
+            row += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        }
         if (row < (uint32_t)M && update_filter[row]) {  // row >= M: a selection mask of another render; never read out of bounds
             const float gx = viewspace_grad[3 * (size_t)row], gy = viewspace_grad[3 * (size_t)row + 1];
             offset_gradient_accum[(size_t)a * K + k] += sqrtf(gx * gx + gy * gy);
