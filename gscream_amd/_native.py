@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsraster.so")  #
 EXPORTED_SYMBOLS = (
     "gsr_version", "gsr_abi_version", "gsr_last_error", "gsr_device_count", "gsr_geom_bytes", "gsr_image_bytes",
     "gsr_binning_bytes", "gsr_backward_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward",
-    "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_end", "gsr_stage_name",
+    "gsr_backward", "gsr_filter", "gsr_mark_visible", "gsr_profile_begin", "gsr_profile_begin_sampled", "gsr_profile_end", "gsr_stage_name",
     "gsr_loss_workspace_bytes", "gsr_rgb_loss_forward", "gsr_rgb_loss_backward", "gsr_rgb_loss_forward_window",
     "gsr_rgb_loss_backward_window",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
@@ -93,6 +93,8 @@ def load():
     lib.gsr_mark_visible.argtypes = [_c_int] + [_vp] * 5
     lib.gsr_profile_begin.restype = _c_int
     lib.gsr_profile_begin.argtypes = [ctypes.c_uint]
+    lib.gsr_profile_begin_sampled.restype = _c_int
+    lib.gsr_profile_begin_sampled.argtypes = [ctypes.c_uint, ctypes.c_uint]
     lib.gsr_profile_end.restype = _c_int
     lib.gsr_profile_end.argtypes = [ctypes.POINTER(Profile)]
     lib.gsr_stage_name.restype = ctypes.c_char_p
@@ -139,10 +141,11 @@ STAGE_NAMES = ("preprocess", "count_scan", "scatter", "tile_sort", "blend_forwar
 NEED_CAPACITY = 1
 
 
-def profile_begin(stages=None):
-    """Start timing stages with HIP events (all stages, or only the named ones to keep the stream undisturbed)."""
+def profile_begin(stages=None, every=1):
+    """Start timing stages with HIP events (all stages, or only the named ones to keep the stream undisturbed; every = n
+    times only every n-th invocation of a stage)."""
     mask = 0 if not stages else sum(1 << STAGE_NAMES.index(s) for s in stages)
-    check(load().gsr_profile_begin(mask), "gsr_profile_begin")
+    check(load().gsr_profile_begin_sampled(mask, int(every)), "gsr_profile_begin_sampled")
 
 
 def profile_end():

@@ -35,6 +35,8 @@ struct GsrProfRec { int stage; hipEvent_t t0, t1; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static unsigned g_prof_mask = 0xffffffffu;
+static unsigned g_prof_every = 1;                  // time every n-th invocation of a stage (gsr_profile_begin_sampled)
+static unsigned g_prof_seen[GSR_NUM_STAGES] = {};  // invocations of each stage since gsr_profile_begin
 static std::vector<GsrProfRec> g_prof;
 
 struct GsrStageTimer {
@@ -45,6 +47,7 @@ struct GsrStageTimer {
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (!g_prof_on || !((g_prof_mask >> stage) & 1u)) return;
+        if (g_prof_seen[stage]++ % g_prof_every != 0u) return;  // sampled: the markers perturb the stream (a bubble on either side)
         if (hipEventCreate(&rec.t0) != hipSuccess || hipEventCreate(&rec.t1) != hipSuccess) return;
         rec.stage = stage;
         on = hipEventRecord(rec.t0, stream) == hipSuccess;
@@ -73,15 +76,19 @@ extern "C" const char* gsr_stage_name(int stage)
     return (stage >= 0 && stage < GSR_NUM_STAGES) ? g_stage_names[stage] : "";
 }
 
-extern "C" int gsr_profile_begin(unsigned stage_mask)
+extern "C" int gsr_profile_begin_sampled(unsigned stage_mask, unsigned every)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_mask = stage_mask ? stage_mask : 0xffffffffu;
+    g_prof_every = every ? every : 1u;
+    for (unsigned& n : g_prof_seen) n = 0u;
     for (auto& r : g_prof) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     g_prof.clear();
     g_prof_on = true;
     return GSR_OK;
 }
+
+extern "C" int gsr_profile_begin(unsigned stage_mask) { return gsr_profile_begin_sampled(stage_mask, 1u); }
 
 extern "C" int gsr_profile_end(gsr_profile* out_host)
 {

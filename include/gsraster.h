@@ -326,6 +326,9 @@ int gsr_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* work
  * returns the per-stage totals.  This is the only process-wide state in the library; off by default.
  */
 int gsr_profile_begin(unsigned stage_mask /* bit i = time stage i; 0 = all */);
+/* The same, timing only every `every`-th invocation of each selected stage (the first one included): an event pair costs the
+ * stream a bubble on either side of the stage, so a benchmark that wants a stage's duration from inside its timed region samples. */
+int gsr_profile_begin_sampled(unsigned stage_mask, unsigned every);
 int gsr_profile_end(gsr_profile* out_host);
 const char* gsr_stage_name(int stage);
 

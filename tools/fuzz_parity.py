@@ -1,6 +1,8 @@
 """Randomised parity sweep of the rasterizer against the CPU oracle (diagnostic; run on the GPU box):
 random sizes (not multiples of 16), cameras, scales (tiny splats to ones covering > 64 tiles), depth ties, all
-three upstream gradient maps on or off.  usage: python tools/fuzz_parity.py [n_cases] [seed0]"""
+three upstream gradient maps on or off.  usage: python tools/fuzz_parity.py [n_cases] [seed0]
+FUZZ_KNOBS=1: every case is also run with the occlusion cut-off forced on + the scatter forced into bands + the two-stage forward,
+and must come out bit-identical (images, radii, gradients)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,6 +37,15 @@ def main():
         ref = Hh.oracle_backward(s, st, grads, nthreads=16)
         set_tuning(tile_cull=bool(c % 2))
         got = Hh.hip_run(s, grads)
+        if os.environ.get("FUZZ_KNOBS"):
+            # round 4: the performance knobs must not change one output bit -- occlusion cut-off forced on (it works on the tile-cull
+            # masks: a no-op with culling off), the scatter forced into bands of tile rows, the two-stage forward
+            for knobs in (dict(occlusion_cut=True, scatter_bands=3), dict(occlusion_cut=True, scatter_bands=2, speculative=False)):
+                set_tuning(tile_cull=bool(c % 2), **knobs)
+                alt = Hh.hip_run(s, grads)
+                for k in got:
+                    assert np.array_equal(got[k], alt[k]), (c, knobs, k)
+            set_tuning(tile_cull=bool(c % 2))
         assert (got["radii"] == st["radii"]).all(), (c, "radii")
         for k in ("out_color", "out_depth", "out_unc"):
             Hh.assert_images_close(got[k], st[k], f"case{c}/{k}")
