@@ -33,7 +33,7 @@ class Stage1Result(ctypes.Structure):
 class Tuning(ctypes.Structure):
     _fields_ = [("disable_tile_cull", ctypes.c_int32), ("disable_speculation", ctypes.c_int32),
                 ("disable_partial_sort", ctypes.c_int32), ("inference", ctypes.c_int32), ("scatter_bands", ctypes.c_int32),
-                ("occlusion_cut", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                ("occlusion_cut", ctypes.c_int32), ("heavy_groups", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):

@@ -174,6 +174,8 @@ struct GsrThreadDeviceState {
     uint32_t* host[GSR_MAX_DEVICES] = {};
     uint32_t* dev[GSR_MAX_DEVICES] = {};
     hipEvent_t ev[GSR_MAX_DEVICES] = {};
+    uint8_t heavy_mode[GSR_MAX_DEVICES] = {};   // per-Gaussian backward: 1 = launch the heavy-group kernel (gsr_heavy_groups_expected)
+    uint8_t heavy_probe[GSR_MAX_DEVICES] = {};  // backwards to wait before the heavy kernel is launched again just to count the groups
     ~GsrThreadDeviceState()
     {
         for (int d = 0; d < GSR_MAX_DEVICES; d++) {
@@ -195,8 +197,10 @@ static int gsr_current_device(int* d)
 }
 
 // words of the pinned, device-mapped block (one per host thread and device): 0, 1 = {R, longest list} of stage 1, 4 = prefiltered
-// trap, 8 = "the per-Gaussian backward met a heavy group"
+// trap, 8 = the per-Gaussian backward's report on heavy groups (0 = nothing new, 1 = the one-wave kernel met one, 2 + n = the
+// heavy kernel was given n)
 #define GSR_PINNED_HEAVY_SEEN 8
+#define GSR_HEAVY_MIN_GROUPS 192  // fewer heavy groups than this: the one-wave kernel does them itself (gauss_bwd.hip, launcher)
 static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
 {
     int d = 0;
@@ -212,6 +216,19 @@ static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
     }
     *host = g_tds.host[d]; *dev = g_tds.dev[d];
     return GSR_OK;
+}
+
+// The state machine behind `heavy_expected` (see gsr_backward): report = the pinned word, mode / probe = the thread's state.
+static bool gsr_heavy_groups_expected(uint32_t report, uint8_t* mode, uint8_t* probe)
+{
+    if (report >= 2u) {  // counted by the heavy kernel
+        *mode = (report - 2u) >= GSR_HEAVY_MIN_GROUPS;
+        *probe = (report - 2u) > 0u ? 64 : 0;  // none at all: the next sighting is counted at once
+    } else if (report == 1u && !*mode) {  // met by the one-wave kernel while it was doing them itself
+        if (*probe > 0) --*probe;
+        else *mode = 1;
+    }  // 0, or 1 in heavy mode (the heavy kernel of that call has not reported yet): nothing new
+    return *mode != 0;
 }
 
 static int gsr_info_event(hipEvent_t* ev)
@@ -499,14 +516,19 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binnin
                   "backward blend");
     else
         GSR_HIP(hipMemsetAsync(heavy, 0, 2 * sizeof(uint32_t), stream), "heavy-group counters");
-    // Did this thread's previous backward (on this device) meet a group of large splats?  One word of the pinned block: the
-    // per-Gaussian kernel sets it, the host reads and clears it here.  A hint only: without the heavy kernel the first kernel
-    // does such groups itself.
+    // Is the heavy-group kernel worth its launch?  Decided from what this thread's previous backwards (on this device) reported
+    // through one word of the pinned block, read and cleared here without waiting for anything -- a hint only: both ways give the
+    // same bits.  The heavy kernel reports how many groups it was given; below GSR_HEAVY_MIN_GROUPS the next calls go without it
+    // (then only "met one" is known, so every 64th call launches it again to count).
     volatile uint32_t* pinned = nullptr;
     uint32_t* pinned_dev = nullptr;
     rc = gsr_info_buffer(&pinned, &pinned_dev);
     if (rc) return rc;
-    const bool heavy_expected = pinned[GSR_PINNED_HEAVY_SEEN] != 0u;
+    int devidx = 0;
+    rc = gsr_current_device(&devidx);
+    if (rc) return rc;
+    bool heavy_expected = gsr_heavy_groups_expected(pinned[GSR_PINNED_HEAVY_SEEN], &g_tds.heavy_mode[devidx], &g_tds.heavy_probe[devidx]);
+    if (tuning && tuning->heavy_groups) heavy_expected = tuning->heavy_groups == 1;
     pinned[GSR_PINNED_HEAVY_SEEN] = 0u;
     GSR_STAGE(GSR_STAGE_GAUSS_BWD, gsr_launch_gauss_backward(P, D, M, cam, means3D, radii, shs, scales, rotations, cov3D_precomp, geom, slots, slot_written, heavy,
                                         pinned_dev + GSR_PINNED_HEAVY_SEEN, heavy_expected, R,

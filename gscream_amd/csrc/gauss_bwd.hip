@@ -104,7 +104,8 @@ struct GsrGaussArgs {
     const float* rotations; const float* cov3D_precomp; const uint32_t* offsets; const uint32_t* tiles; int num_slots;
     const float4* slots; uint8_t* slot_written;
     uint32_t* heavy;  // [0] = number of heavy groups, [1] = groups fetched dynamically (both reset by the backward blend), [16 ..] = indices
-    uint32_t* heavy_seen;  // host-mapped word (may be null): set to 1 by any heavy group -- the host's hint for its NEXT backward
+    uint32_t* heavy_seen;  // host-mapped word (may be null), the host's hint for its NEXT backward: the one-wave kernel sets it to 1 at any
+                           // heavy group, the heavy kernel (when launched) to 2 + the number of groups it was given
     int inline_heavy;      // 1 = no heavy kernel follows this launch: the one-wave kernel does the heavy groups itself
     float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dfeatures, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drotations;
 };
@@ -457,6 +458,7 @@ __global__ void __launch_bounds__(256) gsr_gauss_bwd_heavy_kernel(const GsrGauss
     uint8_t* __restrict__ slot_written = A.slot_written;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t nheavy = A.heavy[0];  // the groups gsr_gauss_bwd_kernel listed (any order: groups are independent)
+    if (blockIdx.x == 0 && t == 0 && A.heavy_seen) *A.heavy_seen = 2u + nheavy;  // (after every store of the first kernel: stream order)
     __shared__ uint32_t s_next;
     // the first gridDim.x groups are dealt by block index, the rest is fetched from a counter as workgroups come free
     // (groups differ in size by an order of magnitude; a few hundred fetches per launch: the counter is not a bottleneck)
@@ -584,9 +586,11 @@ hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, con
     const dim3 grid((P + 63) / 64);
     // every group of 64 Gaussians is done by exactly one kernel: the first one does the light groups and lists the heavy
     // ones, a small grid of 256-thread workgroups then walks that list.  On a scene without large splats that second launch
-    // found nothing to do and still cost 4.5 us, so it is only made when the caller's PREVIOUS backward met a heavy group
-    // (heavy_expected, from the host-mapped word the first kernel sets); otherwise the first kernel does whatever heavy groups
-    // turn up itself -- same bits either way.
+    // found nothing to do and still cost 4.5 us, and with a hundred heavy groups it costs more (~22 us, a chain of dependent
+    // round trips however few the groups) than the first kernel loses by doing them itself (config 4: 112 groups, 24.5 us against
+    // +11 us), so it is only made when the caller's PREVIOUS backwards met enough of them (heavy_expected, api.hip: from the
+    // host-mapped word both kernels report to); otherwise the first kernel does whatever heavy groups turn up itself -- same
+    // bits either way.
     A.heavy_seen = heavy_seen_mapped; A.inline_heavy = heavy_expected ? 0 : 1;
     hipLaunchKernelGGL(gsr_gauss_bwd_kernel, grid, dim3(64), 0, stream, A);
     if (heavy_expected)

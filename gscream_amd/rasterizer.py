@@ -38,7 +38,7 @@ _occlusion_mode = [None]  # None = automatic (per device, from the previous fram
 _occlusion_state = {}     # per device: {"on": bool, "hold": frames left before the next probe}
 
 
-def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_bands=0, occlusion_cut=None):
+def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_bands=0, occlusion_cut=None, heavy_groups=None):
     """Performance knobs.  Images, radii and gradients do not depend on them.
     partial_sort=False sorts every per-tile list completely (the reference's lists); by default lists longer than 2048
     entries are depth-sorted only as far as the blend is expected to walk, with a complete sort as fall-back.
@@ -52,6 +52,9 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_band
     # occlusion_cut: conservative per-tile occlusion cut-off in front of the binning (gsr_tuning.occlusion_cut).  None = automatic:
     # switched on for frames of large splats (>= 4 binned instances per Gaussian in the previous frame), kept while it removes at least
     # a quarter of the instances, probed again every 64 frames otherwise.  Results do not depend on it; num_rendered does.
+    # heavy_groups: None = automatic, True / False = always / never launch the per-Gaussian backward's cooperative kernel for groups of
+    # large splats (gsr_tuning.heavy_groups)
+    _tuning.heavy_groups = 0 if heavy_groups is None else 1 if heavy_groups else 2
     _occlusion_mode[0] = occlusion_cut
     _occlusion_state.clear()
     _tuning_inf.disable_tile_cull, _tuning_inf.disable_speculation = _tuning.disable_tile_cull, _tuning.disable_speculation

@@ -82,7 +82,10 @@ typedef struct gsr_tuning {
                                   (tile, depth bucket; 16 buckets per octave of view depth); behind the bucket at which a tile's sum says
                                   "every pixel's transmittance is below 1e-4" nothing can blend (DGR forward.cu:537), and those instances
                                   are never binned.  Images, radii, gradients unchanged bit for bit; num_rendered and the lists shrink */
-    int32_t reserved[2];
+    int32_t heavy_groups; /* per-Gaussian backward, groups of 64 Gaussians with more than 1024 gradient slots (large splats).  0 = automatic:
+                                  a second, cooperative kernel takes them when the caller's previous backwards met enough of them to pay for
+                                  its launch; 1 = always launch it, 2 = never (the one-wave kernel does them).  Same bits in every mode */
+    int32_t reserved;
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */

@@ -548,11 +548,12 @@ def test_more_cases_against_live_oracle(variant):
         # kernel did their sums above; it must be as bit-reproducible as the one-wave path
         assert int(got["radii"][:64].astype(bool).sum()) > 0 and int(st["tiles_touched"][:64].sum()) > 4096
         # ... and the same bits come out of the one-wave kernel, which does the heavy groups itself when the caller's previous
-        # backward had met none (the heavy kernel is then not launched; the first kernel sets the hint for the next call)
-        small = S.scene_config1(seed=1, P=200, W=64, H=64)
-        Hh.hip_run(small, S.upstream_grads(1, 64, 64))  # a backward without heavy groups clears the hint
+        # backwards met too few to pay for the second launch (automatic mode: api.hip, gsr_heavy_groups_expected)
+        set_tuning(heavy_groups=False)
         inline = Hh.hip_run(s, grads)                    # heavy groups done inline
+        set_tuning(heavy_groups=True)
         again = Hh.hip_run(s, grads)                     # ... by the cooperative kernel
+        set_tuning()
         for k in Hh.GRAD_KEYS:
             if k in got:
                 assert np.array_equal(got[k], again[k]), f"{k}: the heavy-group backward is bit-reproducible"
