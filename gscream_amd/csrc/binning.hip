@@ -678,17 +678,22 @@ __device__ __forceinline__ void gsr_sort_lds_fused(u64* k, const uint32_t n, con
     }
 }
 
-// Bucket sort of one tile list held in registers (n <= NT * KPT keys, thread t owns keys t, t + NT, ...): the
-// 64-bit keys (depth bits, id) are spread over 4 * NT equal-width buckets of their own range; a counting
-// pass (LDS atomics) places every key in its bucket's slice of k[], and each bucket -- one or two keys on average --
-// is finished with an insertion sort by the thread that owns it.  O(n) instead of the bitonic network's
-// n log^2 n / 2 compare-exchanges of 5 VALU operations each (2048 keys: 66 stages).  Exact for any input; only its
-// speed depends on the keys being spread out: a bucket with more than GSR_BUCKET_MAX keys (depth clusters finer than
-// 1/1024 .. 1/4096 of the tile's depth range) is sorted by the whole workgroup with the plain network on its slice; if more than
-// half of the list sits in such buckets, or in more than GSR_HEAVY_MAX of them, the tile falls back to the fused network
-// altogether.  Returns false in that case, with the keys stored at k[GSR_PAD(i)] for it; true with the sorted keys at k[i].
-#define GSR_BUCKET_MAX 16
-#define GSR_HEAVY_MAX 16
+// Counting sort of one tile list held in registers (n <= NT * KPT keys, thread t owns keys t, t + NT, ...), two levels, O(n)
+// instead of the bitonic network's n log^2 n / 2 compare-exchanges of 5 VALU operations each (2048 keys: 66 stages).
+// Level 1: the 64-bit keys (depth bits, id) are spread over 4 * NT equal-width buckets of their own range (LDS atomics, one scan).
+// Level 2: a bucket of c keys is cut into 2^floor(log2 c) equal-width sub-buckets (the next key bits), numbered inside the bucket's
+// own slice [start, start + c) -- so ONE n-entry counter array serves all buckets (16-bit counters packed into offs[], which is free
+// once every key knows its sub-bucket) and its exclusive scan is the placement.  A key's position inside its sub-bucket -- one or two
+// keys when the cluster is smooth at that resolution -- is its rank by counting: independent LDS reads, no serial chain.
+// Exact for any input; its speed no longer depends on the keys being spread out.  Depth keys are not, in general: surfaces, and the
+// layers of an anchor grid, put dozens of buckets of 20 - 70 keys into every list of the large-splat stand-in frame
+// (tools/sort_buckets_probe.py).  Rounds 1 - 3 finished the level-1 buckets with an insertion sort by the owning thread (serial,
+// dependent LDS round trips: fine for 1 - 2 keys, the slowest thread's 10 - 13-key bucket set the pace of every tile even on the
+// uniform bench scene) and sent clustered tiles to the network: tile sort 32 -> 22 us on the bench scene, 108 -> 66 us at config 4,
+// 134 -> 35 us on the large-splat frame (round 4).  Only keys that are equal in every bit the two levels look at (thousands of
+// Gaussians on exact depth planes: the ids differ) defeat it; the sum of the squared sub-bucket counts measures that, and beyond
+// 24 n the tile falls back to the fused network.  Returns false in that case, with the keys stored at k[GSR_PAD(i)] for it; true
+// with the sorted keys at k[i].
 // NT threads, KPT keys per thread in registers (n <= NT * KPT), 4 * NT buckets (thread t owns buckets 4t .. 4t+3).
 template <int NT, int KPT>
 __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[KPT], const uint32_t n, u64* k, uint32_t* offs /*[4 NT]*/,
@@ -696,8 +701,6 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[KPT], const uint
 {
     constexpr int NW = NT / 64, NB = 4 * NT, LOGNB = NT == 256 ? 10 : 12;
     static_assert(NT == 256 || NT == 1024, "bucket count = 4 NT must match LOGNB");
-    __shared__ uint2 heavy[GSR_HEAVY_MAX];
-    __shared__ uint32_t heavy_n[1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     u64 mn = ~0ull, mx = 0ull;
 #pragma unroll
@@ -727,65 +730,95 @@ __device__ __forceinline__ bool gsr_sort_buckets(const u64 (&v)[KPT], const uint
     const uint32_t h0 = offs[4 * t], h1 = offs[4 * t + 1], h2 = offs[4 * t + 2], h3 = offs[4 * t + 3];
     const uint32_t mine = h0 + h1 + h2 + h3;
     const uint32_t incl = gsr_wave_scan_add(mine);
-    // keys in buckets that are too long for an insertion sort (depth clusters), and how many such buckets
-    const uint32_t hh[4] = { h0, h1, h2, h3 };
-    uint32_t hk = 0u, hn = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (hh[q] > GSR_BUCKET_MAX) { hk += hh[q]; hn++; }
-    hk = gsr_wave_scan_add(hk);
-    hn = gsr_wave_scan_add(hn);
     if (lane == 63) { wtot[wave] = incl; wtot[NW] = 0u; wtot[NW + 1] = 0u; }
-    if (t == 0) heavy_n[0] = 0u;
     __syncthreads();
-    if (lane == 63) { atomicAdd(&wtot[NW], hk); atomicAdd(&wtot[NW + 1], hn); }
     uint32_t run = incl - mine;
     for (int w = 0; w < wave; w++) run += wtot[w];
-    __syncthreads();
-    // A few clusters are sorted separately after the placement (network on their slices); if most of the list sits in
-    // clusters, or in many of them, the whole tile goes to the fused network (block-uniform decision).
-    if (2u * wtot[NW] > n || wtot[NW + 1] > GSR_HEAVY_MAX) {
-#pragma unroll
-        for (int j = 0; j < KPT; j++)
-            if ((uint32_t)(t + NT * j) < n) k[GSR_PAD(t + NT * j)] = v[j];
-        __syncthreads();
-        return false;
-    }
     offs[4 * t] = run; offs[4 * t + 1] = run + h0; offs[4 * t + 2] = run + h0 + h1; offs[4 * t + 3] = run + h0 + h1 + h2;
     __syncthreads();
-    // placement: offs[bucket] is the next free position of the bucket's slice (and its end once every key is placed)
+    // ---- second level: 16-bit sub-bucket counters, two per word of offs[] (free once every key knows its sub-bucket) ----
+    uint32_t idx[KPT];
+    const bool fits2 = n <= 2u * (uint32_t)NB;  // (block-uniform; only the 1024-thread class can exceed it)
 #pragma unroll
-    for (int j = 0; j < KPT; j++)
-        if ((uint32_t)(t + NT * j) < n) k[atomicAdd(&offs[b[j]], 1u)] = v[j];
-    __syncthreads();
-    // every bucket finished by its owner (insertion sort; slices hold <= GSR_BUCKET_MAX keys, mostly 0 - 2); the
-    // slices of the few heavy buckets are listed and sorted by the whole workgroup afterwards
-    uint32_t lo = run;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t hi = offs[4 * t + q];
-        if (hi - lo > GSR_BUCKET_MAX) {
-            heavy[atomicAdd(&heavy_n[0], 1u)] = make_uint2(lo, hi - lo);
-        } else {
-            for (uint32_t i = lo + 1; i < hi; i++) {
-                const u64 x = k[i];
-                uint32_t j = i;
-                while (j > lo && k[j - 1] > x) { k[j] = k[j - 1]; j--; }
-                k[j] = x;
-            }
+    for (int j = 0; j < KPT; j++) {
+        idx[j] = 0u;
+        if ((uint32_t)(t + NT * j) < n) {
+            const uint32_t s0 = offs[b[j]], c = (b[j] + 1u < (uint32_t)NB ? offs[b[j] + 1u] : n) - s0;
+            const int L = min(31 - __builtin_clz(c), shift);  // c >= 1 (this key); 2^L <= c sub-buckets, never finer than the key bits left
+            idx[j] = s0 + (uint32_t)(((v[j] - kmin) >> (shift - L)) & (u64)((1u << L) - 1u));
         }
-        lo = hi;
     }
     __syncthreads();
-    const uint32_t nh = heavy_n[0];
-    for (uint32_t c = 0; c < nh; c++) gsr_bitonic(k + heavy[c].x, heavy[c].y, NT);  // ends with a barrier
+    for (int i = t; i < NB; i += NT) offs[i] = 0u;
+    __syncthreads();
+    if (fits2) {
+#pragma unroll
+        for (int j = 0; j < KPT; j++)
+            if ((uint32_t)(t + NT * j) < n) atomicAdd(&offs[idx[j] >> 1], 1u << ((idx[j] & 1u) * 16u));
+    }
+    __syncthreads();
+    {   // exclusive scan of the counters in place (thread t owns words 4t .. 4t+3 = entries 8t .. 8t+7), and the sum of their squares
+        uint32_t c2[8], loc = 0u, sq = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t w = offs[4 * t + e];
+            c2[2 * e] = w & 0xffffu; c2[2 * e + 1] = w >> 16;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) { loc += c2[e]; sq += c2[e] * c2[e]; }
+        const uint32_t incl2 = gsr_wave_scan_add(loc);
+        const uint32_t sqw = gsr_wave_scan_add(sq);
+        if (lane == 63) { wtot[wave] = incl2; atomicAdd(&wtot[NW + 1], sqw); }
+        __syncthreads();
+        if (!fits2 || wtot[NW + 1] > 24u * n) {  // keys equal in every bit both levels look at: the network (block-uniform)
+#pragma unroll
+            for (int j = 0; j < KPT; j++)
+                if ((uint32_t)(t + NT * j) < n) k[GSR_PAD(t + NT * j)] = v[j];
+            __syncthreads();
+            return false;
+        }
+        uint32_t run2 = incl2 - loc;
+        for (int w = 0; w < wave; w++) run2 += wtot[w];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t lo16 = run2, hi16 = run2 + c2[2 * e];
+            offs[4 * t + e] = lo16 | (hi16 << 16);
+            run2 = hi16 + c2[2 * e + 1];
+        }
+    }
+    __syncthreads();
+    // placement: a counter is the next free position of its sub-bucket's slice (and the slice's end once every key is placed)
+#pragma unroll
+    for (int j = 0; j < KPT; j++)
+        if ((uint32_t)(t + NT * j) < n) {
+            const uint32_t sh = (idx[j] & 1u) * 16u;
+            k[(atomicAdd(&offs[idx[j] >> 1], 1u << sh) >> sh) & 0xffffu] = v[j];
+        }
+    __syncthreads();
+    // a key's place inside its sub-bucket (one key for most): its rank by counting; a slice starts where its predecessor ends
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+        uint32_t r = 0u;
+        if ((uint32_t)(t + NT * j) < n) {
+            const uint32_t en = (offs[idx[j] >> 1] >> ((idx[j] & 1u) * 16u)) & 0xffffu;
+            const uint32_t st = idx[j] ? (offs[(idx[j] - 1u) >> 1] >> (((idx[j] - 1u) & 1u) * 16u)) & 0xffffu : 0u;
+            r = st;
+            for (uint32_t i = st; i < en; i++) r += k[i] < v[j] ? 1u : 0u;
+        }
+        idx[j] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; j++)
+        if ((uint32_t)(t + NT * j) < n) k[idx[j]] = v[j];
+    __syncthreads();
     return true;
 }
 
 // LDS variant for lo < n <= hi (dynamic LDS = 8 * GSR_PAD(hi) bytes).  NT = 256 threads (8 keys each) for the lists up
 // to 2048, 1024 threads (16 keys each) for the class up to 16384.
 template <int NT>
-__global__ void __launch_bounds__(NT) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 8 : 4))) gsr_tile_sort_lds_kernel(const uint2* __restrict__ ranges,
                                                                const u64* __restrict__ seg_keys,
                                                                uint32_t* __restrict__ point_list,
                                                                uint8_t* __restrict__ slot_written, uint32_t lo,
@@ -836,7 +869,7 @@ __global__ void __launch_bounds__(NT) gsr_tile_sort_lds_kernel(const uint2* __re
 // still blending it says so (need_full[tile]) and the tile is redone after a full sort (gsr_launch_sort_fixup).
 // Fixed LDS (21 KiB) whatever the list length; a full bitonic sort of a 14 000-entry list needs 123 KiB and ~9x the
 // compare-exchanges.
-__global__ void __launch_bounds__(256) gsr_tile_sort_near_kernel(const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) gsr_tile_sort_near_kernel(const uint2* __restrict__ ranges,
                                                                  const u64* __restrict__ seg_keys,
                                                                  uint32_t* __restrict__ point_list,
                                                                  uint8_t* __restrict__ slot_written,

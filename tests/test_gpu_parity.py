@@ -242,17 +242,19 @@ def test_speculative_hint_exactly_at_the_partial_sort_cap():
         Hh.assert_images_close(ref[k], st[k], k)
 
 
-@pytest.mark.parametrize("clustered_frac", [0.3, 1.0])
+@pytest.mark.parametrize("clustered_frac", [0.3, 0.6, 1.0])
 def test_tile_sort_with_depth_clusters(clustered_frac):
     """The O(n) bucket sort of the tile lists spreads the keys over 1024 equal-width buckets of the tile's depth range;
     Gaussians sitting on a few exact depth planes put hundreds of keys into one bucket.  30 % of the cloud on two planes:
-    those buckets are sorted on their own; the whole cloud on eight planes: the tile falls back to the sorting network.
+    those buckets are sorted on their own; the whole cloud on eight planes: the tile falls back to the sorting network;
+    60 % on forty planes: dozens of buckets of 17 - 64 keys per tile, each sorted by one wave (rank by counting).
     The lists must equal the oracle's either way (ties on a plane -> ascending id)."""
     s = S.scene_config1(seed=35, P=4500, W=64, H=64, lateral=0.3)
     s["scales"] *= 0.5
     rng = np.random.default_rng(35)
     z = s["means3D"][:, 2]
-    planes = np.array([2.5, 4.0], np.float32) if clustered_frac < 1.0 else np.linspace(2.2, 5.8, 8).astype(np.float32)
+    planes = (np.array([2.5, 4.0], np.float32) if clustered_frac < 0.5 else
+              np.linspace(2.2, 5.8, 40 if clustered_frac < 1.0 else 8).astype(np.float32))
     pick = rng.random(z.shape[0]) < clustered_frac
     scale = np.where(pick, planes[rng.integers(0, len(planes), z.shape[0])] / z, 1.0).astype(np.float32)
     s["means3D"] = (s["means3D"] * scale[:, None]).astype(np.float32)  # same pixel, depth snapped to a plane
