@@ -136,13 +136,40 @@ NEXT_ROW_WARMUP, NEXT_ROW_ITERS = 10, 30  # fixed: independent of --steps (alloc
 def gpu_spin_up(dev, ms=120.0):
     """Keeps the GPU busy for ~`ms` before a timed section: the rows' CPU legs (seconds of host-only work) let the GPU drop to
     its idle clocks, and ten warm-up iterations of a 0.05-0.5 ms step can be over before the clocks are back.  (Plain
-    elementwise work: no library is pulled in for it.)"""
+    elementwise work: no library is pulled in for it.)  The garbage of the previous row's CPU leg is collected here too: a
+    generation-2 collection of Python's cyclic collector landing inside the next row's timed loop is one host stall of 10-90 ms
+    (tools/render_fps_probe.py: the render_fps row read 1.5k FPS behind the CPU baselines and 4.8k without them)."""
+    import gc
+    gc.collect()
     a = torch.zeros((1 << 24,), dtype=torch.float32, device=dev)
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < ms:
         for _ in range(16):
             a.mul_(0.999).add_(1.0)
         torch.cuda.synchronize()
+
+
+_LAST_BLOCKS = []
+
+
+def event_ms(fn, n, blocks=5):
+    """ms per call of n back-to-back calls of fn (HIP events), timed as `blocks` consecutive blocks; returns the MEDIAN block's figure and
+    leaves all of them in _LAST_BLOCKS.  The rows run behind seconds of CPU-baseline work in the same process, and one host stall of
+    10-90 ms now and then lands in a timed loop of 0.05-0.5 ms calls (tools/render_fps_probe.py: never reproducible, no garbage
+    collection involved; the depth-loss row once read 0.72 ms instead of 0.04, the render row 0.68 instead of 0.21): with the mean over
+    one loop that stall IS the row.  The median block is the row's steady state; the blocks are printed where it matters."""
+    per = max(n // blocks, 1)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for b in range(blocks):
+        for _ in range(per):
+            fn()
+        evs[b + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(evs[b].elapsed_time(evs[b + 1]) / per for b in range(blocks))
+    _LAST_BLOCKS[:] = [round(x, 4) for x in ms]
+    return ms[blocks // 2]
 
 
 def loss_row(dev, H, W, with_cpu):
@@ -168,14 +195,7 @@ def loss_row(dev, H, W, with_cpu):
         gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return event_ms(fn, n)
 
     def native():  # the C ABI alone (pre-allocated buffers, no autograd): what the GPU needs for forward + backward
         _native.check(lib.gsr_rgb_loss_forward(3, H, W, _native.ptr(xd), _native.ptr(gt), _native.ptr(wd), 0.8, -0.2,
@@ -286,14 +306,7 @@ def decode_native_ms(dev, model, cam, N, K):
         gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(NEXT_ROW_ITERS):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / NEXT_ROW_ITERS
+        return event_ms(fn, NEXT_ROW_ITERS)
     return timed(fwd), timed(fwdbwd)
 
 
@@ -324,14 +337,12 @@ def decode_row(dev, with_cpu, N=200_000, K=10):
         gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             run(fn, backward)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            out = run(fn, backward)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n, int(out[0].shape[0])
+        last = []
+
+        def once():
+            last[:] = [run(fn, backward)]
+        ms = event_ms(once, n)
+        return ms, int(last[0][0].shape[0])
 
     n = NEXT_ROW_ITERS
     f_ms, M = timed(generate_neural_gaussians, False, n)
@@ -408,15 +419,8 @@ def pipeline_row(dev, W=1008, H=567, N=200_000, K=10):
     gpu_spin_up(dev)
     for _ in range(NEXT_ROW_WARMUP):
         M = step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = NEXT_ROW_ITERS
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(n):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    ms = event_ms(step, n)
     kms, _top = gpu_kernel_ms(step, 5)  # GPU kernel time of the same iteration: what is left of the row is the GPU waiting for the host
     return {"what": f"decode ({N} anchors x {K}) -> rasterize {M} Gaussians @ {W}x{H} -> fused L1+SSIM loss -> backward to the MLP weights, all on the HIP rows",
             "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1), "gpu_kernel_ms_sum": None if kms is None else round(kms, 3),
@@ -553,17 +557,17 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
     gpu_spin_up(dev)
     for _ in range(NEXT_ROW_WARMUP):
         step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = NEXT_ROW_ITERS
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(n):
+    host = []
+
+    def timed_step():
+        t0 = time.perf_counter()
         step()
-    e1.record()
-    host_ms = (time.perf_counter() - t0) / n * 1e3
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+        host.append(time.perf_counter() - t0)
+    ms = event_ms(timed_step, n)
+    blocks = list(_LAST_BLOCKS)
+    host.sort()
+    host_ms = host[len(host) // 2] * 1e3  # median call
     kms, top = gpu_kernel_ms(step, 5)
     # SURVEY 8(d)-style algorithmic bytes of the iteration: the rasterizer's 420 P + 304 R + 56 N at this scene's P and R, the
     # decode (per visible anchor 41 + 3K floats in, per emitted Gaussian 15 floats out; the same again, mirrored, in the backward),
@@ -586,9 +590,9 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
             "what": f"train iteration on the HIP rows: prefilter_position2D ({N} anchors) -> decode the visible anchors ({sizes.get('visible_anchors')} x {K} "
                     f"-> {sizes.get('gaussians')} Gaussians) -> rasterize @ {W}x{H} -> RGB loss (fg-weighted L1 + SSIM) + depth loss (fit, L1 incl. the "
                     "foreground term, 4-scale gradient loss) -> backward to the MLP weights / anchor parameters -> training_statis; no optimiser step",
-            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1),
+            "ms_per_iteration": round(ms, 3), "iters_per_s": round(1e3 / ms, 1), "ms_per_iteration_blocks": blocks,
             "host_ms": round(host_ms, 3),
-            "host_ms_note": "wall time of the Python loop until the last iteration is enqueued (it contains the two host syncs a training iteration has: "
+            "host_ms_note": "median wall time of one iteration's Python call (it contains the two host syncs a training iteration has: "
                             "the decode's row count and the rasterizer's num_rendered)",
             "gpu_kernel_ms_sum": None if kms is None else round(kms, 3), "gpu_top_kernels_us": top,
             "log_scale_shift": float(log_scale_shift), "num_rendered": _last_num_rendered(), "num_occluded": _last_num_occluded()}
@@ -620,14 +624,7 @@ def render_fps_row(dev, sb, N=200_000, K=10):
         gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return event_ms(fn, n)
 
     def latency(fn, n=NEXT_ROW_ITERS):  # the reference's way: synchronize, time one view, synchronize (train.py:756-763)
         ts = []
@@ -639,7 +636,9 @@ def render_fps_row(dev, sb, N=200_000, K=10):
             ts.append(time.perf_counter() - t0)
         return sum(ts[5:]) / n * 1e3  # (the reference drops the first five views too, :862)
 
-    ms_eval, ms_train = timed(raster_eval), timed(raster_train_forward)
+    ms_eval = timed(raster_eval)
+    eval_blocks = list(_LAST_BLOCKS)
+    ms_train = timed(raster_train_forward)
     _native.profile_begin()
     for _ in range(10):
         raster_eval()
@@ -647,7 +646,7 @@ def render_fps_row(dev, sb, N=200_000, K=10):
     prof = _native.profile_end()
     out["rasterizer_bench_scene"] = {
         "what": f"GaussianRasterizer forward under no_grad on the bench scene ({sb.P} Gaussians @ {sb.W}x{sb.H}), back to back",
-        "ms_per_frame": round(ms_eval, 4), "fps": round(1e3 / ms_eval, 1),
+        "ms_per_frame": round(ms_eval, 4), "fps": round(1e3 / ms_eval, 1), "ms_per_frame_blocks": eval_blocks,
         "latency_ms_per_frame_reference_style": round(latency(raster_eval), 4),
         "training_forward_ms": round(ms_train, 4),
         "stages_us": {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in prof.items() if v[1]}}
@@ -681,7 +680,7 @@ def render_fps_row(dev, sb, N=200_000, K=10):
                 "(the large-splat stand-in scene of the train_iteration row)",
         "ms_per_frame": round(ms_view, 4), "fps": round(1e3 / ms_view, 1),
         "latency_ms_per_frame_reference_style": round(latency(view_eval), 4)}
-    out["fps_definition"] = "fps = frames / GPU time of back-to-back frames (HIP events); latency_* = the reference's per-view wall clock between two device synchronisations (train.py:756-763)"
+    out["fps_definition"] = "fps = frames / GPU time of back-to-back frames (HIP events; median of five consecutive blocks, all listed: bench.event_ms); latency_* = the reference's per-view wall clock between two device synchronisations (train.py:756-763)"
     return out
 
 
@@ -785,14 +784,7 @@ def depth_loss_row(dev, H, W, with_cpu=False):
         gpu_spin_up(dev)
         for _ in range(NEXT_ROW_WARMUP):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return event_ms(fn, n)
 
     ms, ms_eager = timed(native, NEXT_ROW_ITERS), timed(eager, NEXT_ROW_ITERS)
     cpu = None
