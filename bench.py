@@ -53,7 +53,17 @@ WORKLOADS = {
     "config4": (2_000_000, 1920, 1080, 3, (True, True, True),
                 "config4: 2M synthetic Gaussians, 1920x1080, fwd+bwd (HBM stress)"),
     "small": (50_000, 504, 284, 4, (True, True, True), "small: 50k Gaussians, 504x284 (plumbing check)"),
+    # not a BASELINE config: config 2's sizes on a cloud shaped like a trained scene (synthetic.scene_surfaces: surfaces + floaters;
+    # clustered depth keys, early saturation) -- a robustness probe for what the uniform slab does not exercise
+    "surfaces": (1_000_000, 1008, 567, 1, (True, False, False),
+                 "surfaces: 1M Gaussians on six tilted surfaces + 15 % floaters (synthetic.scene_surfaces, seed 1), 1008x567, fwd+bwd, "
+                 "RGB-only upstream grads; NOT a BASELINE config"),
 }
+
+
+def scene_for(workload, seed, P, W, H):
+    from gscream_amd import synthetic as S
+    return (S.scene_surfaces if workload == "surfaces" else S.scene_slab)(seed, P, W, H)
 
 
 def stage_algorithmic_bytes(P, R, N, T):
@@ -71,7 +81,7 @@ def stage_algorithmic_bytes(P, R, N, T):
     }
 
 
-def cpu_baseline(P, W, H, seed, gsel, budget_s=12.0):
+def cpu_baseline(P, W, H, seed, gsel, budget_s=12.0, workload="config2"):
     """Times oracle fwd+bwd (CPU port of the reference algorithm, OpenMP over tiles / Gaussians) on the host cores, on the
     SAME workload as the GPU line (same generator, size and upstream-gradient selection), for a bounded number of
     iterations (~budget_s of CPU work)."""
@@ -79,7 +89,7 @@ def cpu_baseline(P, W, H, seed, gsel, budget_s=12.0):
     from gscream_amd import synthetic as S
     from oracle import oracle as O
     threads = max(1, min(O.max_threads(), os.cpu_count() or 1, 64))
-    s = S.scene_slab(seed, P, W, H)
+    s = scene_for(workload, seed, P, W, H)
     grads = S.upstream_grads(seed, W, H, *gsel)
     st = Hh.oracle_forward(s, nthreads=threads)  # warm-up (page-in, thread pool)
     n, t0 = 0, time.perf_counter()
@@ -856,10 +866,10 @@ def load_pmc(workload):
 class SceneBench:
     """One synthetic scene resident in HBM + the step closure (one forward + one full backward through the public API)."""
 
-    def __init__(self, dev, P, W, H, scene_seed, grad_seed, gsel):
+    def __init__(self, dev, P, W, H, scene_seed, grad_seed, gsel, workload="config2"):
         from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer
         from gscream_amd import synthetic as S
-        s = S.scene_slab(scene_seed, P, W, H)
+        s = scene_for(workload, scene_seed, P, W, H)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.leaves = [t(s[k]).requires_grad_(True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")]
         self.means2D = torch.zeros_like(self.leaves[0], requires_grad=True)
@@ -1013,7 +1023,7 @@ def main():
         return
 
     P, W, H, seed, gsel, desc = WORKLOADS[args.workload]
-    sb = SceneBench(dev, P, W, H, multi.scene_seed(seed, rank, world), seed, gsel)  # one independent scene per GPU
+    sb = SceneBench(dev, P, W, H, multi.scene_seed(seed, rank, world), seed, gsel, args.workload)  # one independent scene per GPU
     step, rs = sb.step, sb.rs
     means3D, opac, unc, colors, scales, rots = sb.leaves
 
@@ -1163,7 +1173,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["strict_parity_build"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["parity_check"], out["cpu_baseline"] = cpu_baseline(P, W, H, multi.scene_seed(seed, rank, world), gsel, args.cpu_budget)
+            out["parity_check"], out["cpu_baseline"] = cpu_baseline(P, W, H, multi.scene_seed(seed, rank, world), gsel, args.cpu_budget, args.workload)
             out["cpu_torch_naive"] = cpu_torch_naive()
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -103,6 +103,37 @@ def scene_slab(seed, P, W, H, tanfovx=0.6, bg=(0.0, 0.0, 0.0), scale_mu=0.01, sc
         bg=np.asarray(bg, np.float32), scale_modifier=1.0)
 
 
+def scene_surfaces(seed, P, W, H, tanfovx=0.6, bg=(0.0, 0.0, 0.0), scale_mu=0.01, scale_sigma=0.6, n_surfaces=6, floaters=0.15):
+    """A cloud shaped like a TRAINED scene rather than a uniform slab: 85 % of the Gaussians lie on a few tilted, slightly wavy surfaces
+    (depth jitter 0.5 % of the surface depth, opacity U(0.3, 1)), the rest are slab-like floaters.  Per-tile depth keys cluster around
+    the surface depths and the front surface saturates most pixels early: the regime the per-tile sort and the depth-ordered walks see
+    in training, which the uniform slab of configs 2 - 4 does not exercise.  Same camera, scales and lateral overshoot as scene_slab."""
+    rng = np.random.default_rng(seed)
+    tanfovy = tanfovx * H / W
+    u = rng.uniform(-1.15, 1.15, size=P)
+    v = rng.uniform(-1.15, 1.15, size=P)
+    z0 = np.sort(rng.uniform(2.0, 7.0, size=n_surfaces))
+    tilt = rng.uniform(-0.6, 0.6, size=(n_surfaces, 2))
+    wav = rng.uniform(0.0, 0.15, size=n_surfaces)
+    which = rng.integers(0, n_surfaces, size=P)
+    z = z0[which] + tilt[which, 0] * u + tilt[which, 1] * v + wav[which] * np.sin(5.0 * u + 3.0 * v)
+    z = z * (1.0 + 0.005 * rng.normal(size=P))
+    fl = rng.random(P) < floaters
+    z = np.where(fl, rng.uniform(1.5, 8.0, size=P), np.clip(z, 1.2, 9.0))
+    x, y = u * tanfovx * z, v * tanfovy * z
+    opac = np.where(fl, rng.uniform(0, 1, size=P) ** 2, rng.uniform(0.3, 1.0, size=P))
+    view, proj, campos = camera_matrices(tanfovx, tanfovy)
+    return dict(
+        means3D=np.stack([x, y, z], 1).astype(np.float32),
+        scales=np.exp(rng.normal(math.log(scale_mu), scale_sigma, size=(P, 3))).astype(np.float32),
+        rotations=_quats(rng, P),
+        opacities=opac.reshape(P, 1).astype(np.float32),
+        uncertainties=rng.uniform(0, 1, size=(P, 1)).astype(np.float32),
+        colors=rng.uniform(0, 1, size=(P, 3)).astype(np.float32),
+        W=W, H=H, tanfovx=float(tanfovx), tanfovy=float(tanfovy), viewmatrix=view, projmatrix=proj, campos=campos,
+        bg=np.asarray(bg, np.float32), scale_modifier=1.0)
+
+
 def scene_stack(seed=5, P=1500, n_stack=700, W=112, H=71):
     """SURVEY 8(c) fixture 5: many Gaussians stacked on the centre pixel (multi-batch tile lists,
     T < 1e-4 early stop) on a non-multiple-of-16 image."""

@@ -93,6 +93,6 @@ for wl in sys.argv[1:] or ["config2", "config4", "train_iteration"]:
         rasterizer.set_tuning(occlusion_cut=None)
     else:
         P, W, H, seed, gsel, desc = B.WORKLOADS[wl]
-        sb = B.SceneBench(dev, P, W, H, seed, seed, gsel)
+        sb = B.SceneBench(dev, P, W, H, seed, seed, gsel, wl)
         sb.step()
         report(wl)
