@@ -40,7 +40,7 @@ def main():
         if os.environ.get("FUZZ_KNOBS"):
             # round 4: the performance knobs must not change one output bit -- occlusion cut-off forced on (it works on the tile-cull
             # masks: a no-op with culling off), the scatter forced into bands of tile rows, the two-stage forward
-            for knobs in (dict(occlusion_cut=True, scatter_bands=3), dict(occlusion_cut=True, scatter_bands=2, speculative=False)):
+            for knobs in (dict(occlusion_cut=True, scatter_bands=3, heavy_groups=True), dict(occlusion_cut=True, scatter_bands=2, speculative=False, heavy_groups=False)):
                 set_tuning(tile_cull=bool(c % 2), **knobs)
                 alt = Hh.hip_run(s, grads)
                 for k in got:
