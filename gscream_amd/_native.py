@@ -93,8 +93,9 @@ def load():
     lib.gsr_mark_visible.argtypes = [_c_int] + [_vp] * 5
     lib.gsr_profile_begin.restype = _c_int
     lib.gsr_profile_begin.argtypes = [ctypes.c_uint]
-    lib.gsr_profile_begin_sampled.restype = _c_int
-    lib.gsr_profile_begin_sampled.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    if hasattr(lib, "gsr_profile_begin_sampled") or not os.environ.get("GSR_SKIP_ABI_CHECK"):  # (absent from an older build in an A/B run)
+        lib.gsr_profile_begin_sampled.restype = _c_int
+        lib.gsr_profile_begin_sampled.argtypes = [ctypes.c_uint, ctypes.c_uint]
     lib.gsr_profile_end.restype = _c_int
     lib.gsr_profile_end.argtypes = [ctypes.POINTER(Profile)]
     lib.gsr_stage_name.restype = ctypes.c_char_p
@@ -145,7 +146,11 @@ def profile_begin(stages=None, every=1):
     """Start timing stages with HIP events (all stages, or only the named ones to keep the stream undisturbed; every = n
     times only every n-th invocation of a stage)."""
     mask = 0 if not stages else sum(1 << STAGE_NAMES.index(s) for s in stages)
-    check(load().gsr_profile_begin_sampled(mask, int(every)), "gsr_profile_begin_sampled")
+    lib = load()
+    if os.environ.get("GSR_SKIP_ABI_CHECK") and not hasattr(lib, "gsr_profile_begin_sampled"):  # an older library in an A/B run (tools/gpu_ab_r3.sh)
+        check(lib.gsr_profile_begin(mask), "gsr_profile_begin")
+        return
+    check(lib.gsr_profile_begin_sampled(mask, int(every)), "gsr_profile_begin_sampled")
 
 
 def profile_end():
