@@ -164,6 +164,29 @@ def test_slab_scene_against_live_oracle(P, W, H, seed):
     _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
 
 
+def test_surface_scene_against_live_oracle():
+    """A cloud shaped like a trained scene (synthetic.scene_surfaces, the bench's `surfaces` workload scaled down): 85 % of the
+    Gaussians on six thin surfaces -- per-tile depth keys in clusters (the tile sort's second counting level does the work), the
+    front surface saturates most pixels early (short walks, many threshold decisions near T = 1e-4)."""
+    P, W, H, seed = 90_000, 504, 284, 31
+    s = S.scene_surfaces(seed, P, W, H)
+    grads = S.upstream_grads(seed, W, H)
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    st = Hh.oracle_forward(s, nthreads=nthreads)
+    ref = Hh.oracle_backward(s, st, grads, nthreads=nthreads)
+    got = Hh.hip_run(s, grads)
+    assert (got["radii"] == st["radii"]).all()
+    for k in ("out_color", "out_depth", "out_unc"):
+        Hh.assert_images_close(got[k], st[k], k)
+    Hh.assert_grads_close(got, ref, context="surfaces")
+    kept, dropped = _check_culled_binning(s, Hh.hip_run(s, keep_state=True), st)
+    assert kept + dropped == st["num_rendered"]
+    set_tuning(tile_cull=False)
+    g2 = Hh.hip_run(s, keep_state=True)
+    assert g2["num_rendered"] == st["num_rendered"]
+    _check_binning(s, g2, st["point_list"], st["ranges"][:, 1] - st["ranges"][:, 0])
+
+
 @pytest.mark.parametrize("P,W,H,expect_class", [(14_000, 32, 32, "large"), (40_000, 32, 16, "global")])
 def test_long_tile_lists_use_the_big_sort_paths(P, W, H, expect_class):
     """Tiny image + big cloud: per-tile lists beyond the 4096-entry LDS sort (-> 128 KiB LDS variant) and beyond
