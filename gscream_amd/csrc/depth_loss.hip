@@ -10,7 +10,7 @@
 // absent).  The gradient flows through the fit as well, as it does through the reference's autograd graph:
 //   dL/dd = s G + m (A + B d + C y),   G = dL/da per pixel,  A, B, C scalars of (sum G, sum G d, the normal equations).
 // The torch path is ~60 small kernels (slicing, masked products, four pyramids, two reductions each) + their autograd
-// mirror; here: one pass of sums, one stencil pass producing G, one pass for the gradient, and two one-block finishers.
+// mirror; here: one pass of sums, one stencil pass producing G (the fit in its prologue), one one-block finisher, one pass for the gradient.
 // All sums are per-workgroup partials in double finished in a fixed order: bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,14 +30,39 @@ struct GdlParams {  // device-resident scalars shared by the passes
     float loss, l1_mean, smooth, pad2;
 };
 
-__device__ __forceinline__ double gdl_block_sum(double v, double* red /*[4]*/)
+// Workgroup sums of NV values with ONE barrier: lanes by xor-shuffle, then the four waves in order; the totals end up in tot[NV]
+// (LDS), valid for every thread after the call.  (The first version reduced one value at a time, two barriers each: the sums kernel
+// spent its time in 18 barriers, the one-block finishers in 9 dependent rounds of strided loads.)
+template <int NV>
+__device__ __forceinline__ void gdl_block_sums(double (&v)[NV], double* red /*[NV * 4]*/, double* tot /*[NV]*/)
 {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    for (int i = 0; i < NV; i++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[i] += __shfl_xor(v[i], d, 64);
+        if ((threadIdx.x & 63) == 0) red[i * 4 + (threadIdx.x >> 6)] = v[i];
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if (threadIdx.x < NV) tot[threadIdx.x] = ((red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + red[threadIdx.x * 4 + 2]) + red[threadIdx.x * 4 + 3];
     __syncthreads();
-    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// Totals of the per-workgroup partials part[nparts][NV] (one block): every thread takes whole rows (NV independent loads each,
+// rows t, t + 256, ... in order), then one workgroup sum.
+template <int NV>
+__device__ __forceinline__ void gdl_total_partials(int nparts, const double* __restrict__ part, double* red, double* tot)
+{
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += GDL_THREADS) {
+        double r[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) r[i] = part[(size_t)b * NV + i];
+#pragma unroll
+        for (int i = 0; i < NV; i++) v[i] += r[i];
+    }
+    gdl_block_sums<NV>(v, red, tot);
 }
 
 // pass 1: normal-equation sums over the fit mask, and the gradient-mask sums of the four lattices
@@ -46,7 +71,7 @@ __global__ void __launch_bounds__(GDL_THREADS) gdl_sums_kernel(int H, int W, con
                                                                const float* __restrict__ lsq_mask,
                                                                const float* __restrict__ grad_mask, double* __restrict__ part)
 {
-    __shared__ double red[4];
+    __shared__ double red[(5 + GDL_SCALES) * 4], tot[5 + GDL_SCALES];
     double acc[5 + GDL_SCALES] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     const int N = H * W;
     for (int p = blockIdx.x * GDL_THREADS + threadIdx.x; p < N; p += gridDim.x * GDL_THREADS) {
@@ -59,39 +84,28 @@ __global__ void __launch_bounds__(GDL_THREADS) gdl_sums_kernel(int H, int W, con
         for (int k = 0; k < GDL_SCALES; k++)
             if (((x | yy) & ((1 << k) - 1)) == 0) acc[5 + k] += (double)g;
     }
-    for (int i = 0; i < 5 + GDL_SCALES; i++) {
-        const double s = gdl_block_sum(acc[i], red);
-        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (5 + GDL_SCALES) + i] = s;
-    }
+    gdl_block_sums<5 + GDL_SCALES>(acc, red, tot);
+    if (threadIdx.x < 5 + GDL_SCALES) part[(size_t)blockIdx.x * (5 + GDL_SCALES) + threadIdx.x] = tot[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(GDL_THREADS) gdl_fit_kernel(int nparts, int H, int W, const double* __restrict__ part,
-                                                              float lambda_l1, float lambda_smooth, GdlParams* __restrict__ P)
+// the least-squares fit and the constants of the passes from the totals of pass 1 (one thread)
+__device__ __forceinline__ GdlParams gdl_fit(const double* tot /*[5 + GDL_SCALES]*/, int H, int W, float lambda_l1, float lambda_smooth)
 {
-    __shared__ double red[4];
-    double tot[5 + GDL_SCALES];
-    for (int i = 0; i < 5 + GDL_SCALES; i++) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < nparts; b += GDL_THREADS) v += part[(size_t)b * (5 + GDL_SCALES) + i];
-        tot[i] = gdl_block_sum(v, red);
+    GdlParams q;
+    q.a00 = tot[0]; q.a01 = tot[1]; q.a11 = tot[2]; q.b0 = tot[3]; q.b1 = tot[4];
+    q.det = q.a00 * q.a11 - q.a01 * q.a01;                       // loss_utils.py:97
+    q.s0 = q.det != 0.0 ? (q.a11 * q.b0 - q.a01 * q.b1) / q.det : 0.0;   // :100
+    q.t = q.det != 0.0 ? (-q.a01 * q.b0 + q.a00 * q.b1) / q.det : 0.0;   // :101
+    q.s = (float)fabs(q.s0);                                      // train.py:552
+    q.sgn = q.s0 > 0.0 ? 1.f : (q.s0 < 0.0 ? -1.f : 0.f);
+    q.shift = (float)q.t;
+    for (int k = 0; k < GDL_SCALES; k++) {
+        q.Ms[k] = tot[5 + k];
+        q.cs[k] = q.Ms[k] != 0.0 ? (float)(0.5 * (double)lambda_smooth / q.Ms[k]) : 0.f;  // :40-49
     }
-    if (threadIdx.x == 0) {
-        GdlParams q;
-        q.a00 = tot[0]; q.a01 = tot[1]; q.a11 = tot[2]; q.b0 = tot[3]; q.b1 = tot[4];
-        q.det = q.a00 * q.a11 - q.a01 * q.a01;                       // loss_utils.py:97
-        q.s0 = q.det != 0.0 ? (q.a11 * q.b0 - q.a01 * q.b1) / q.det : 0.0;   // :100
-        q.t = q.det != 0.0 ? (-q.a01 * q.b0 + q.a00 * q.b1) / q.det : 0.0;   // :101
-        q.s = (float)fabs(q.s0);                                      // train.py:552
-        q.sgn = q.s0 > 0.0 ? 1.f : (q.s0 < 0.0 ? -1.f : 0.f);
-        q.shift = (float)q.t;
-        for (int k = 0; k < GDL_SCALES; k++) {
-            q.Ms[k] = tot[5 + k];
-            q.cs[k] = q.Ms[k] != 0.0 ? (float)(0.5 * (double)lambda_smooth / q.Ms[k]) : 0.f;  // :40-49
-        }
-        q.cl1 = (float)((double)lambda_l1 / ((double)H * (double)W));
-        q.A = q.B = q.C = q.loss = q.l1_mean = q.smooth = q.pad = q.pad2 = 0.f;
-        *P = q;
-    }
+    q.cl1 = (float)((double)lambda_l1 / ((double)H * (double)W));
+    q.A = q.B = q.C = q.loss = q.l1_mean = q.smooth = q.pad = q.pad2 = 0.f;
+    return q;
 }
 
 __device__ __forceinline__ float gdl_sign(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -101,22 +115,35 @@ __global__ void __launch_bounds__(GDL_THREADS) gdl_stencil_kernel(int H, int W, 
                                                                   const float* __restrict__ target,
                                                                   const float* __restrict__ l1_weight,
                                                                   const float* __restrict__ grad_mask,
-                                                                  const GdlParams* __restrict__ P, float* __restrict__ G,
+                                                                  int nparts1, const double* __restrict__ part1, float lambda_l1,
+                                                                  float lambda_smooth, GdlParams* __restrict__ P, float* __restrict__ G,
                                                                   double* __restrict__ part)
 {
-    __shared__ double red[4];
-    const float s = P->s, t = P->shift, cl1 = P->cl1;
+    __shared__ double red[(5 + GDL_SCALES) * 4], tot[5 + GDL_SCALES];
+    __shared__ GdlParams sq;
+    // The fit is folded in: EVERY workgroup totals the partials of pass 1 (nparts1 x 9 doubles, L2 hits; the same fixed order
+    // everywhere, so all of them get the same bits) and solves the 2 x 2 system -- a launch of its own for that cost 4.6 us between two
+    // kernels of 6 and 17.  Workgroup 0 leaves the parameters for the finisher and the backward.
+    gdl_total_partials<5 + GDL_SCALES>(nparts1, part1, red, tot);
+    if (threadIdx.x == 0) {
+        sq = gdl_fit(tot, H, W, lambda_l1, lambda_smooth);
+        if (blockIdx.x == 0) *P = sq;
+    }
+    __syncthreads();
+    const float s = sq.s, t = sq.shift, cl1 = sq.cl1;
     float cs[GDL_SCALES];
 #pragma unroll
-    for (int k = 0; k < GDL_SCALES; k++) cs[k] = P->cs[k];
+    for (int k = 0; k < GDL_SCALES; k++) cs[k] = sq.cs[k];
+    __syncthreads();  // (red / tot are used again for this pass's own sums)
     double acc[3 + GDL_SCALES] = { 0, 0, 0, 0, 0, 0, 0 };  // l1 sum, sum G, sum G d, edge sums per scale
-    const int N = H * W;
     auto diff = [&](int x, int y) {  // g (a - y) at a pixel (gradient_loss :62-63)
         const int q = y * W + x;
         const float gm = grad_mask ? grad_mask[q] : 1.0f;
         return gm * ((s * depth[q] + t) - target[q]);
     };
     auto gm_at = [&](int x, int y) { return grad_mask ? grad_mask[y * W + x] : 1.0f; };
+    // (a 2-D walk -- 256-pixel row segments per workgroup, no division per pixel -- was measured: 21.5 instead of 17.5 us)
+    const int N = H * W;
     for (int p = blockIdx.x * GDL_THREADS + threadIdx.x; p < N; p += gridDim.x * GDL_THREADS) {
         const int x = p % W, y = p / W;
         const float d = depth[p], r = (s * d + t) - target[p];
@@ -153,22 +180,15 @@ __global__ void __launch_bounds__(GDL_THREADS) gdl_stencil_kernel(int H, int W, 
         acc[1] += (double)g;
         acc[2] += (double)g * (double)d;
     }
-    for (int i = 0; i < 3 + GDL_SCALES; i++) {
-        const double v = gdl_block_sum(acc[i], red);
-        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (3 + GDL_SCALES) + i] = v;
-    }
+    gdl_block_sums<3 + GDL_SCALES>(acc, red, tot);
+    if (threadIdx.x < 3 + GDL_SCALES) part[(size_t)blockIdx.x * (3 + GDL_SCALES) + threadIdx.x] = tot[threadIdx.x];
 }
 
 __global__ void __launch_bounds__(GDL_THREADS) gdl_finish_kernel(int nparts, int H, int W, const double* __restrict__ part,
                                                                  float lambda_l1, GdlParams* __restrict__ P, float* __restrict__ out)
 {
-    __shared__ double red[4];
-    double tot[3 + GDL_SCALES];
-    for (int i = 0; i < 3 + GDL_SCALES; i++) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < nparts; b += GDL_THREADS) v += part[(size_t)b * (3 + GDL_SCALES) + i];
-        tot[i] = gdl_block_sum(v, red);
-    }
+    __shared__ double red[(3 + GDL_SCALES) * 4], tot[3 + GDL_SCALES];
+    gdl_total_partials<3 + GDL_SCALES>(nparts, part, red, tot);
     if (threadIdx.x == 0) {
         GdlParams q = *P;
         const double l1_mean = tot[0] / ((double)H * (double)W);
@@ -204,7 +224,9 @@ __global__ void __launch_bounds__(GDL_THREADS) gdl_backward_kernel(int N, const 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
+#ifndef GDL_BLOCKS
 #define GDL_BLOCKS 512
+#endif
 struct GdlWorkspace {
     float* G;
     double *part1, *part2;
@@ -233,11 +255,10 @@ hipError_t gdl_launch_forward(int H, int W, const float* depth, const float* tar
     const GdlWorkspace w = gdl_carve(workspace, H, W);
     const int N = H * W;
     int nb = (N + GDL_THREADS - 1) / GDL_THREADS;
-    if (nb > GDL_BLOCKS) nb = GDL_BLOCKS;
+    if (nb > GDL_BLOCKS) nb = GDL_BLOCKS;  // (1024 / 2304 workgroups measured: no change / slower)
     hipLaunchKernelGGL(gdl_sums_kernel, dim3(nb), dim3(GDL_THREADS), 0, stream, H, W, depth, target, lsq_mask, grad_mask, w.part1);
-    hipLaunchKernelGGL(gdl_fit_kernel, dim3(1), dim3(GDL_THREADS), 0, stream, nb, H, W, w.part1, lambda_l1, lambda_smooth, w.params);
     hipLaunchKernelGGL(gdl_stencil_kernel, dim3(nb), dim3(GDL_THREADS), 0, stream, H, W, depth, target, l1_weight, grad_mask,
-                       w.params, w.G, w.part2);
+                       nb, w.part1, lambda_l1, lambda_smooth, w.params, w.G, w.part2);
     hipLaunchKernelGGL(gdl_finish_kernel, dim3(1), dim3(GDL_THREADS), 0, stream, nb, H, W, w.part2, lambda_l1, w.params, out5);
     return hipGetLastError();
 }

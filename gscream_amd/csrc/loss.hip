@@ -10,8 +10,8 @@
 // means over C*H*W like torch's .mean() of the broadcast product.
 //
 // Mapping.  One 256-thread workgroup per 32x16 pixel tile and channel.  The (32+10)x(16+10) halo of both images is
-// staged in LDS once; the 2-D window is separable, so a horizontal pass produces five row-filtered planes
-// (x, y, x^2, y^2, xy) in LDS and a vertical pass finishes them per pixel: 16 taps-equivalents per quantity instead
+// staged in LDS once; the 2-D window is separable, so a horizontal pass produces four row-filtered planes
+// (x, y, x^2 + y^2, xy) in LDS and a vertical pass finishes them per pixel: 16 taps-equivalents per quantity instead
 // of 121, no intermediate image ever reaches HBM (the torch path writes 5 convolved planes + ~10 elementwise
 // temporaries per call).  The forward also emits the three partial-derivative planes the backward needs
 // (d/d mu1, d/d E[x^2], d/d E[xy] of the weighted map); the backward filters those with the same two passes and
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) gsl_forward_kernel(int H, int W, const fl
 {
     const float* GSL_G = taps.g;
     __shared__ float sx[GSL_HH][GSL_HW + 1], sy[GSL_HH][GSL_HW + 1];
-    __shared__ float hx[5][GSL_HH][GSL_TW];
+    __shared__ float hx[4][GSL_HH][GSL_TW];
     __shared__ double red[2][4];
     const int t = threadIdx.x, ch = blockIdx.z;
     const int x0 = blockIdx.x * GSL_TW, y0 = blockIdx.y * GSL_TH;
@@ -83,49 +83,51 @@ __global__ void __launch_bounds__(256) gsl_forward_kernel(int H, int W, const fl
         float xs[14], ys[14];
 #pragma unroll
         for (int k = 0; k < 14; k++) { xs[k] = sx[r][c + k]; ys[k] = sy[r][c + k]; }
-        float s1[4] = { 0, 0, 0, 0 }, s2[4] = { 0, 0, 0, 0 }, s11[4] = { 0, 0, 0, 0 }, s22[4] = { 0, 0, 0, 0 }, s12[4] = { 0, 0, 0, 0 };
+        // FOUR filtered quantities, not five: the map needs sigma1^2 + sigma2^2 = E[x^2 + y^2] - mu1^2 - mu2^2 and sigma12 = E[xy] - mu1 mu2,
+        // never E[x^2] and E[y^2] apart (and d ssim / d E[x^2] = d ssim / d E[x^2 + y^2]: the backward's planes are unchanged)
+        float s1[4] = { 0, 0, 0, 0 }, s2[4] = { 0, 0, 0, 0 }, sS[4] = { 0, 0, 0, 0 }, s12[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int k = 0; k < 14; k++) {
-            const float x = xs[k], y = ys[k], xx = x * x, yy = y * y, xy = x * y;
+            const float x = xs[k], y = ys[k], ss = x * x + y * y, xy = x * y;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int tap = k - o;
                 if (tap >= 0 && tap < 11) {
                     const float g = GSL_G[tap];
-                    s1[o] += g * x; s2[o] += g * y; s11[o] += g * xx; s22[o] += g * yy; s12[o] += g * xy;
+                    s1[o] += g * x; s2[o] += g * y; sS[o] += g * ss; s12[o] += g * xy;
                 }
             }
         }
 #pragma unroll
         for (int o = 0; o < 4; o++) {
-            hx[0][r][c + o] = s1[o]; hx[1][r][c + o] = s2[o]; hx[2][r][c + o] = s11[o]; hx[3][r][c + o] = s22[o]; hx[4][r][c + o] = s12[o];
+            hx[0][r][c + o] = s1[o]; hx[1][r][c + o] = s2[o]; hx[2][r][c + o] = sS[o]; hx[3][r][c + o] = s12[o];
         }
     }
     __syncthreads();
     double l1sum = 0.0, ssum = 0.0;
     // vertical pass: a thread finishes two vertically adjacent pixels from a 12-row register window
     const int vc = t % GSL_TW, vr = (t / GSL_TW) * 2;
-    float col[5][12];
+    float col[4][12];
 #pragma unroll
-    for (int q = 0; q < 5; q++)
+    for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int k = 0; k < 12; k++) col[q][k] = hx[q][vr + k][vc];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int r = vr + half, c = vc;
         const int px = x0 + c, py = y0 + r;
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        float mu1 = 0.f, mu2 = 0.f, eS = 0.f, e12 = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
             const float g = GSL_G[k];
             mu1 += g * col[0][half + k]; mu2 += g * col[1][half + k];
-            e11 += g * col[2][half + k]; e22 += g * col[3][half + k]; e12 += g * col[4][half + k];
+            eS += g * col[2][half + k]; e12 += g * col[3][half + k];
         }
         if (px < W && py < H) {
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // loss_utils.py:153-154
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
-            const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
+            const float sig12 = e12 - mu12;
+            const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = (eS - mu1_sq - mu2_sq) + C2;
             const float inv = 1.0f / (Cc * D);
             const float ssim = A * B * inv;
             const float m = weight ? weight[(size_t)py * W + px] : 1.0f;
@@ -159,17 +161,16 @@ __global__ void __launch_bounds__(256) gsl_forward_kernel(int H, int W, const fl
 __global__ void __launch_bounds__(256) gsl_finish_kernel(int nparts, const GslPartial* __restrict__ partial, double count,
                                                          float a_l1, float a_ssim, float* __restrict__ out)
 {
-    __shared__ double red[2][256];
+    __shared__ double red[2][4];
     double l1 = 0.0, ss = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) { l1 += partial[i].l1; ss += partial[i].ssim; }
-    red[0][threadIdx.x] = l1; red[1][threadIdx.x] = ss;
+    // (lanes by xor-shuffle, then the four waves: one barrier instead of the eight of an LDS tree)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d, 64); ss += __shfl_xor(ss, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l1; red[1][threadIdx.x >> 6] = ss; }
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        const double ml1 = red[0][0] / count, mss = red[1][0] / count;
+        const double ml1 = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / count, mss = (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / count;
         out[0] = (float)((double)a_l1 * ml1 + (double)a_ssim * mss);
         out[1] = (float)ml1;
         out[2] = (float)mss;
