@@ -161,3 +161,26 @@ def test_naive_torch_f32_matches_oracle_on_config1():
     assert (radii.numpy() != st["radii"]).sum() <= 2
     Hh.assert_images_close(C.numpy(), st["out_color"], "color", max_outlier_frac=1e-3)
     Hh.assert_images_close(U.numpy(), st["out_unc"], "unc", max_outlier_frac=1e-3)
+
+
+def test_surface_scene_generator_is_what_its_workload_says():
+    """synthetic.scene_surfaces (bench.py --workload surfaces, test_surface_scene_against_live_oracle): deterministic, slab-compatible
+    fields, most Gaussians within a percent of a surface depth (the per-tile depth clusters it exists for), earlier saturation in the
+    oracle's render (mean final transmittance below the slab's at the same size)."""
+    a, b = S.scene_surfaces(3, 20_000, 252, 142), S.scene_surfaces(3, 20_000, 252, 142)
+    slab = S.scene_slab(3, 20_000, 252, 142)
+    assert set(a) == set(slab) and all(np.array_equal(a[k], b[k]) for k in a if isinstance(a[k], np.ndarray))
+    assert all(a[k].shape == slab[k].shape and a[k].dtype == slab[k].dtype for k in a if isinstance(a[k], np.ndarray))
+    assert 0.0 <= a["opacities"].min() and a["opacities"].max() <= 1.0 and a["means3D"][:, 2].min() > 1.0
+    import bench as B
+    assert B.scene_for("surfaces", 3, 100, 64, 64)["means3D"].shape == (100, 3) and "surfaces" in B.WORKLOADS
+    assert np.array_equal(B.scene_for("config2", 3, 100, 64, 64)["means3D"], S.scene_slab(3, 100, 64, 64)["means3D"])
+    st, st_slab = Hh.oracle_forward(a, nthreads=4), Hh.oracle_forward(slab, nthreads=4)
+    assert st["final_T"].mean() < 0.85 * st_slab["final_T"].mean()
+    # depth keys of a tile's list cluster: the median gap between neighbouring depths is far below the uniform slab's
+    def median_rel_gap(s, st):
+        r = st["ranges"]
+        t = int(np.argmax(r[:, 1] - r[:, 0]))
+        z = np.sort(st["depths"][st["point_list"][r[t, 0]:r[t, 1]]].astype(np.float64))
+        return float(np.median(np.diff(z)) / (z[-1] - z[0]))
+    assert median_rel_gap(a, st) < 0.5 * median_rel_gap(slab, st_slab)
