@@ -53,11 +53,12 @@ def image_views(buf, P, W, H):
     out["sorted_len"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["need_full"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     Np = (N + 3) & ~3
-    out["ckpt"] = _take(buf, off, CKPT_PLANES * Np * 4, torch.float32, (SEG_MAX, 6 * Np)); off += _align(CKPT_PLANES * Np * 4)
+    nocc = 8 * T * OCC_BUCKETS if T <= 8192 else 1   # occlusion cut-off: occ_mass x 8 XCD copies ALIASES the checkpoint area (gsr_common.h)
+    out["ckpt"] = _take(buf, off, CKPT_PLANES * Np * 4, torch.float32, (SEG_MAX, 6 * Np))
+    out["occ_mass"] = _take(buf, off, nocc * 4, torch.int32, (nocc,))
+    off += _align(max(CKPT_PLANES * Np * 4, nocc * 4))
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
     out["qresume"] = _take(buf, off, 4 * T * 4, torch.int32, (4 * T,)); off += _align(4 * T * 4)
-    nocc = 8 * T * OCC_BUCKETS if T <= 8192 else 1   # occlusion cut-off (gsr_common.h: occ_mass x 8 XCD copies, occ_cut, occ_drop)
-    out["occ_mass"] = _take(buf, off, nocc * 4, torch.int32, (nocc,)); off += _align(nocc * 4)
     out["occ_cut"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["occ_drop"] = _take(buf, off, 256 * 4, torch.int32, (256,)); off += _align(256 * 4)
     out["tile_group"] = _take(buf, off, (T // 64 + 1) * 4, torch.int32, (T // 64 + 1,)); off += _align((T // 64 + 1) * 4)

@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
         for (int k = 0; k < U; k++) {
             const int g = gb + k * blockDim.x;
             rcs[k] = g < hi ? rect[g] : make_uint2(0u, 0u);
-            mks[k] = g < hi ? tmask[g] : 0ull;
+            // (OCC: this kernel also STORES the masks, through oc.tmask_rw -- the same buffer -- so it reads them through that pointer
+            // too: a load through the __restrict__ const view may legally be re-issued after the store)
+            mks[k] = g < hi ? (OCC ? oc.tmask_rw[g] : tmask[g]) : 0ull;
             bks[k] = (OCC && g < hi) ? gsr_occ_bucket(oc.depthkey[g]) : 0u;
         }
 #pragma unroll
@@ -96,11 +98,11 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_tile_hist_kernel(int P, 
                 if (d) {
                     const int g = gb + k * blockDim.x;
                     const u64 nm = mks[k] & ~d;
+                    dropped += (uint32_t)__popcll(mks[k] & d);
                     oc.tmask_rw[g] = nm;
                     oc.tiles[g] = gsr_rect_count(rcs[k], nm);
                     uint2* rd = reinterpret_cast<uint2*>(&oc.rec[g].d.z);
                     *rd = make_uint2((uint32_t)nm, (uint32_t)(nm >> 32));
-                    dropped += (uint32_t)__popcll(mks[k] & d);
                 }
             }
         }

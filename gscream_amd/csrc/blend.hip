@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 #ifndef GSR_PRECISE_MATH
                         unsigned long long banda = 0ull, bandb = 0ull;
                         // (a second copy of the loop body without this test for batches with no flagged instance: no gain, 161 vs 158.5 us)
-                        if ((bandm64 >> j) & 1ull) {  // wave-uniform (j is scalar): the forward flagged this instance
+                        if (SL != 64 || ((bandm64 >> (j & 63)) & 1ull)) {  // wave-uniform (j is scalar): the forward flagged this instance
                             banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & okma;
                             bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & okmb;
                         }

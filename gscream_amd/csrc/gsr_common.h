@@ -171,10 +171,20 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.sorted_len = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.need_full = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.N = N;
-    im.ckpt = (float*)(b + off); off += gsr_align((size_t)GSR_CKPT_PLANES * ((N + 3) & ~(size_t)3) * 4);
+    {
+        // The occlusion cut-off's mass tables (GSR_OCC_COPIES * T * GSR_OCC_BUCKETS words = 5 KB per tile) live only from the preprocess
+        // kernel to the cut-off kernel of the same forward; the checkpoint planes (192 B per pixel = 48 KB per full tile) are first
+        // written by the forward blend, later on the same stream: the tables ALIAS the checkpoint area (sized for the larger of the
+        // two: images of a few pixels) instead of adding 11.6 MB (1008x567) / 42 MB (1920x1080) to every image workspace autograd
+        // keeps alive (round 5).
+        const size_t ck = (size_t)GSR_CKPT_PLANES * ((N + 3) & ~(size_t)3) * 4;
+        const size_t oc = T <= GSR_OCC_MAX_TILES ? (size_t)GSR_OCC_COPIES * T * GSR_OCC_BUCKETS * 4 : 4;
+        im.ckpt = (float*)(b + off);
+        im.occ_mass = (uint32_t*)(b + off);
+        off += gsr_align(ck > oc ? ck : oc);
+    }
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.qresume = (uint32_t*)(b + off); off += gsr_align(4 * T * 4);
-    im.occ_mass = (uint32_t*)(b + off); off += gsr_align(T <= GSR_OCC_MAX_TILES ? (size_t)GSR_OCC_COPIES * T * GSR_OCC_BUCKETS * 4 : 4);
     im.occ_cut = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.occ_drop = (uint32_t*)(b + off); off += gsr_align((size_t)GSR_MAX_CHUNKS * 4);
     im.tile_group = (uint32_t*)(b + off); off += gsr_align((T / 64 + 1) * 4);

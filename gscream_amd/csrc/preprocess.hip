@@ -196,8 +196,17 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
                             // integer adds: order-free.  Into THIS XCD's copy of the table with an L2-local (workgroup-scope)
                             // atomic: every workgroup that touches the copy runs on this XCD, i.e. behind the same L2; device-scope
                             // atomics go to memory and cost this kernel 63 us on a large-splat frame
+                            // ASSUMPTION (gfx942 / gfx950 only, stated in DESIGN 3.1): an XCD's workgroup-scope atomics execute in that XCD's
+                            // L2 and reach memory at the kernel boundary, so all adds to one copy are ordered by that L2.  The HIP memory
+                            // model does not promise this; any other target takes agent scope.  A lost add could only LOWER a mass, i.e.
+                            // drop fewer instances: the cut-off stays conservative either way.
+#if defined(__gfx942__) || defined(__gfx950__)
                             if (m) __hip_atomic_fetch_add(&occ_xcd[(size_t)(y * cam.gx + x) * GSR_OCC_BUCKETS + o_bkt], m, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                            if (m) __hip_atomic_fetch_add(&occ_xcd[(size_t)(y * cam.gx + x) * GSR_OCC_BUCKETS + o_bkt], m, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+#endif
                         }
                     }
                 }

@@ -22,10 +22,20 @@ import torch.nn as nn
 
 from . import _native
 
-_tuning = _native.Tuning()
+_tuning = _native.Tuning()                    # the knobs as set_tuning left them (occlusion_cut = 0, inference = 0)
 _tuning_ref = _native.ctypes.byref(_tuning)  # built once: the struct is mutated in place by set_tuning
-_tuning_inf = _native.Tuning(inference=1)     # the same knobs with `inference` set: forwards that no backward will follow
-_tuning_inf_ref = _native.ctypes.byref(_tuning_inf)
+# The per-call variants -- `inference` (forwards that no backward will follow) x `occlusion_cut` (decided per device and frame) -- are four
+# IMMUTABLE-between-set_tuning structs: a forward picks one and never writes a shared struct, so two host threads (one per device) cannot
+# flip each other's knob between the choice and the native call.
+_tuning_variants = {(inf, occ): _native.Tuning(inference=inf, occlusion_cut=occ) for inf in (0, 1) for occ in (0, 1)}
+_tuning_variant_refs = {k: _native.ctypes.byref(v) for k, v in _tuning_variants.items()}
+
+
+def _sync_tuning_variants():
+    for (inf, occ), t in _tuning_variants.items():
+        for name, _ in _native.Tuning._fields_:
+            setattr(t, name, getattr(_tuning, name))
+        t.inference, t.occlusion_cut = inf, occ
 _capacity_hint = {}  # per-device: (binning capacity, longest-list provision) for the next speculative forward
 _recent = {}         # per-device: (num_rendered, max_tile_count) of the last few forwards (training hops between views)
 _RECENT_FRAMES = 8
@@ -48,7 +58,7 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_band
     _tuning.disable_tile_cull = 0 if tile_cull else 1
     _tuning.disable_speculation = 0 if speculative else 1
     _tuning.disable_partial_sort = 0 if partial_sort else 1
-    _tuning.scatter_bands = _tuning_inf.scatter_bands = int(scatter_bands)  # 0 = automatic (bands of tile rows per chunk in the scatter)
+    _tuning.scatter_bands = int(scatter_bands)  # 0 = automatic (bands of tile rows per chunk in the scatter)
     # occlusion_cut: conservative per-tile occlusion cut-off in front of the binning (gsr_tuning.occlusion_cut).  None = automatic:
     # switched on for frames of large splats (>= 4 binned instances per Gaussian in the previous frame), kept while it removes at least
     # a quarter of the instances, probed again every 64 frames otherwise.  Results do not depend on it; num_rendered does.
@@ -57,8 +67,7 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_band
     _tuning.heavy_groups = 0 if heavy_groups is None else 1 if heavy_groups else 2
     _occlusion_mode[0] = occlusion_cut
     _occlusion_state.clear()
-    _tuning_inf.disable_tile_cull, _tuning_inf.disable_speculation = _tuning.disable_tile_cull, _tuning.disable_speculation
-    _tuning_inf.disable_partial_sort = _tuning.disable_partial_sort
+    _sync_tuning_variants()
     _capacity_hint.clear()
     _recent.clear()
 
@@ -186,11 +195,10 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         pin = pins[idx] = (t, _native.ctypes.cast(t.data_ptr(), _native.ctypes.POINTER(_native.Stage1Result)))
     res = pin[1]
     debug = 1 if rs.debug else 0
-    tuning = _tuning_inf_ref if inference else _tuning_ref
     occ = _occlusion_mode[0]
     if occ is None:
         occ = _occlusion_state.get(idx, _OCC_OFF)["on"]
-    (_tuning_inf if inference else _tuning).occlusion_cut = 1 if occ else 0
+    tuning = _tuning_variant_refs[(1 if inference else 0, 1 if occ else 0)]  # nothing shared is written per call
     common = (P, int(rs.sh_degree), M, W, H, means3D_c.data_ptr(), _p(scales_c), float(rs.scale_modifier),
               _p(rot_c), _p(opac_c), _p(unc_c), _p(sh_c), _p(cov_c), _p(colors_c), _p(view), _p(proj), _p(campos),
               float(rs.tanfovx), float(rs.tanfovy), 1 if rs.prefiltered else 0)
@@ -237,12 +245,14 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
             maxR = h[0]
         if h[1] > maxL:
             maxL = h[1]
-    _capacity_hint[idx] = (int(1.25 * maxR) + 65536, max(1024, int(1.25 * maxL) + 64))
+    # (the pad on top of the 25 % is relative for small scenes: the library derives the scatter's band count from the capacity, and a
+    # flat +65536 made it split tiny frames into bands for nothing)
+    _capacity_hint[idx] = (int(1.25 * maxR) + min(65536, maxR // 2 + 1024), max(1024, int(1.25 * maxL) + 64))
     if _occlusion_mode[0] is None:  # automatic occlusion cut-off: decide for the NEXT frame on this device
         st = _occlusion_state.get(idx)
         if st is None:
             st = _occlusion_state[idx] = {"on": False, "hold": 0}
-        _occlusion_next(st, P, R, occluded)
+        _occlusion_next(st, P, R, occluded, was_on=bool(occ))
     ls = _last_stage1
     ls["num_rendered"], ls["max_tile_count"], ls["num_slots"], ls["binning_capacity"], ls["speculative"] = R, longest, nslots, cap, done
     ls["num_occluded"] = occluded
@@ -353,13 +363,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_unc.reshape(ctx.uncertainty_shape), g_scales, g_rot, g_cov, None)
 
 
-def _occlusion_next(st, P, R, occluded):
+def _occlusion_next(st, P, R, occluded, was_on=None):
     """Automatic switch of the occlusion cut-off (gsr_tuning.occlusion_cut), per device, from the frame that was just rendered:
     P Gaussians, R binned instances, `occluded` instances the pass removed (0 when it was off).  Off -> on when the frame had at
     least 4 instances per Gaussian (large splats: long lists of which the blend walks a fraction); on -> off when the pass removed
     less than a quarter of the instances, and then not probed again for 64 frames (it costs 3-4 % where nothing covers a tile)."""
+    if was_on is None:
+        was_on = st["on"]
     if st["on"]:
-        if occluded * 4 < R + occluded:
+        # judged only on a frame that really ran with the pass (was_on: what the native call was given for THIS frame)
+        if was_on and occluded * 4 < R + occluded:
             st["on"], st["hold"] = False, 64
     elif st["hold"] > 0:
         st["hold"] -= 1

@@ -52,8 +52,8 @@ typedef struct gsr_stage1_result {
     int32_t num_rendered;  /* R: number of binned (Gaussian, tile) instances.  With tile culling disabled this
                               is the reference's return value of Rasterizer::forward (rasterizer_impl.cu:346) */
     int32_t max_tile_count; /* longest per-tile list; selects the per-tile sort variant */
-    int32_t num_slots;      /* sum of tiles_touched over all Gaussians (every tile of every rectangle):
-                               the number of gradient slots the backward scratch must hold */
+    int32_t num_slots;      /* number of gradient slots the backward scratch must hold: one per BINNED instance, i.e.
+                               equal to num_rendered (tiles the cull or the occlusion cut-off dropped own no slot) */
     int32_t num_occluded;   /* instances the conservative occlusion cut-off removed before binning (gsr_tuning.occlusion_cut;
                                0 when it is off): lets the caller judge whether the pass pays on this kind of frame */
 } gsr_stage1_result;

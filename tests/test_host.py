@@ -34,11 +34,11 @@ def test_tuning_struct_layout_and_the_inference_twin():
     assert ctypes.sizeof(_native.Tuning) == 32 and _native.Tuning.inference.offset == 12
     RZ.set_tuning(tile_cull=False, partial_sort=False)
     try:
-        assert RZ._tuning_inf.inference == 1 and RZ._tuning.inference == 0
-        assert RZ._tuning_inf.disable_tile_cull == 1 and RZ._tuning_inf.disable_partial_sort == 1
+        assert RZ._tuning_variants[(1, 0)].inference == 1 and RZ._tuning.inference == 0 and RZ._tuning_variants[(0, 1)].occlusion_cut == 1
+        assert all(v.disable_tile_cull == 1 and v.disable_partial_sort == 1 for v in RZ._tuning_variants.values())
     finally:
         RZ.set_tuning()
-    assert RZ._tuning_inf.disable_tile_cull == 0
+    assert all(v.disable_tile_cull == 0 for v in RZ._tuning_variants.values())
     a, b = torch.zeros(3, 3), torch.zeros(3, 3, requires_grad=True)
     assert RZ._no_grad_needed(a, a) and not RZ._no_grad_needed(a, b)
     with torch.no_grad():

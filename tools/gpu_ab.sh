@@ -1,24 +1,25 @@
 #!/bin/bash
-# A/B of library variants on the GPU box: quick parity subset + bench stage times, two rounds interleaved.
-# usage: bash tools/gpu_ab.sh [-w workload] name1 name2 ...   ("base" = the shipped libgsraster.so, others = libgsraster_<name>.so)
+# The one A/B runner (replaces the per-experiment gpu_r*.sh scripts of rounds 1-4).  On the GPU box, from the repo root:
+#   bash tools/gpu_ab.sh [variant ...]
+# runs bench.py (stage times from HIP events) on the shipped library, then on every gscream_amd/libgsraster_<variant>.so
+# (built here with `make -C gscream_amd/csrc variant SRC=... NAME=<variant> FLAGS=...`) through GSR_LIB, then on the shipped
+# one again (box drift), for every workload in $WORKLOADS; $TESTS (pytest arguments) run afterwards.  Knobs (environment):
+#   WORKLOADS="config2 config3 config4"   STEPS=50 WARMUP=10   REPEAT=1   TESTS="tests/test_gpu_parity.py"   TAG=ab
+#   BENCH_ARGS="--occlusion 0"            extra bench.py arguments
+# Output: gpurun_out/$TAG/ab.txt (one line per run), err.log.
 set -u
-WL=config2
-if [ "${1:-}" = "-w" ]; then WL=$2; shift 2; fi
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/ab; mkdir -p "$OUT"
-lib() { if [ "$1" = base ]; then echo "$GRAFT_REPO_ROOT/gscream_amd/libgsraster.so"; else echo "$GRAFT_REPO_ROOT/gscream_amd/libgsraster_$1.so"; fi; }
-for n in "$@"; do
-  if [ "$n" != base ]; then
-    GSR_LIB=$(lib $n) timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "golden_forward_backward or slab_scene or config1 or determinism or more_cases" 2>&1 | tail -2 | sed "s/^/[$n parity] /"
-  fi
-done
-for round in 1 2; do
-  for n in "$@"; do
-    GSR_LIB=$(lib $n) timeout 600 python bench.py --workload $WL --steps 100 --warmup 20 --no-cpu-baseline --no-next-rows --no-strict-parity 2> "$OUT/$n.err" | tail -1 > "$OUT/$n.json"
-    python - "$n" "$OUT/$n.json" <<'PY'
-import json, sys
-d = json.load(open(sys.argv[2]))
-print(f"[{sys.argv[1]:>8s}] {d['value']:8.1f} it/s {d['ms_per_step']:.4f} ms | " + " ".join(f"{k.split('_')[0][:4]}{k.split('_')[-1][:3]}={v['avg_ms'] * 1e3:.1f}" for k, v in d["stages"].items()))
-PY
-  done
-done
+TAG=${TAG:-ab}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
+WORKLOADS=${WORKLOADS:-config2}; STEPS=${STEPS:-50}; WARMUP=${WARMUP:-10}; REPEAT=${REPEAT:-1}
+row() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], {k:round(v['avg_ms']*1e3,1) for k,v in d.get('stages',{}).items()})" "$1" "$2"; }
+run() { local wl=$1 name=$2; shift 2
+  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity --steps $STEPS --warmup $WARMUP --workload $wl ${BENCH_ARGS:-} 2>>"$OUT/err.log" | tail -1 | row $wl $name | tee -a "$OUT/ab.txt"
+}
+for wl in $WORKLOADS; do for r in $(seq $REPEAT); do
+  run $wl shipped A=1
+  for v in "$@"; do run $wl $v GSR_LIB=$PWD/gscream_amd/libgsraster_$v.so GSR_SKIP_ABI_CHECK=1; done
+done; [ $# -gt 0 ] && run $wl shipped_again A=1; done
+if [ -n "${TESTS:-}" ]; then timeout 2400 python -m pytest $TESTS -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -15 | tee -a "$OUT/ab.txt"; fi
