@@ -115,14 +115,19 @@ def parity_check(Hh, s, grads, st, ref, threads):
     oracle's walk of that pixel / Gaussian sits next to (tests/helpers.parity_report)."""
     from gscream_amd import _native
     try:
-        rep = Hh.parity_report(Hh.hip_run(s, grads), st, ref, nthreads=threads)
+        rep = Hh.parity_report(Hh.hip_run(s, grads), st, ref, nthreads=threads, s=s, grads=grads)
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
     return {"library": os.path.basename(_native.LIB_PATH), "against": "oracle/gs_oracle.c on the same scene and upstream gradients",
             "px_gt_1e-4": rep["px_gt_1e-4"], "max_abs": rep["max_abs"], "px_by_cause": rep["px_by_cause"],
             "grad_elems_gt_1e-3": rep["grad_elems_gt_1e-3"], "worst_rel": rep["worst_rel"],
             "grad_elems_by_cause": rep["grad_elems_by_cause"], "pixels_at_risk": rep["pixels_at_risk"], "bands": rep["bands"],
-            "per_family": {k: v["n_bad"] for k, v in rep["grads"].items()}}
+            "per_family": {k: v["n_bad"] for k, v in rep["grads"].items()},
+            # where each pixel's walk ended against the oracle's (a flipped T = 1e-4 stop shows here directly) and, for every gradient
+            # element beyond 1e-3, the range the REFERENCE algorithm's own unordered fp32 atomicAdd sums span (oracle.backward_envelope)
+            "last_contributor_differs": rep.get("last_contributor_differs"),
+            "final_T_max_rel_where_same_stop": rep.get("final_T_max_rel_where_same_stop"),
+            "order_noise_envelope": rep.get("order_noise_envelope")}
 
 
 def cpu_torch_naive():

@@ -82,6 +82,44 @@ __device__ __forceinline__ bool gsr_blends_exact(const float cA, const float cB,
     const float alpha = fminf(0.99f, op * expf(power));
     return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 }
+// EXACT REPLAY of the pixels that came near the T = 1e-4 stop (round 5).  The transmittance is accumulated state: the fast path's
+// T differs from the reference chain's by the accumulated alpha errors (measured: tools/t_chain_error.py), so a pixel whose test_T
+// lands that close to 1e-4 (forward.cu:537) may stop one instance earlier or later than the reference -- the "T flips" that were
+// the shipped build's last decision-type outliers.  A guard band cannot settle them in place (the whole chain in front of the
+// decision has to be the reference's), so the forward REMEMBERS which of its pixels came within GSR_TBAND (relative) of the stop --
+// at the stop itself (test_T just below 1e-4: one rarely taken branch per blend) and at the end of the walk (final T just above) --
+// and the quadrant wave then walks those pixels' lists again, all 64 lanes on one pixel: lane i evaluates instance i of a batch with
+// the reference's own expressions (raw conic, accurate expf, no contraction: forward.cu:528-534), the T chain runs over the
+// blending lanes in list order exactly as forward.cu:536-549 rounds it, and the pixel's outputs, final T, contributor count and
+// depth checkpoints are replaced.  ~GSR_TBAND * 1e7 pixels per 1008x567 frame.
+#ifndef GSR_TBAND
+#define GSR_TBAND 1.0e-4f
+#endif
+struct GsrExactAlpha { float alpha, one_minus; bool blends, in_band; };
+__device__ __forceinline__ GsrExactAlpha gsr_alpha_exact(const float cA, const float cB, const float cC, const float op, const float dx, const float dy)
+{
+#pragma clang fp contract(off)
+    GsrExactAlpha r;
+    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    const float raw = op * expf(power);
+    r.alpha = fminf(0.99f, raw);
+    r.blends = !(power > 0.0f) && !(r.alpha < 1.0f / 255.0f);
+    r.one_minus = 1.0f - r.alpha;
+    // (twice the guard band's width: the backward decides band membership on the FAST alpha, a few 1e-7 away from this one)
+    r.in_band = !(power > 0.0f) && fabsf(raw - 1.0f / 255.0f) < (1.0f / 255.0f) * (2.0f * GSR_BAND);
+    return r;
+}
+__device__ __forceinline__ float gsr_mul_exact(const float a, const float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float gsr_wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
 #endif
 
 // -DGSR_TRACE (diagnostic build `make trace`, not shipped): every wavefront of the backward blend records its start and
@@ -293,6 +331,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
 
     const unsigned long long full = __builtin_amdgcn_ballot_w64(true);
     unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
+    unsigned long long riskm = 0ull;  // pixels whose stop came within GSR_TBAND of T = 1e-4 (replayed exactly after the walk)
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Uf = 0.f;
     uint32_t last = 0;
     int npass = 0;  // checkpoints passed (wave-uniform)
@@ -314,8 +353,9 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
         bool stopped = !inside;
         if (inside) {
             const uint32_t nc = n_contrib[pid];
-            last = nc & 0x7fffffffu;
+            last = nc & 0x3fffffffu;
             stopped = (nc >> 31) != 0u;
+            riskm = (nc >> 30) & 1u;  // (per lane here; made a wave mask below)
             Tr = final_T[pid];
             const float4 fa = gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid];
             const float2 fb = gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid];
@@ -337,6 +377,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                 A0 += sa.y; A1 += sa.z; A2 += sa.w; A3 += sb.x; A4 += sb.y;
             }
         donem = __builtin_amdgcn_ballot_w64(stopped);
+        riskm = __builtin_amdgcn_ballot_w64(inside && riskm != 0ull);
         // the walk state above came from memory: settle it here, or the blend loop waits for `Tr` with a counter that also
         // covers the NEXT batch's record loads (the prefetch would be waited for at the first blend of every batch)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -484,6 +525,10 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                 const float test_T = Tr * (1.0f - al1);
                 const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
                 donem |= stopm;
+#if !defined(GSR_PRECISE_MATH) && !defined(GSR_NO_TREPLAY)
+                // a stop that close to 1e-4 may not be the reference's (see GSR_TBAND): remembered, replayed after the walk
+                if (stopm != 0ull) riskm |= __builtin_amdgcn_ballot_w64(test_T >= 0.0001f * (1.0f - GSR_TBAND)) & stopm;
+#endif
                 const unsigned long long okf = okm & ~stopm;
 #ifdef GSR_FWD_EXEC_MASK
                 if (__builtin_amdgcn_inverse_ballot_w64(okf)) {  // EXEC = the pixels that blend: no selects
@@ -517,6 +562,89 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
 
     // ran off the sorted prefix with pixels still blending: the tile is sorted completely and this quadrant resumes at n
     const bool ran_off = nsort < nlist && rg.y <= capacity && donem != full;
+
+    int npl = npass;  // checkpoints passed, per lane: a replayed pixel's own walk may end in another segment than the wave's
+#if !defined(GSR_PRECISE_MATH) && !defined(GSR_NO_TREPLAY)
+    // ---- exact replay of the pixels near the T = 1e-4 stop (see GSR_TBAND) ----
+    // + pixels whose FINAL T lies just above 1e-4: their last blend passed the stop test by less than the band
+    riskm |= __builtin_amdgcn_ballot_w64(inside && Tr < 0.0001f * (1.0f + GSR_TBAND));
+    // (a quadrant that ran off a partially sorted prefix replays at the end of its resumed walk, over the complete list: the
+    // flags travel in bit 30 of n_contrib)
+    if (riskm != 0ull && !ran_off) {
+        for (unsigned long long todo = riskm; todo != 0ull; todo &= todo - 1ull) {
+            const int f = (int)__builtin_ctzll(todo);  // wave-uniform: the pixel all 64 lanes work on
+            const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxf), f));
+            const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pyf), f));
+            const uint32_t fpid = (uint32_t)__builtin_amdgcn_readlane((int)pid, f);
+            float Tq = 1.0f;  // the reference's T (wave-uniform)
+            float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;  // sums of the open segment (uniform)
+            float E0 = 0.f, E1 = 0.f, E2 = 0.f, E3 = 0.f, E4 = 0.f;  // sums of the closed segments
+            int np2 = 0;
+            uint32_t lastq = 0u;
+            bool stoppedq = false;
+            for (int b0 = 0; b0 < n && !stoppedq; b0 += GSR_FWB) {
+                if (b0 > 0 && (b0 & (seg_len - 1)) == 0 && np2 < GSR_SEG_MAX - 1) {  // same restarts as the walk above
+                    if (TRAIN && lane == 0) {
+                        gsr_ckpt_a(ckpt, np2, HW)[fpid] = make_float4(Tq, S0, S1, S2);
+                        gsr_ckpt_b(ckpt, np2, HW)[fpid] = make_float2(S3, S4);
+                    }
+                    np2++;
+                    E0 += S0; E1 += S1; E2 += S2; E3 += S3; E4 += S4;
+                    S0 = 0.f; S1 = 0.f; S2 = 0.f; S3 = 0.f; S4 = 0.f;
+                }
+                const int c2 = min(GSR_FWB, n - b0);
+                GsrExactAlpha ea = {0.f, 1.f, false, false};
+                float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
+                float rdep = 0.f, rfeat = 0.f;
+                if (lane < c2) {
+                    const uint32_t gid = ids[b0 + lane] & 0x7fffffffu;
+                    const GsrRec* r = rec + gid;
+                    const float4 ra = r->a, rb = r->b;
+                    rc = r->c; rdep = rb.z; rfeat = rb.w;
+                    ea = gsr_alpha_exact(ra.z, ra.w, rb.x, rb.y, ra.x - fx, ra.y - fy);
+                    // the backward runs its own exact alpha check only on flagged list entries: this walk may visit entries
+                    // the pixel's fast walk never reached
+                    if (ea.in_band) ids[b0 + lane] = gid | 0x80000000u;
+                }
+                unsigned long long m = __builtin_amdgcn_ballot_w64(ea.blends), blended = 0ull;
+                const float Tstart = Tq;
+                while (m != 0ull) {  // the T chain, in list order, rounded like forward.cu:536-549
+                    const int i = (int)__builtin_ctzll(m);
+                    const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ea.one_minus), i));
+                    const float t = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gsr_mul_exact(Tq, o))));
+                    if (t < 0.0001f) { stoppedq = true; break; }
+                    Tq = t;
+                    lastq = (uint32_t)(b0 + i + 1);
+                    blended |= 1ull << i;
+                    m &= m - 1ull;
+                }
+                // weights alpha_i * T_i: T_i from a prefix product over the blending lanes (sums, not decisions: its rounding differs
+                // from the chain's by ulps)
+                const bool mine = (blended >> lane) & 1ull;
+                float pf = mine ? ea.one_minus : 1.0f;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float q = __shfl_up(pf, d, 64);
+                    if (lane >= d) pf *= q;
+                }
+                float excl = __shfl_up(pf, 1, 64);
+                if (lane == 0) excl = 1.0f;
+                const float w = mine ? ea.alpha * (Tstart * excl) : 0.0f;
+                S0 += gsr_wave_sum(rc.x * w); S1 += gsr_wave_sum(rc.y * w); S2 += gsr_wave_sum(rc.z * w);
+                S3 += gsr_wave_sum(rdep * w); S4 += gsr_wave_sum(rfeat * w);
+            }
+            // (a replay that reaches the end of a partially sorted prefix without stopping would need the entries behind it: it is
+            // dropped and the pixel keeps its fast walk -- a flip exactly at the cut of a list beyond 2048 entries)
+            if (!(nsort < nlist && !stoppedq)) {
+                if (lane == f) {
+                    Tr = Tq; C0 = S0; C1 = S1; C2 = S2; Dp = S3; Uf = S4; last = lastq; npl = np2;
+                    sAcc[0][lane] = E0; sAcc[1][lane] = E1; sAcc[2][lane] = E2; sAcc[3][lane] = E3; sAcc[4][lane] = E4;
+                }
+                GSR_COUNT_ADD(3, 1);
+            }
+        }
+    }
+#endif
     if (lane == 0) {
         if (ran_off) need_full[tile] = 1u;
         qresume[u] = ran_off ? (uint32_t)n : 0u;
@@ -532,10 +660,12 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
         const float E0 = sAcc[0][lane], E1 = sAcc[1][lane], E2 = sAcc[2][lane], E3 = sAcc[3][lane], E4 = sAcc[4][lane];
         if (TRAIN || ran_off) {  // (ran_off is wave-uniform)
             // sums behind the last checkpoint + how many checkpoints were passed
-            gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float4(__int_as_float(npass), C0, C1, C2);
+            gsr_ckpt_a(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float4(__int_as_float(npl), C0, C1, C2);
             gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[pid] = make_float2(Dp, Uf);
             final_T[pid] = Tr;
-            n_contrib[pid] = last | ((ran_off && __builtin_amdgcn_inverse_ballot_w64(donem)) ? 0x80000000u : 0u);  // top bit: for the resume only
+            // top bits: for the resume only (31: the pixel had stopped, 30: its stop was inside the T band)
+            n_contrib[pid] = last | ((ran_off && __builtin_amdgcn_inverse_ballot_w64(donem)) ? 0x80000000u : 0u) |
+                             ((ran_off && __builtin_amdgcn_inverse_ballot_w64(riskm)) ? 0x40000000u : 0u);
             if (!TRAIN) {  // + the closed segments' sums, which the training forward keeps in its checkpoint slots
                 gsr_ckpt_a(ckpt, 0, HW)[pid] = make_float4(0.f, E0, E1, E2);
                 gsr_ckpt_b(ckpt, 0, HW)[pid] = make_float2(E3, E4);
@@ -651,8 +781,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const size_t pa = ina ? (size_t)py * W + pxa : 0, pb = inb ? (size_t)py * W + pxb : 0;
 
     const gsr_f2 Tf = {ina ? final_T[pa] : 0.f, inb ? final_T[pb] : 0.f};
-    // (bit 31 is the forward's resume flag: cleared by its fix-up pass, masked here in case the caller skipped that pass)
-    const int lastca = ina ? (int)(n_contrib[pa] & 0x7fffffffu) : 0, lastcb = inb ? (int)(n_contrib[pb] & 0x7fffffffu) : 0;
+    // (bits 31 / 30 are the forward's resume flags: cleared by its fix-up pass, masked here in case the caller skipped that pass)
+    const int lastca = ina ? (int)(n_contrib[pa] & 0x3fffffffu) : 0, lastcb = inb ? (int)(n_contrib[pb] & 0x3fffffffu) : 0;
     const gsr_f2 g0 = {ina ? dL_dcolor[pa] : 0.f, inb ? dL_dcolor[pb] : 0.f};
     const gsr_f2 g1 = {ina ? dL_dcolor[HW + pa] : 0.f, inb ? dL_dcolor[HW + pb] : 0.f};
     const gsr_f2 g2 = {ina ? dL_dcolor[2 * HW + pa] : 0.f, inb ? dL_dcolor[2 * HW + pb] : 0.f};

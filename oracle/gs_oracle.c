@@ -505,6 +505,117 @@ void gso_render_backward(int W, int H, const uint32_t *ranges, const uint32_t *p
         }
 }
 
+/* ORDER-NOISE ENVELOPE of the reference's own backward blend (round 5).  backward.cu:554-601 scatters the 11 per-contribution
+ * terms with unordered fp32 atomicAdd: the reference's result for a Gaussian is whatever order the hardware served its pixels
+ * in, so two runs of the REFERENCE differ by the rounding of a re-ordered fp32 sum.  gso_render_backward accumulates in double
+ * (order-free); this function measures, for `ng` chosen Gaussians, how far fp32 accumulation in K random contribution orders
+ * spreads: it collects every (pixel -> Gaussian) contribution exactly as gso_render_backward forms it (same walk, same fp32
+ * expressions), then adds them up K times in fp32, each time in another random permutation.
+ *   sums[ng][K][11]: mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, colour r, g, b, depth, feature  (slot order of g_*).
+ * A Gaussian's tiles are the tiles of its rectangle (getRect, the oracle's un-culled lists).  Returns the largest number of
+ * contributions one Gaussian had.  Test infrastructure like the rest of the file: parity_check uses it to say whether a gradient
+ * element that differs from the double-accumulated value by more than 1e-3 lies inside the reference's own order noise. */
+static uint64_t env_rng(uint64_t *s) { *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17; return *s; }
+int gso_backward_envelope(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *bg,
+                          const float *means2D, const int *radii, const float *conic_opacity, const float *colors, const float *depths,
+                          const float *unc, const float *final_T, const uint32_t *n_contrib, const float *dL_dpix,
+                          const float *dL_ddepthpix, const float *dL_duncpix, int ng, const int *gids, int K, uint64_t seed,
+                          float *sums)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    int most = 0;
+    for (int q = 0; q < ng; q++) {
+        const int target = gids[q];
+        int x0, y0, x1, y1;
+        get_rect(means2D[2 * target], means2D[2 * target + 1], radii[target], gx, gy, &x0, &y0, &x1, &y1);
+        const int cap = imax(1, (x1 - x0) * (y1 - y0) * TILE * TILE);
+        float *con = (float *)malloc((size_t)cap * 11 * sizeof(float));
+        int nc = 0;
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++)
+                for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
+                    for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
+                        /* the walk of gso_render_backward for this pixel, up to the target (backward.cu:492-603) */
+                        const int tile = ty * gx + tx;
+                        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+                        const size_t pid = (size_t)py * W + px;
+                        const float pixfx = (float)px, pixfy = (float)py;
+                        const float T_final = final_T[pid];
+                        float T = T_final;
+                        const uint32_t last_contributor = n_contrib[pid];
+                        float accum_rec[3] = { 0, 0, 0 }, accum_depth_rec = 0, accum_unc_rec = 0;
+                        const float dL_dpixel[3] = { dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[(size_t)2 * H * W + pid] };
+                        const float dL_dpd = dL_ddepthpix[pid], dL_dunc = dL_duncpix[pid];
+                        float last_alpha = 0, last_color[3] = { 0, 0, 0 }, last_depth = 0, last_unc = 0;
+                        uint32_t contributor = r1 - r0;
+                        for (uint32_t kk = 0; kk < r1 - r0; kk++) {
+                            contributor--;
+                            if (contributor >= last_contributor) continue;
+                            const uint32_t g = point_list[r1 - 1 - kk];
+                            const float dx = means2D[2 * g] - pixfx, dy = means2D[2 * g + 1] - pixfy;
+                            const float *co = conic_opacity + 4 * g;
+                            const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                            if (power > 0.0f) { if ((int)g == target) break; continue; }
+                            const float G = expf(power);
+                            const float alpha = fminf(0.99f, co[3] * G);
+                            if (alpha < 1.0f / 255.0f) { if ((int)g == target) break; continue; }
+                            T = T / (1.f - alpha);
+                            const float dchannel_dcolor = alpha * T;
+                            float dL_dalpha = 0.0f;
+                            float vcol[3];
+                            for (int ch = 0; ch < 3; ch++) {
+                                const float c = colors[3 * g + ch];
+                                accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                                last_color[ch] = c;
+                                dL_dalpha += (c - accum_rec[ch]) * dL_dpixel[ch];
+                                vcol[ch] = dchannel_dcolor * dL_dpixel[ch];
+                            }
+                            const float c_d = depths[g];
+                            accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                            last_depth = c_d;
+                            dL_dalpha += (c_d - accum_depth_rec) * dL_dpd;
+                            const float c_unc = unc[g];
+                            accum_unc_rec = last_alpha * last_unc + (1.f - last_alpha) * accum_unc_rec;
+                            last_unc = c_unc;
+                            dL_dalpha += (c_unc - accum_unc_rec) * dL_dunc;
+                            dL_dalpha *= T;
+                            last_alpha = alpha;
+                            float bg_dot = 0;
+                            for (int i = 0; i < 3; i++) bg_dot += bg[i] * dL_dpixel[i];
+                            dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                            if ((int)g != target) continue;
+                            const float dL_dG = co[3] * dL_dalpha;
+                            const float gdx = G * dx, gdy = G * dy;
+                            const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                            const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                            float *v = con + (size_t)nc * 11;
+                            v[0] = dL_dG * dG_ddelx * ddelx_dx; v[1] = dL_dG * dG_ddely * ddely_dy;
+                            v[2] = -0.5f * gdx * dx * dL_dG; v[3] = -0.5f * gdx * dy * dL_dG; v[4] = -0.5f * gdy * dy * dL_dG;
+                            v[5] = G * dL_dalpha;
+                            v[6] = vcol[0]; v[7] = vcol[1]; v[8] = vcol[2];
+                            v[9] = dchannel_dcolor * dL_dpd; v[10] = dchannel_dcolor * dL_dunc;
+                            nc++;
+                            break;
+                        }
+                    }
+        if (nc > most) most = nc;
+        int *perm = (int *)malloc((size_t)imax(nc, 1) * sizeof(int));
+        uint64_t st = seed * 0x9E3779B97F4A7C15ull + (uint64_t)target * 0xD1B54A32D192ED03ull + 1ull;
+        for (int k = 0; k < K; k++) {
+            for (int i = 0; i < nc; i++) perm[i] = i;
+            for (int i = nc - 1; i > 0; i--) { const int j = (int)(env_rng(&st) % (uint64_t)(i + 1)); const int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+            float acc[11] = { 0 };
+            for (int i = 0; i < nc; i++)
+                for (int c = 0; c < 11; c++) acc[c] += con[(size_t)perm[i] * 11 + c];  /* fp32, this order: what one atomicAdd sequence gives */
+            memcpy(sums + ((size_t)q * K + k) * 11, acc, sizeof(acc));
+        }
+        free(perm);
+        free(con);
+    }
+    return most;
+}
+
 /* backward.cu:20-139 computeColorFromSH (bwd) */
 static void sh_backward(int idx, int deg, int M, const float *means, const float *campos, const float *shs,
                         const unsigned char *clamped, const float *dL_dcolor, float *dL_dmeans, float *dL_dshs)

@@ -188,6 +188,63 @@ def backward(st, means3D, scales, rotations, dL_dcolor, dL_ddepth, dL_dunc, *, t
     return out
 
 
+def backward_envelope(st, gids, means3D, scales, rotations, dL_dcolor, dL_ddepth, dL_dunc, *, tanfovx, tanfovy, viewmatrix,
+                      projmatrix, campos=None, scale_modifier=1.0, shs=None, sh_degree=0, K=64, seed=1):
+    """Order-noise envelope of the reference algorithm for the Gaussians `gids` (gso_backward_envelope): the 11 per-contribution
+    sums of backward.cu:554-601 accumulated in fp32 in K random contribution orders (what unordered atomicAdd yields), each pushed
+    through the per-Gaussian backward (backward.cu:144-406) like the real thing.  Returns {family: [len(gids), K, ...]} for the
+    same gradient families as backward(); compare with backward()'s double-accumulated rows."""
+    L = lib()
+    L.gso_backward_envelope.restype = ctypes.c_int
+    W, H = st["W"], st["H"]
+    gids = np.ascontiguousarray(gids, dtype=np.int32)
+    ng = int(gids.shape[0])
+    means3D, scales, rotations, shs = _f(means3D), _f(scales), _f(rotations), _f(shs)
+    viewmatrix, projmatrix = _f(viewmatrix), _f(projmatrix)
+    campos = _f(np.zeros(3, np.float32) if campos is None else campos)
+    M = 0 if shs is None else shs.shape[1]
+    dL_dcolor = _f(dL_dcolor).reshape(3, H, W)
+    dL_ddepth = _f(dL_ddepth).reshape(H, W)
+    dL_dunc = _f(dL_dunc).reshape(H, W)
+    sums = np.zeros((max(ng, 1), K, 11), np.float32)
+    fam = dict(dL_dmeans2D=np.zeros((ng, K, 3), np.float32), dL_dcolors=np.zeros((ng, K, 3), np.float32),
+               dL_dopacity=np.zeros((ng, K, 1), np.float32), dL_duncertainty=np.zeros((ng, K, 1), np.float32),
+               dL_dmeans3D=np.zeros((ng, K, 3), np.float32), dL_dcov3D=np.zeros((ng, K, 6), np.float32),
+               dL_dscales=np.zeros((ng, K, 3), np.float32), dL_drotations=np.zeros((ng, K, 4), np.float32),
+               dL_dsh=np.zeros((ng, K, M, 3), np.float32))
+    if ng == 0:
+        return fam
+    most = L.gso_backward_envelope(
+        ctypes.c_int(W), ctypes.c_int(H), _p(st["ranges"], _u32p), _p(st["point_list"], _u32p), _p(st["bg"], _f32p),
+        _p(st["means2D"], _f32p), _p(st["radii"], _i32p), _p(st["conic_opacity"], _f32p), _p(st["colors"], _f32p),
+        _p(st["depths"], _f32p), _p(st["unc"], _f32p), _p(st["final_T"], _f32p), _p(st["n_contrib"], _u32p),
+        _p(dL_dcolor, _f32p), _p(dL_ddepth, _f32p), _p(dL_dunc, _f32p), ctypes.c_int(ng), _p(gids, _i32p), ctypes.c_int(K),
+        ctypes.c_uint64(seed), _p(sums, _f32p))
+    fam["contributions_max"] = int(most)
+    # the per-Gaussian backward on the ng rows, once per order (every per-Gaussian array gathered to ng rows)
+    gat = lambda a: None if a is None else np.ascontiguousarray(a[gids])
+    m3, sc, ro, sh_g = gat(means3D), gat(scales), gat(rotations), gat(shs)
+    radii, clamped, cov3D = gat(st["radii"]), gat(st["clamped"]), gat(_f(st["cov3D"]))
+    for k in range(K):
+        g_mean2D = np.ascontiguousarray(sums[:ng, k, 0:2]); g_conic = np.ascontiguousarray(sums[:ng, k, 2:5])
+        g_colors = np.ascontiguousarray(sums[:ng, k, 6:9]); g_depth = np.ascontiguousarray(sums[:ng, k, 9])
+        o = dict(m3=np.zeros((ng, 3), np.float32), cov=np.zeros((ng, 6), np.float32), sh=np.zeros((ng, M, 3), np.float32),
+                 sc=np.zeros((ng, 3), np.float32), ro=np.zeros((ng, 4), np.float32))
+        L.gso_preprocess_backward(
+            ctypes.c_int(ng), ctypes.c_int(sh_degree), ctypes.c_int(M), _p(m3, _f32p), _p(radii, _i32p), _p(sh_g, _f32p),
+            _p(clamped, _u8p), _p(sc, _f32p), _p(ro, _f32p), ctypes.c_float(scale_modifier), _p(cov3D, _f32p),
+            _p(viewmatrix, _f32p), _p(projmatrix, _f32p), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_float(tanfovx),
+            ctypes.c_float(tanfovy), _p(campos, _f32p), _p(g_mean2D, _f32p), _p(g_conic, _f32p), _p(g_colors, _f32p),
+            _p(g_depth, _f32p), _p(o["m3"], _f32p), _p(o["cov"], _f32p), _p(o["sh"], _f32p), _p(o["sc"], _f32p), _p(o["ro"], _f32p))
+        fam["dL_dmeans2D"][:, k, :2] = sums[:ng, k, 0:2]
+        fam["dL_dcolors"][:, k] = sums[:ng, k, 6:9]
+        fam["dL_dopacity"][:, k, 0] = sums[:ng, k, 5]
+        fam["dL_duncertainty"][:, k, 0] = sums[:ng, k, 10]
+        fam["dL_dmeans3D"][:, k] = o["m3"]; fam["dL_dcov3D"][:, k] = o["cov"]; fam["dL_dscales"][:, k] = o["sc"]
+        fam["dL_drotations"][:, k] = o["ro"]; fam["dL_dsh"][:, k] = o["sh"]
+    return fam
+
+
 def visible_filter(means3D, scales, rotations, *, W, H, tanfovx, tanfovy, viewmatrix, projmatrix, scale_modifier=1.0,
                    cov3D_precomp=None):
     """rasterizer_impl.cu:350-406 visible_filter -> radii."""

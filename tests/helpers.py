@@ -43,6 +43,17 @@ def oracle_backward(s, st, grads, nthreads=1):
                       nthreads=nthreads)
 
 
+def oracle_envelope(s, st, grads, gids, K=64, seed=1):
+    """Order-noise envelope of the reference algorithm for the Gaussians `gids` (oracle.backward_envelope)."""
+    from oracle import oracle as O
+    gc, gd, gu = grads
+    scales = None if "cov3D_precomp" in s else s["scales"]
+    rots = None if "cov3D_precomp" in s else s["rotations"]
+    return O.backward_envelope(st, gids, s["means3D"], scales, rots, gc, gd, gu, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"],
+                               viewmatrix=s["viewmatrix"], projmatrix=s["projmatrix"], campos=s["campos"],
+                               scale_modifier=s["scale_modifier"], shs=s.get("shs"), sh_degree=s.get("sh_degree", 0), K=K, seed=seed)
+
+
 def hip_settings(s, device="cuda", debug=False):
     import torch
     from gscream_amd import GaussianRasterizationSettings
@@ -91,6 +102,17 @@ def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False):
                                         uncertainties=inp["uncertainties"], **kw)
     out.update(out_color=color.detach().cpu().numpy(), out_depth=depth.detach().cpu().numpy(),
                out_unc=unc.detach().cpu().numpy(), radii=radii.cpu().numpy())
+    if rg and not keep_state and color.grad_fn is not None and s["means3D"].shape[0] > 0:
+        # where every pixel's walk ended (decoded from the workspaces autograd holds, before the backward consumes anything): the
+        # Gaussian blended last and the final transmittance -- a T = 1e-4 stop that differs from the oracle's shows here directly
+        from gscream_amd import _layout
+        geom, binning, img = color.grad_fn.saved_tensors[-3:]
+        R = int(color.grad_fn.num_rendered)
+        iv = _layout.image_views(img, s["means3D"].shape[0], s["W"], s["H"])
+        bv = _layout.binning_views(binning, R, capacity=int(color.grad_fn.binning_capacity))
+        out["final_T"] = iv["final_T"].cpu().numpy().copy()
+        out["last_gid"] = last_gaussian(iv["ranges"].cpu().numpy().astype(np.int64), bv["point_list"].cpu().numpy().astype(np.int64),
+                                        (iv["n_contrib"].cpu().numpy().astype(np.int64) & 0x3fffffff), s["W"], s["H"])
     if rg and not keep_state:
         gc, gd, gu = (torch.from_numpy(g).to(device) for g in grads)
         loss = (color * gc).sum() + (depth * gd).sum() + (unc * gu).sum()
@@ -108,6 +130,21 @@ def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False):
             out["dL_drotations"] = kw["rotations"].grad.cpu().numpy()
         if "cov3D_precomp" in kw:
             out["dL_dcov3D"] = kw["cov3D_precomp"].grad.cpu().numpy()
+    return out
+
+
+def last_gaussian(ranges, point_list, n_contrib, W, H):
+    """[H, W] id of the Gaussian each pixel blended last (-1: none): point_list[ranges[tile, 0] + n_contrib - 1].  Comparable between
+    implementations whose lists differ (tile culling drops instances no pixel blends, so list POSITIONS differ, Gaussians do not)."""
+    gx = (W + 15) // 16
+    ys, xs = np.mgrid[0:H, 0:W]
+    tile = (ys // 16) * gx + (xs // 16)
+    nc = np.asarray(n_contrib, np.int64).reshape(H, W)
+    pos = np.asarray(ranges, np.int64).reshape(-1, 2)[tile, 0] + nc - 1
+    pl = np.asarray(point_list, np.int64)
+    out = np.full((H, W), -1, np.int64)
+    ok = nc > 0
+    out[ok] = pl[pos[ok]]
     return out
 
 
@@ -192,7 +229,7 @@ def assert_grads_nearly_equal(a, b, keys=GRAD_KEYS, context=""):
 ALPHA_BAND, T_BAND = 1e-4, 1e-3
 
 
-def parity_report(got, st, ref=None, nthreads=1):
+def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_orders=256, envelope_max_rows=64):
     """Element-wise parity of HIP outputs `got` against the oracle state `st` (+ gradients `ref`), with every outlier
     classified by the decision its pixel / Gaussian sits next to in the ORACLE's walk (oracle.margins):
       alpha = only the alpha >= 1/255 test is within ALPHA_BAND, T = only the T < 1e-4 stop is within T_BAND, both, neither.
@@ -212,7 +249,14 @@ def parity_report(got, st, ref=None, nthreads=1):
     out["px_by_cause"] = {"alpha": int((bad & near_a & ~near_t).sum()), "T": int((bad & near_t & ~near_a).sum()),
                           "both": int((bad & near_a & near_t).sum()), "neither": int((bad & ~near_a & ~near_t).sum())}
     out["pixels_at_risk"] = {"alpha": int(near_a.sum()), "T": int(near_t.sum()), "power_sign(|power|<1e-6)": int((mg["m_pow"] < 1e-6).sum())}
-    out["n_contrib_differs"] = int((got["n_contrib"] != st["n_contrib"]).sum()) if "n_contrib" in got else None
+    if "last_gid" in got:
+        # pixels whose walk ended at another Gaussian than the oracle's: a flipped T = 1e-4 stop (or a flipped alpha test of the last instance)
+        ref_last = last_gaussian(st["ranges"], st["point_list"], st["n_contrib"], W, H)
+        diff = got["last_gid"] != ref_last
+        out["last_contributor_differs"] = {"pixels": int(diff.sum()), "near_T_stop": int((diff & near_t).sum()), "near_alpha": int((diff & near_a & ~near_t).sum())}
+        ft, rt = got["final_T"].astype(np.float64), st["final_T"].astype(np.float64)
+        same = ~diff & (rt > 0)
+        out["final_T_max_rel_where_same_stop"] = float((np.abs(ft[same] - rt[same]) / rt[same]).max()) if same.any() else 0.0
     if ref is not None:
         P = st["radii"].shape[0]
         ga = np.zeros(P, bool); gt = np.zeros(P, bool)
@@ -236,5 +280,41 @@ def parity_report(got, st, ref=None, nthreads=1):
                 cause["alpha"] += int(per_row[ga & ~gt].sum()); cause["T"] += int(per_row[gt & ~ga].sum())
                 cause["both"] += int(per_row[ga & gt].sum()); cause["neither"] += int(per_row[~ga & ~gt].sum())
         out["grad_elems_by_cause"] = cause
+        if s is not None and grads is not None and out["grad_elems_gt_1e-3"]:
+            # ORDER-NOISE ENVELOPE (round 5): the reference scatters its per-contribution terms with unordered fp32 atomicAdd
+            # (backward.cu:554-601), so its own result for a Gaussian moves with the order its pixels were served in.  For every
+            # outlier row: the same sums in `envelope_orders` random orders (oracle.backward_envelope) -> is our value inside the
+            # range the reference algorithm itself produces?  Listed per element with the range.
+            rows = np.zeros(P, bool)
+            fam_bad = {}
+            for k in GRAD_KEYS:
+                if k in ref and k in got and np.asarray(ref[k]).size:
+                    g64 = np.asarray(got[k], np.float64)
+                    r64 = np.asarray(ref[k], np.float64).reshape(g64.shape)
+                    r = np.abs(g64 - r64) / (np.abs(r64) + 1e-3 * max(np.abs(r64).max(), 1e-30))
+                    fam_bad[k] = (r > GRAD_REL_TOL).reshape(P, -1)
+                    rows |= fam_bad[k].any(axis=1)
+            gids = np.nonzero(rows)[0][:envelope_max_rows].astype(np.int32)
+            env = oracle_envelope(s, st, grads, gids, K=envelope_orders)
+            listing, inside, outside = [], 0, 0
+            for qi, g in enumerate(gids):
+                for k, fb in fam_bad.items():
+                    if k not in env:
+                        continue
+                    for c in np.nonzero(fb[g])[0]:
+                        ours = float(np.asarray(got[k]).reshape(P, -1)[g, c])
+                        dbl = float(np.asarray(ref[k]).reshape(P, -1)[g, c])
+                        e = env[k][qi].reshape(envelope_orders, -1)[:, c].astype(np.float64)
+                        lo, hi = float(e.min()), float(e.max())
+                        half = max(abs(lo - dbl), abs(hi - dbl))
+                        ok = lo <= ours <= hi
+                        inside += ok; outside += (not ok)
+                        cls = "alpha" if (ga[g] and not gt[g]) else "T" if (gt[g] and not ga[g]) else "both" if (ga[g] and gt[g]) else "neither"
+                        listing.append({"gaussian": int(g), "family": k, "component": int(c), "cause": cls, "ours": ours, "oracle_double": dbl,
+                                        "reference_fp32_orders_min": lo, "reference_fp32_orders_max": hi,
+                                        "ours_minus_double_over_envelope_halfwidth": (abs(ours - dbl) / half) if half > 0 else float("inf"),
+                                        "inside_envelope": bool(ok)})
+            out["order_noise_envelope"] = {"orders": envelope_orders, "rows_examined": int(len(gids)), "rows_total": int(rows.sum()),
+                                           "elements_inside": int(inside), "elements_outside": int(outside), "elements": listing}
     out["bands"] = {"alpha_rel": ALPHA_BAND, "T_rel": T_BAND}
     return out

@@ -184,3 +184,29 @@ def test_surface_scene_generator_is_what_its_workload_says():
         z = np.sort(st["depths"][st["point_list"][r[t, 0]:r[t, 1]]].astype(np.float64))
         return float(np.median(np.diff(z)) / (z[-1] - z[0]))
     assert median_rel_gap(a, st) < 0.5 * median_rel_gap(slab, st_slab)
+
+
+def test_order_noise_envelope_brackets_the_double_accumulated_backward():
+    """oracle.backward_envelope (round 5): the 11 per-contribution sums of backward.cu:554-601 accumulated in fp32 in K random orders
+    -- what the reference's unordered atomicAdd produces -- pushed through the per-Gaussian backward.  On config 1 every order agrees
+    with the double-accumulated oracle backward to fp32 rounding (the walk that collects the contributions is the backward's own),
+    different orders give different bits (it IS order noise), and a Gaussian nobody blends has an all-zero envelope."""
+    import helpers as Hh
+    from gscream_amd import synthetic as S
+    s = S.scene_config1()
+    grads = S.upstream_grads(1, s["W"], s["H"])
+    st = Hh.oracle_forward(s)
+    ref = Hh.oracle_backward(s, st, grads)
+    culled = int(np.nonzero(st["radii"] == 0)[0][0])
+    gids = np.array([0, 5, 17, 100, 1999, culled], np.int32)
+    K = 16
+    env = Hh.oracle_envelope(s, st, grads, gids, K=K)
+    assert env["contributions_max"] > 16
+    differs = 0
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_duncertainty", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
+        r = np.asarray(ref[k], np.float64).reshape(len(s["means3D"]), -1)[gids]
+        e = env[k].reshape(len(gids), K, -1).astype(np.float64)
+        assert np.abs(e - r[:, None, :]).max() <= 5e-6 * np.abs(r).max(), k
+        assert (e[-1] == 0).all(), k                      # the culled Gaussian
+        differs += int((e.max(axis=1) != e.min(axis=1)).sum())
+    assert differs > 0

@@ -36,7 +36,7 @@ def main():
     for k in Hh.GRAD_KEYS:
         if k in ref and k in got:
             out["grads"][k] = Hh.grad_report(got[k], ref[k], 1e-3)
-    out["parity_check"] = Hh.parity_report(got, st, ref, nthreads=nt)  # + every outlier classified (alpha = 1/255 vs T = 1e-4 flips)
+    out["parity_check"] = Hh.parity_report(got, st, ref, nthreads=nt, s=s, grads=grads)  # + every outlier classified (alpha = 1/255 vs T = 1e-4 flips)
     print(json.dumps(out))
 
 
