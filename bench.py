@@ -58,12 +58,59 @@ WORKLOADS = {
     "surfaces": (1_000_000, 1008, 567, 1, (True, False, False),
                  "surfaces: 1M Gaussians on six tilted surfaces + 15 % floaters (synthetic.scene_surfaces, seed 1), 1008x567, fwd+bwd, "
                  "RGB-only upstream grads; NOT a BASELINE config"),
+    # not a BASELINE config either: the frame GScream renders at ITERATION 0 of a scene -- a synthetic SfM-like surface point cloud
+    # through the reference's own initialisation (create_from_pcd restated: standin_model.Model.from_pcd) and the fused decode.  P is
+    # whatever the decode emits (~200k anchors x 10 offsets x the share with opacity > 0).  Upstream gradients as in training: RGB + depth.
+    "init_state": (None, 1008, 567, 1, (True, True, False),
+                   "init_state: ~200k voxelised surface points -> GaussianModel.create_from_pcd restated (scales from distCUDA2, zero offsets / "
+                   "features, default-init MLPs) -> decode at the camera -> rasterize 1008x567, fwd+bwd, RGB + depth upstream grads; NOT a BASELINE config"),
 }
+
+_SCENE_CACHE = {}
 
 
 def scene_for(workload, seed, P, W, H):
     from gscream_amd import synthetic as S
+    if workload == "init_state":  # built on the GPU rows (knn + decode): once per process, the CPU-baseline leg reuses it
+        key = (workload, seed, W, H)
+        if key not in _SCENE_CACHE:
+            _SCENE_CACHE[key] = S.scene_init_state(seed, W, H)
+        return _SCENE_CACHE[key]
     return (S.scene_surfaces if workload == "surfaces" else S.scene_slab)(seed, P, W, H)
+
+
+def scene_stats(sb):
+    """What kind of frame this is (untimed, one forward through the native entry): instances per Gaussian, per-tile list lengths, how
+    deep the tiles were walked -- and which of the large-splat mechanisms it triggers: the occlusion cut-off (automatic: on after a frame
+    with >= 4 instances per Gaussian), the partial sort (lists beyond 2048 entries), the cooperative per-Gaussian backward kernel
+    (64-Gaussian groups beyond 1024 gradient slots; launched from 192 such groups on)."""
+    from gscream_amd import _layout, rasterizer as RZ
+    means3D, opac, unc, colors, scales, rots = sb.leaves
+    e = torch.Tensor([])
+    with torch.no_grad():
+        R, _c, _d, _u, radii, geom, binning, img, cap = RZ._forward_native(means3D.detach(), e, colors.detach(), opac.detach(), unc.detach(),
+                                                                         scales.detach(), rots.detach(), e, sb.rs)
+    gv, iv = _layout.geom_views(geom, sb.P), _layout.image_views(img, sb.P, sb.W, sb.H)
+    tiles = gv["tiles"].cpu().numpy().astype(np.int64)
+    ranges = iv["ranges"].cpu().numpy().astype(np.int64)
+    ll = ranges[:, 1] - ranges[:, 0]
+    tw = iv["tile_work"].cpu().numpy().astype(np.int64)
+    vis = tiles[tiles > 0]
+    q = lambda a: {} if a.size == 0 else {"mean": round(float(a.mean()), 2), "p50": int(np.percentile(a, 50)), "p90": int(np.percentile(a, 90)),
+                                          "p99": int(np.percentile(a, 99)), "max": int(a.max())}
+    pad = (-tiles.size) % 64
+    group_slots = np.concatenate([tiles, np.zeros(pad, np.int64)]).reshape(-1, 64).sum(axis=1)
+    heavy = int((group_slots > 1024).sum())
+    hist = lambda a, edges: {f"<={b}": int(((a > a_) & (a <= b)).sum()) for a_, b in zip([-1] + edges[:-1], edges)}
+    occ = RZ._occlusion_state.get(sb.leaves[0].device.index, {"on": False})["on"] if RZ._occlusion_mode[0] is None else bool(RZ._occlusion_mode[0])
+    return {"gaussians": int(sb.P), "binned_on_screen": int((tiles > 0).sum()), "num_rendered": int(R),
+            "instances_per_binned_gaussian": q(vis), "instances_per_gaussian_hist": hist(vis, [1, 2, 4, 8, 16, 32, 64, 1 << 30]),
+            "tile_list_length": q(ll), "tile_list_length_hist": hist(ll, [64, 256, 512, 1024, 2048, 4096, 1 << 30]),
+            "tile_depth_walked": q(tw), "walked_fraction_of_binned": round(float(np.minimum(tw, ll).sum()) / max(1, int(ll.sum())), 4),
+            "mechanisms": {"occlusion_cut_on_next_frame": bool(occ), "occlusion_rule": "on after a frame with num_rendered >= 4 x Gaussians",
+                           "instances_per_gaussian_all": round(float(R) / max(1, sb.P), 2),
+                           "partial_sort_fires": bool(ll.max() > 2048) if ll.size else False, "longest_list": int(ll.max()) if ll.size else 0,
+                           "heavy_groups_gt_1024_slots": heavy, "heavy_kernel_launched": bool(heavy >= 192)}}
 
 
 def stage_algorithmic_bytes(P, R, N, T):
@@ -512,7 +559,7 @@ def train_iteration_cpu_baseline(model, cam_np, vis, W, H, tfx, tfy, gt, midas, 
                       f"fwd, R={st['num_rendered']} -> loss oracle -> gs_oracle.c bwd -> autograd to the model parameters): {dt:.1f} s"}
 
 
-def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0, with_cpu=False):
+def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0, with_cpu=False, model_kind="standin"):
     """One complete training iteration of the renderer as train.py runs it on the reference view (train.py:433 anchor
     prefilter -> :527 render with the visible mask -> :535-561 RGB loss incl. the foreground term and the depth loss with
     its foreground term -> :575 backward -> :597-602 training_statis), minus the optimiser step, every piece on the HIP rows."""
@@ -523,7 +570,16 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
     from gscream_amd import gaussian_renderer as GR
     from gscream_amd import loss_utils as L
     from gscream_amd import standin_model as SM
-    model = SM.Model(N, K, seed=11, dtype=torch.float32, spread=1.5).to(dev)
+    if model_kind == "init_state":
+        # the state GaussianModel.create_from_pcd leaves for a synthetic SfM-like surface cloud (synthetic.surface_point_cloud ->
+        # standin_model.Model.from_pcd: scene/gaussian_model.py:301-345 restated), i.e. what iteration 0 of a GScream run renders
+        from gscream_amd import simple_knn as KN
+        pts = SM.voxelize(S.surface_point_cloud(1, N, 0.6, H / W), 0.001)
+        anchors = torch.from_numpy(pts).float().to(dev)
+        model = SM.Model.from_pcd(anchors, torch.clamp_min(KN.distCUDA2(anchors), 0.0000001), K=K, seed=1).to(dev)
+        N = int(anchors.shape[0])
+    else:
+        model = SM.Model(N, K, seed=11, dtype=torch.float32, spread=1.5).to(dev)
     if log_scale_shift:
         # (diagnostic) The stand-in's random covariance MLP decodes splats with a sigma of ~10 px (13 tiles each: R = 13.5M);
         # shifting the anchors' log-scales shrinks them.  At -2 the scene is 860k tiny, faint splats in a blob: R = 1.6M, nothing
@@ -532,7 +588,8 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
         with torch.no_grad():
             model._scaling += float(log_scale_shift)
     w2c = np.eye(4, dtype=np.float32)
-    w2c[2, 3] = 6.0
+    if model_kind != "init_state":  # (the surface cloud is built in front of a camera at the origin; the stand-in blob sits around it)
+        w2c[2, 3] = 6.0
     tfx, tfy = 0.6, 0.6 * H / W
     view, proj, campos = S.camera_matrices(tfx, tfy, w2c)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -601,7 +658,7 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
                                                gt, midas, rgb_w, valid, fg_mask)
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
-    return {"roofline": roof, "cpu_baseline": cpu,
+    return {"roofline": roof, "cpu_baseline": cpu, "model": model_kind,
             "what": f"train iteration on the HIP rows: prefilter_position2D ({N} anchors) -> decode the visible anchors ({sizes.get('visible_anchors')} x {K} "
                     f"-> {sizes.get('gaussians')} Gaussians) -> rasterize @ {W}x{H} -> RGB loss (fg-weighted L1 + SSIM) + depth loss (fit, L1 incl. the "
                     "foreground term, 4-scale gradient loss) -> backward to the MLP weights / anchor parameters -> training_statis; no optimiser step",
@@ -875,6 +932,7 @@ class SceneBench:
         from gscream_amd import GaussianRasterizationSettings, GaussianRasterizer
         from gscream_amd import synthetic as S
         s = scene_for(workload, scene_seed, P, W, H)
+        P = int(s["means3D"].shape[0])  # (a model-derived workload decides its own size)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.leaves = [t(s[k]).requires_grad_(True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")]
         self.means2D = torch.zeros_like(self.leaves[0], requires_grad=True)
@@ -1029,7 +1087,7 @@ def main():
 
     P, W, H, seed, gsel, desc = WORKLOADS[args.workload]
     sb = SceneBench(dev, P, W, H, multi.scene_seed(seed, rank, world), seed, gsel, args.workload)  # one independent scene per GPU
-    step, rs = sb.step, sb.rs
+    step, rs, P = sb.step, sb.rs, sb.P
     means3D, opac, unc, colors, scales, rots = sb.leaves
 
     def barrier():
@@ -1137,6 +1195,7 @@ def main():
                                                       "algorithmic_GB": round(total_bytes_ref / 1e9, 4),
                                                       "frac_of_hbm_peak": round(total_bytes_ref / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBS, 4)}},
             "stages": stages,
+            "scene_stats": scene_stats(sb),
             "stages_note": "survey_model_* = SURVEY 8(d) per-stage bytes of the REFERENCE algorithm (e.g. six radix passes for tile_sort) over our "
                            "launch time: a work-equivalent rate that can exceed the HBM peak where our kernel moves fewer bytes; pmc_moved_* = bytes "
                            "the launch really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_latest.json)",
@@ -1164,6 +1223,9 @@ def main():
                     ("neural_gaussian_decode", lambda: decode_row(dev, not args.no_cpu_baseline)),
                     ("pipeline_decode_raster_loss", lambda: pipeline_row(dev)),
                     ("train_iteration", lambda: train_iteration_row(dev, with_cpu=not args.no_cpu_baseline)),
+                    # the same iteration on the model state the reference's own initialisation produces (the stand-in's
+                    # N(0, 3) anchors / N(-2, 0.3) log-scales are arbitrary; this cloud and its scales follow create_from_pcd)
+                    ("train_iteration_init_state", lambda: train_iteration_row(dev, model_kind="init_state")),
                     ("render_fps", lambda: render_fps_row(dev, sb)),
                     ("simple_knn", lambda: knn_row(dev, not args.no_cpu_baseline)))
             out["next_rows"] = {}

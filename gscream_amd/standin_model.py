@@ -2,8 +2,17 @@
 (scene/gaussian_model.py:118-144 MLPs, :43-54 activations, :241-242 get_scaling, :265-266 get_rotation, the
 densification accumulators; scene/cameras.py camera_center and the fields render() / prefilter_*() read).
 A seeded parameter container for tests and bench.py -- no arithmetic of the path lives here."""
+import numpy as np
 import torch
 from torch import nn
+
+
+def voxelize(points, voxel_size=0.001):
+    """GaussianModel.voxelize_sample (scene/gaussian_model.py:295-299): snap to a voxel_size grid and keep one point per voxel
+    (np.unique sorts, so the reference's shuffle in front of it has no effect on the result).  0.001 is the reference's default
+    (arguments/__init__.py:52); `voxel_size <= 0` there means "the median 3-NN distance" (:306-313), which the caller computes."""
+    points = np.asarray(points)
+    return np.unique(np.round(points / voxel_size), axis=0) * voxel_size
 
 
 class Camera:
@@ -47,6 +56,21 @@ class Model(nn.Module):
         if use_feat_bank:                                # :107-113 (view-adaptive feature bank, off in every shipped config)
             self.mlp_feature_bank = nn.Sequential(nn.Linear(3 + 1, feat_dim), nn.ReLU(True), nn.Linear(feat_dim, 3),
                                                   nn.Softmax(dim=1)).to(dtype)
+
+    @classmethod
+    def from_pcd(cls, anchors, dist2, K=10, feat_dim=32, seed=0):
+        """The state GaussianModel.create_from_pcd leaves (scene/gaussian_model.py:301-345) for the voxelised points `anchors` [N,3]
+        and their clamped mean 3-NN squared distances `dist2` [N] (simple_knn.distCUDA2, clamp_min 1e-7): `_scaling` = log(sqrt(dist2))
+        in all six columns, zero offsets and anchor features, identity rotations; the MLPs keep nn.Linear's default initialisation
+        (the reference builds them with plain nn.Sequential(nn.Linear, ...), :118-144)."""
+        N = int(anchors.shape[0])
+        m = cls(N, K, feat_dim=feat_dim, seed=seed, dtype=torch.float32)
+        with torch.no_grad():
+            m._anchor.copy_(anchors.detach().float().cpu())
+            m._anchor_feat.zero_()
+            m._offset.zero_()
+            m._scaling.copy_(torch.log(torch.sqrt(dist2.detach().float().cpu()))[:, None].repeat(1, 6))
+        return m
 
     get_anchor = property(lambda self: self._anchor)
     get_scaling = property(lambda self: 1.0 * torch.exp(self._scaling))  # :241-242

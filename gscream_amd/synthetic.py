@@ -134,6 +134,70 @@ def scene_surfaces(seed, P, W, H, tanfovx=0.6, bg=(0.0, 0.0, 0.0), scale_mu=0.01
         bg=np.asarray(bg, np.float32), scale_modifier=1.0)
 
 
+def surface_point_cloud(seed, n_points=200_000, tanfovx=0.6, aspect=567.0 / 1008.0):
+    """A synthetic stand-in for the SfM point cloud GScream initialises a SPIn-NeRF scene from (scene/dataset_readers.py ->
+    GaussianModel.create_from_pcd): a forward-facing capture (camera at the origin looking down +z, COLMAP axes: y down) of a room
+    corner -- floor, back wall, side wall, a table top and two round objects on it, a few percent stray points -- sampled with the
+    uneven density SfM gives (denser where textured / near).  [n, 3] float64, metres; every point inside a 1.2x frustum, z in 2..10."""
+    rng = np.random.default_rng(seed)
+    tanfovy = tanfovx * aspect
+    share = np.array([0.30, 0.25, 0.10, 0.17, 0.08, 0.06, 0.04])
+    cnt = np.floor(share * n_points).astype(int)
+    cnt[0] += n_points - cnt.sum()
+    parts = []
+    u = lambda n, a, b: rng.uniform(a, b, size=n)
+    # floor: y = 1.3 (below the camera), slightly tilted; denser near the camera
+    z = 2.0 + 8.0 * rng.beta(1.2, 2.0, size=cnt[0]); x = u(cnt[0], -1.2, 1.2) * tanfovx * z
+    parts.append(np.stack([x, 1.3 + 0.02 * x + 0.01 * np.sin(3.0 * z), z], 1))
+    # back wall at z ~ 9.5 with a shallow relief
+    x = u(cnt[1], -1.2, 1.2) * tanfovx * 9.5; y = u(cnt[1], -1.2, 1.0) * tanfovy * 9.5
+    parts.append(np.stack([x, y, 9.5 + 0.05 * np.sin(2.0 * x) * np.cos(3.0 * y)], 1))
+    # left side wall: x = -0.9 tan z ... a plane receding from the camera
+    z = u(cnt[2], 3.0, 9.5); y = u(cnt[2], -1.0, 1.0) * tanfovy * z
+    parts.append(np.stack([-0.95 * tanfovx * z + 0.3, y, z], 1))
+    # table top (the object the reference removes sits on it): y = 0.45, z in 3.5..5.5
+    z = u(cnt[3], 3.5, 5.5); x = u(cnt[3], -1.4, 1.4)
+    parts.append(np.stack([x, np.full(cnt[3], 0.45), z], 1))
+    # two round objects on the table
+    for k, (c, r) in zip((4, 5), (((-0.4, 0.05, 4.3), 0.40), ((0.55, 0.20, 4.8), 0.25))):
+        d = rng.normal(size=(cnt[k], 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[:, 2] = -np.abs(d[:, 2])          # the half facing the camera
+        parts.append(np.asarray(c)[None, :] + r * d)
+    # stray points (SfM outliers) anywhere in the frustum
+    z = u(cnt[6], 2.0, 10.0)
+    parts.append(np.stack([u(cnt[6], -1.1, 1.1) * tanfovx * z, u(cnt[6], -1.1, 1.1) * tanfovy * z, z], 1))
+    pts = np.concatenate(parts, 0)
+    pts += 0.002 * rng.normal(size=pts.shape)       # triangulation noise, 2 mm
+    return pts
+
+
+def scene_init_state(seed, W, H, n_points=200_000, K=10, tanfovx=0.6, bg=(0.0, 0.0, 0.0), device="cuda", return_model=False):
+    """The frame GScream renders at ITERATION 0 of a scene: `surface_point_cloud` -> the reference's initialisation restated
+    (standin_model.Model.from_pcd = scene/gaussian_model.py:295-345: voxelise at voxel_size 0.001, anchor scales
+    log(sqrt(mean 3-NN dist^2)) from this package's distCUDA2, zero offsets / features, identity rotations, default-init MLPs) -> the
+    fused decode at a camera at the origin -> the rasterizer-level scene dict the other generators return.  Needs the GPU rows
+    (gsr_knn_mean_dist2, gsr_decode_*): there is no CPU path in this package."""
+    import torch
+    from . import neural_gaussians as NG
+    from . import simple_knn as KN
+    from . import standin_model as SM
+    pts = SM.voxelize(surface_point_cloud(seed, n_points, tanfovx, H / W), 0.001)
+    anchors = torch.from_numpy(pts).float().to(device)
+    dist2 = torch.clamp_min(KN.distCUDA2(anchors), 0.0000001)
+    model = SM.Model.from_pcd(anchors, dist2, K=K, seed=seed).to(device)
+    tanfovy = tanfovx * H / W
+    view, proj, campos = camera_matrices(tanfovx, tanfovy)
+    cam = SM.Camera(torch.from_numpy(campos).to(device))
+    model.eval()
+    with torch.no_grad():
+        xyz, color, opacity, unc, scaling, rot = NG.generate_neural_gaussians(cam, model, None, is_training=False)
+    n = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy())
+    s = dict(means3D=n(xyz), scales=n(scaling), rotations=n(rot), opacities=n(opacity).reshape(-1, 1), uncertainties=n(unc).reshape(-1, 1),
+             colors=n(color), W=W, H=H, tanfovx=float(tanfovx), tanfovy=float(tanfovy), viewmatrix=view, projmatrix=proj, campos=campos,
+             bg=np.asarray(bg, np.float32), scale_modifier=1.0, anchors=int(anchors.shape[0]))
+    return (s, model) if return_model else s
+
+
 def scene_stack(seed=5, P=1500, n_stack=700, W=112, H=71):
     """SURVEY 8(c) fixture 5: many Gaussians stacked on the centre pixel (multi-batch tile lists,
     T < 1e-4 early stop) on a non-multiple-of-16 image."""

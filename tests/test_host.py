@@ -186,3 +186,37 @@ def test_occlusion_cutoff_switches_itself_from_what_the_frames_look_like():
     assert RZ._occlusion_mode[0] is False and not RZ._occlusion_state
     RZ.set_tuning()
     assert RZ._occlusion_mode[0] is None
+
+
+def test_init_state_generator_follows_create_from_pcd():
+    """synthetic.surface_point_cloud -> standin_model.voxelize / Model.from_pcd: the state scene/gaussian_model.py:301-345 leaves
+    (voxelised anchors, _scaling = log(sqrt(mean 3-NN dist^2)) in all six columns, zero offsets / features, identity rotations,
+    default-init MLPs), here with the exact 3-NN distances of the kNN oracle in the place of distCUDA2 (the GPU path uses this
+    package's gsr_knn_mean_dist2, tested against the same oracle)."""
+    import numpy as np
+    from gscream_amd import standin_model as SM
+    from gscream_amd import synthetic as S
+    from oracle import decode_oracle as DO
+    from oracle import knn_oracle as KO
+    pts = S.surface_point_cloud(3, 6000)
+    assert pts.shape == (6000, 3) and pts[:, 2].min() > 1.9 and pts[:, 2].max() < 10.1
+    assert np.array_equal(pts, S.surface_point_cloud(3, 6000)) and not np.array_equal(pts, S.surface_point_cloud(4, 6000))
+    v = SM.voxelize(pts, 0.001)
+    assert v.shape[0] <= 6000 and np.abs(v / 0.001 - np.round(v / 0.001)).max() < 1e-6            # on the grid
+    assert np.unique(np.round(v / 0.001), axis=0).shape[0] == v.shape[0]                         # one point per voxel
+    coarse = SM.voxelize(pts, 0.5)
+    assert coarse.shape[0] < 2000                                                                 # a coarse grid merges points
+    d2 = np.maximum(KO.mean_dist2(v), 1e-7)
+    m = SM.Model.from_pcd(torch.from_numpy(v).float(), torch.from_numpy(d2).float(), K=10, seed=1)
+    assert torch.equal(m._anchor.detach(), torch.from_numpy(v).float())
+    assert not m._offset.any() and not m._anchor_feat.any() and bool((m.get_rotation[:, 0] == 1).all())
+    want = np.log(np.sqrt(d2)).astype(np.float32)
+    assert np.allclose(m._scaling.detach().numpy(), np.repeat(want[:, None], 6, axis=1), rtol=0, atol=1e-6)
+    # decoded at the origin: every offset of an anchor sits ON the anchor (zero offsets), about half pass opacity > 0, faint
+    m.eval()
+    with torch.no_grad():
+        xyz, color, opacity, unc, scaling, rot = DO.generate_neural_gaussians(SM.Camera(torch.zeros(3)), m, None, False)
+    assert 0.2 * 10 * v.shape[0] < xyz.shape[0] < 0.8 * 10 * v.shape[0]
+    d = torch.cdist(xyz[:50].double(), m._anchor.detach().double()).min(dim=1).values
+    assert float(d.max()) < 1e-6
+    assert 0.0 < float(opacity.mean()) < 0.4 and float(opacity.max()) < 1.0
