@@ -63,6 +63,51 @@ def pick_device(local_rank, oversubscribe=False):
     return local_rank % max(n, 1)
 
 
+def pin_to_gpu_numa(device_index):
+    """Keep this rank's host threads on the NUMA node its GPU hangs off (one process per GPU: the launch path -- Python, ctypes, the
+    pinned read-back word -- then never crosses the socket interconnect).  Best effort and Linux only: the node comes from the
+    device's PCI address in sysfs, the CPU list from /sys/devices/system/node; without either (containers often hide them, or report
+    node -1) nothing is changed.  Returns what was done, for the bench line."""
+    info = {"pinned": False, "numa_node": None, "cpus": None, "why": None}
+    try:
+        if not hasattr(os, "sched_setaffinity"):
+            info["why"] = "os.sched_setaffinity not available"
+            return info
+        bdf = None
+        try:
+            from torch.cuda import get_device_properties
+            pr = get_device_properties(device_index)
+            dom, bus, dv = getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)
+            if bus is not None and dv is not None:
+                bdf = f"{int(dom):04x}:{int(bus):02x}:{int(dv):02x}.0"
+        except Exception as e:  # noqa: BLE001
+            info["why"] = f"no PCI address for device {device_index}: {e!r}"
+        node = None
+        if bdf is not None:
+            path = f"/sys/bus/pci/devices/{bdf}/numa_node"
+            if os.path.exists(path):
+                node = int(open(path).read().strip())
+            else:
+                info["why"] = f"{path} not present"
+        if node is None or node < 0:
+            info["why"] = info["why"] or f"sysfs reports numa_node {node} for {bdf}"
+            return info
+        cl = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+        cpus = set()
+        for part in cl.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            info["why"] = f"node {node} has no CPU this process may run on"
+            return info
+        os.sched_setaffinity(0, allowed)
+        info.update(pinned=True, numa_node=node, cpus=len(allowed), why=f"GPU {device_index} ({bdf}) is on NUMA node {node}")
+    except Exception as e:  # noqa: BLE001
+        info["why"] = repr(e)
+    return info
+
+
 class SceneQueue:
     """Shared work queue for more scenes than GPUs (BASELINE.json config 5: ten SPIn-NeRF scenes on eight GPUs; the
     reference trains them one after the other, scripts/run.py:14-80).  A rank that finishes a scene pulls the next

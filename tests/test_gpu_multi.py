@@ -190,6 +190,11 @@ def test_bench_gpus_flag_launches_the_ranks_itself(native_lib):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collective_world_size"] == 2 and line["scaling"] == "weak"
     assert line["config"]["oversubscribed_test_mode"] is True
+    # round 5: every rank's own figures travel on the line (gathered with multi.gather_objects)
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["iters_per_s"] > 0 and r["num_rendered"] > 0 and r["host_ms"] > 0 for r in pr)
+    assert all("numa" in r and "pinned" in r["numa"] for r in pr)
+    assert abs(line["value"] - 2 * min(r["iters_per_s"] for r in pr)) <= 0.02 * line["value"], "value = all steps / the slowest rank"
     one = json.loads([l for l in _bench("--gpus", "1").stdout.splitlines() if l.startswith("{")][-1])
     assert one["n_gpus"] == 1 and one["value"] > 0
 
@@ -207,3 +212,4 @@ def test_config5_work_queue_runs_every_scene_once(native_lib):
     assert all(600_000 <= s["P"] <= 1_400_000 for s in line["scenes"])
     assert line["checks_passed"] == 10 and all(s["check_ok"] for s in line["scenes"]), "every scene's outputs are checked on its rank"
     assert line["wall_clock"]["seconds_first_to_last_barrier"] >= line["slowest_rank_busy_s"]
+    assert sorted(sum((r["scenes"] for r in line["per_rank"]), [])) == list(range(10)) and all(r["build_all_scenes_s"] > 0 for r in line["per_rank"])

@@ -5,7 +5,12 @@ CPU analysis on the oracle's forward state (sampled tiles): for every traversed 
   pairs_G  = (instance, block) pairs with at least one blending pixel        (what a block-level compaction would walk)
   util_G   = blending (instance, pixel) pairs / (pairs_G * pixels per block)  (lane utilisation of those iterations)
   iters_4  = sum over groups of 4 sibling blocks of max(block list length)    (4 blocks per wavefront, one per DPP row)
-usage: python tools/lane_utilisation.py [ntiles]"""
+Round 5 ("opposite-half pairing"): the backward's lane holds one pixel of the strip's LEFT 8x8 half and one of
+the RIGHT half; an instance that blends only left pixels and one that blends only right pixels commute (no pixel sees both), so the
+two could share ONE packed iteration; instances that blend in both halves are barriers.  Per (tile, strip, 64-position depth
+segment) -- the backward's work unit -- the walk's sequence of blending instances is classified L / R / both and the iterations
+that vanish are counted for pairing windows of 1, 4, 8 and unbounded (greedy zip of the L and R sub-sequences between barriers).
+usage: python tools/lane_utilisation.py [ntiles] [workload: config2 | config3 | config4 | surfaces]"""
 import os
 import sys
 
@@ -18,10 +23,34 @@ import helpers as Hh  # noqa: E402
 from gscream_amd import synthetic as S  # noqa: E402
 
 
+def paired_iterations(seq, window):
+    """seq: array of 1 (left only), 2 (right only), 3 (both), in walk order.  Iterations when a left-only and a right-only instance
+    at most `window` sequence positions apart (None = any) may share one; both-half instances are barriers."""
+    it, pend_type, pend = 0, 0, []
+    for k, t in enumerate(seq):
+        if t == 3:
+            it += 1
+            pend, pend_type = [], 0
+            continue
+        if window is not None:
+            while pend and pend[0] < k - window:
+                pend.pop(0)
+        if pend and pend_type != t:
+            pend.pop(0)          # rides along with the pending opposite-half instance
+        else:
+            if not pend:
+                pend_type = t
+            pend.append(k)
+            it += 1
+    return it
+
+
 def main():
     ntiles = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    P, W, H = 1_000_000, 1008, 567
-    s = S.scene_slab(1, P, W, H)
+    wl = sys.argv[2] if len(sys.argv) > 2 else "config2"
+    seed, P, W, H = {"config2": (1, 1_000_000, 1008, 567), "config3": (2, 1_000_000, 1008, 567), "config4": (3, 2_000_000, 1920, 1080),
+                     "surfaces": (1, 1_000_000, 1008, 567)}[wl]
+    s = (S.scene_surfaces if wl == "surfaces" else S.scene_slab)(seed, P, W, H)
     st = Hh.oracle_forward(s, nthreads=os.cpu_count())
     gx, gy = (W + 15) // 16, (H + 15) // 16
     rng = np.random.default_rng(0)
@@ -31,6 +60,9 @@ def main():
     tot_pairs = 0
     acc = {k: dict(pairs=0, iters4=0) for k in grans}
     trav = 0
+    windows = (1, 4, 8, None)
+    pair_now, pair_single, pair_after = 0, 0, {w: 0 for w in windows}
+    seg_len = 64 if gx * gy <= 4096 else 128
     for t in tiles:
         tx, ty = t % gx, t // gx
         a, b = st["ranges"][t]
@@ -46,6 +78,21 @@ def main():
         alpha = np.minimum(0.99, con[ids, 3][:, None, None] * np.exp(power))
         blend = (power <= 0) & (alpha >= 1 / 255) & (np.arange(depth)[:, None, None] < nc[None])   # [n,16,16]
         tot_pairs += int(blend.sum())
+        # opposite-half pairing, per (strip, depth segment): the backward walks back to front, the count does not depend on direction
+        for strip in range(2):
+            left = blend[:, strip * 8:strip * 8 + 8, 0:8].any(axis=(1, 2))
+            right = blend[:, strip * 8:strip * 8 + 8, 8:16].any(axis=(1, 2))
+            pat = left.astype(np.int8) + 2 * right.astype(np.int8)
+            for lo in range(0, depth, seg_len):
+                hi = depth if lo // seg_len >= 7 else min(depth, lo + seg_len)   # the last of 8 segments takes the rest
+                seq = pat[lo:hi]
+                seq = seq[seq > 0]
+                pair_now += int(seq.size)
+                pair_single += int((seq < 3).sum())
+                for w in windows:
+                    pair_after[w] += paired_iterations(seq, w)
+                if lo // seg_len >= 7:
+                    break
         for k, (bw, bh) in grans.items():
             blk = blend.reshape(depth, 16 // bh, bh, 16 // bw, bw).any(axis=(2, 4))   # [n, by, bx]
             cnt = blk.sum(0)                                                        # list length per block
@@ -58,7 +105,12 @@ def main():
         p = acc[k]["pairs"]
         print(f"  {k:5s}: (instance, block) pairs per tile {p / ntiles:8.0f}   lane utilisation {tot_pairs / (p * bw * bh):.3f}   "
               f"4-block wave iterations per tile {acc[k]['iters4'] / ntiles:8.0f}  (balance {p / 4 / max(acc[k]['iters4'], 1):.2f})")
+    print(f"opposite-half pairing ({wl}, segments of {seg_len}): blending (instance, strip) iterations per tile {pair_now / ntiles:.0f}, "
+          f"{pair_single / max(pair_now, 1):.1%} of them touch one 8x8 half only")
+    for w in windows:
+        print(f"  window {str(w):>4s}: {pair_after[w] / ntiles:8.0f} iterations per tile, {1 - pair_after[w] / max(pair_now, 1):.1%} vanish")
 
 
+    # (printed by main, kept separate for readability)
 if __name__ == "__main__":
     main()
