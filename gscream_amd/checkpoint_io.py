@@ -6,6 +6,13 @@ Host-side I/O only (no kernels).  The reference writes both with third-party pac
 directly: the standard header `plyfile` emits for one `vertex` element of float32 properties
 (`format binary_little_endian 1.0`), followed by the packed records.
 
+PARITY OF THE LAYOUT: **unpinned** -- `plyfile` is not installed in the build container, so no file written by the reference's own
+`PlyData.write` exists to compare with; the header below is the one plyfile's documentation specifies for a structured array of
+'f4' fields (`ply` / `format binary_little_endian 1.0` / `element vertex N` / one `property float <name>` line per field in dtype
+order / `end_header`, newline-terminated ASCII, records packed without padding).  tests/test_checkpoint_io.py writes such a file
+byte by byte (independently of `save_ply`), with the optional `comment` / `obj_info` lines plyfile preserves, and checks that the
+reader recovers every column and that `save_ply` emits exactly those header bytes.
+
     attribute order:  x y z  nx ny nz  f_offset_0..(3K-1)  f_anchor_feat_0..(F-1)  opacity  uncertainty  scale_0..5  rot_0..3
     f_offset_i       : `_offset.transpose(1, 2).flatten(1)`  (component-major: index c*K + k), undone on load
 """
@@ -63,7 +70,7 @@ def _read_vertex_table(path):
             if not line:
                 raise ValueError(f"{path}: truncated PLY header")
             tok = line.decode("ascii", "replace").split()
-            if not tok or tok[0] == "comment":
+            if not tok or tok[0] in ("comment", "obj_info"):
                 continue
             if tok[0] == "format":
                 fmt = tok[1]

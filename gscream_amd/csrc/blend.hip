@@ -578,67 +578,85 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             const uint32_t fpid = (uint32_t)__builtin_amdgcn_readlane((int)pid, f);
             float Tq = 1.0f;  // the reference's T (wave-uniform)
             float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;  // sums of the open segment (uniform)
-            float E0 = 0.f, E1 = 0.f, E2 = 0.f, E3 = 0.f, E4 = 0.f;  // sums of the closed segments
+            // (sums of the closed segments: in LDS, sRep[0..4], touched once per segment -- five registers the walk loop's
+            // allocation does not have to leave room for: 74 VGPRs = 6 waves per SIMD with them, 72 = 7 without)
+            __shared__ float sRep[8];
+            if (lane < 5) sRep[lane] = 0.0f;
             int np2 = 0;
             uint32_t lastq = 0u;
             bool stoppedq = false;
+            // Software pipeline over the batches: list entries two batches ahead and records one batch ahead are in flight while a
+            // batch is evaluated (a replay is a chain of dependent L2 round trips at the END of a wave's life: its latency, not its
+            // instruction count, is what the launch pays -- first version, loads inside the loop + a scalar T loop: forward 94 -> 114 us)
+            auto fetch_id = [&](const int b) -> uint32_t { return b + lane < n ? (ids[b + lane] & 0x7fffffffu) : 0xffffffffu; };
+            struct RecRegs { float4 a; float4 b; };  // (the colour is requested at the top of its own batch: the ripple covers its latency)
+            auto fetch_rec = [&](const uint32_t gid) -> RecRegs {
+                RecRegs r = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+                if (gid != 0xffffffffu) { const GsrRec* q = rec + gid; r.a = q->a; r.b = q->b; }
+                return r;
+            };
+            uint32_t gid_cur = fetch_id(0), gid_nxt = fetch_id(GSR_FWB);
+            RecRegs rc_cur = fetch_rec(gid_cur);
             for (int b0 = 0; b0 < n && !stoppedq; b0 += GSR_FWB) {
+                const uint32_t gid_nn = fetch_id(b0 + 2 * GSR_FWB);
+                const RecRegs rc_nxt = fetch_rec(gid_nxt);
+                float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gid_cur != 0xffffffffu) col = rec[gid_cur].c;
                 if (b0 > 0 && (b0 & (seg_len - 1)) == 0 && np2 < GSR_SEG_MAX - 1) {  // same restarts as the walk above
                     if (TRAIN && lane == 0) {
                         gsr_ckpt_a(ckpt, np2, HW)[fpid] = make_float4(Tq, S0, S1, S2);
                         gsr_ckpt_b(ckpt, np2, HW)[fpid] = make_float2(S3, S4);
                     }
                     np2++;
-                    E0 += S0; E1 += S1; E2 += S2; E3 += S3; E4 += S4;
+                    if (lane < 5) sRep[lane] += lane == 0 ? S0 : lane == 1 ? S1 : lane == 2 ? S2 : lane == 3 ? S3 : S4;
                     S0 = 0.f; S1 = 0.f; S2 = 0.f; S3 = 0.f; S4 = 0.f;
                 }
-                const int c2 = min(GSR_FWB, n - b0);
                 GsrExactAlpha ea = {0.f, 1.f, false, false};
-                float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
-                float rdep = 0.f, rfeat = 0.f;
-                if (lane < c2) {
-                    const uint32_t gid = ids[b0 + lane] & 0x7fffffffu;
-                    const GsrRec* r = rec + gid;
-                    const float4 ra = r->a, rb = r->b;
-                    rc = r->c; rdep = rb.z; rfeat = rb.w;
-                    ea = gsr_alpha_exact(ra.z, ra.w, rb.x, rb.y, ra.x - fx, ra.y - fy);
+                if (gid_cur != 0xffffffffu) {
+                    ea = gsr_alpha_exact(rc_cur.a.z, rc_cur.a.w, rc_cur.b.x, rc_cur.b.y, rc_cur.a.x - fx, rc_cur.a.y - fy);
                     // the backward runs its own exact alpha check only on flagged list entries: this walk may visit entries
                     // the pixel's fast walk never reached
-                    if (ea.in_band) ids[b0 + lane] = gid | 0x80000000u;
+                    if (ea.in_band) ids[b0 + lane] = gid_cur | 0x80000000u;
                 }
-                unsigned long long m = __builtin_amdgcn_ballot_w64(ea.blends), blended = 0ull;
-                const float Tstart = Tq;
-                while (m != 0ull) {  // the T chain, in list order, rounded like forward.cu:536-549
-                    const int i = (int)__builtin_ctzll(m);
-                    const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ea.one_minus), i));
-                    const float t = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gsr_mul_exact(Tq, o))));
-                    if (t < 0.0001f) { stoppedq = true; break; }
-                    Tq = t;
-                    lastq = (uint32_t)(b0 + i + 1);
-                    blended |= 1ull << i;
-                    m &= m - 1ull;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ea.blends);
+                float w = 0.0f;
+                if (m != 0ull) {  // (wave-uniform)
+                    // The T chain in list order, rounded like forward.cu:536-549 -- T <- fl(T * (1 - alpha)) over the blending instances --
+                    // as a RIPPLE over the lanes: X[i] <- X[i-1] * f[i] (f = 1 - alpha on blending lanes, exactly 1 elsewhere; lane 0
+                    // takes the batch's incoming T) repeated until the highest blending lane has its value: after step s the lanes <= s
+                    // hold the sequentially rounded products.  One DPP wave shift + one multiply per step, no scalar round trips.
+                    const float f = ea.blends ? ea.one_minus : 1.0f;
+                    const int hi = 63 - (int)__builtin_clzll(m);
+                    float X = Tq, Y = Tq;
+                    for (int st = 0; st <= hi; st++) {
+                        Y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Tq), __float_as_int(X), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+                        X = gsr_mul_exact(Y, f);
+                    }
+                    // X = T behind each lane's instance, Y = T in front of it (both final for lanes <= hi); T is non-increasing, so
+                    // the first blending lane whose product is below 1e-4 is where forward.cu:537 stops
+                    const unsigned long long stopm = __builtin_amdgcn_ballot_w64(ea.blends && X < 0.0001f);
+                    unsigned long long blended = m;
+                    if (stopm != 0ull) {
+                        stoppedq = true;
+                        blended = m & ((1ull << __builtin_ctzll(stopm)) - 1ull);
+                    }
+                    if (blended != 0ull) {
+                        const int lb = 63 - (int)__builtin_clzll(blended);
+                        Tq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(X), lb));
+                        lastq = (uint32_t)(b0 + lb + 1);
+                    }
+                    if ((blended >> lane) & 1ull) w = ea.alpha * Y;
                 }
-                // weights alpha_i * T_i: T_i from a prefix product over the blending lanes (sums, not decisions: its rounding differs
-                // from the chain's by ulps)
-                const bool mine = (blended >> lane) & 1ull;
-                float pf = mine ? ea.one_minus : 1.0f;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float q = __shfl_up(pf, d, 64);
-                    if (lane >= d) pf *= q;
-                }
-                float excl = __shfl_up(pf, 1, 64);
-                if (lane == 0) excl = 1.0f;
-                const float w = mine ? ea.alpha * (Tstart * excl) : 0.0f;
-                S0 += gsr_wave_sum(rc.x * w); S1 += gsr_wave_sum(rc.y * w); S2 += gsr_wave_sum(rc.z * w);
-                S3 += gsr_wave_sum(rdep * w); S4 += gsr_wave_sum(rfeat * w);
+                S0 += gsr_wave_sum(col.x * w); S1 += gsr_wave_sum(col.y * w); S2 += gsr_wave_sum(col.z * w);
+                S3 += gsr_wave_sum(rc_cur.b.z * w); S4 += gsr_wave_sum(rc_cur.b.w * w);
+                gid_cur = gid_nxt; gid_nxt = gid_nn; rc_cur = rc_nxt;
             }
             // (a replay that reaches the end of a partially sorted prefix without stopping would need the entries behind it: it is
             // dropped and the pixel keeps its fast walk -- a flip exactly at the cut of a list beyond 2048 entries)
             if (!(nsort < nlist && !stoppedq)) {
                 if (lane == f) {
                     Tr = Tq; C0 = S0; C1 = S1; C2 = S2; Dp = S3; Uf = S4; last = lastq; npl = np2;
-                    sAcc[0][lane] = E0; sAcc[1][lane] = E1; sAcc[2][lane] = E2; sAcc[3][lane] = E3; sAcc[4][lane] = E4;
+                    sAcc[0][lane] = sRep[0]; sAcc[1][lane] = sRep[1]; sAcc[2][lane] = sRep[2]; sAcc[3][lane] = sRep[3]; sAcc[4][lane] = sRep[4];
                 }
                 GSR_COUNT_ADD(3, 1);
             }

@@ -69,3 +69,39 @@ def test_mlp_checkpoint_round_trip(tmp_path):
     for (ka, pa), (kb, pb) in zip(a.state_dict().items(), b.state_dict().items()):
         if ka.startswith("mlp_"):
             assert ka == kb and torch.equal(pa, pb), ka
+
+
+def test_reader_parses_a_file_laid_out_as_plyfile_documents_it(tmp_path):
+    """`plyfile` is absent here, so the PLY layout is UNPINNED against the reference's own writer (checkpoint_io.py says so); this is
+    the next best thing: a file built byte by byte in the test -- the header plyfile documents for `PlyElement.describe(structured
+    array of 'f4' fields, 'vertex')` + `PlyData([el]).write()` on a little-endian host, attribute order of
+    scene/gaussian_model.py:502-514 / :623-642, with the `comment` and `obj_info` lines plyfile carries through -- is read back
+    column by column, and `save_ply` produces the same header bytes (minus the optional lines) and the same record bytes."""
+    from gscream_amd import checkpoint_io as IO
+    N, K, F = 7, 10, 32
+    rng = np.random.default_rng(5)
+    names = (["x", "y", "z", "nx", "ny", "nz"] + [f"f_offset_{i}" for i in range(3 * K)] + [f"f_anchor_feat_{i}" for i in range(F)] +
+             ["opacity", "uncertainty"] + [f"scale_{i}" for i in range(6)] + [f"rot_{i}" for i in range(4)])
+    table = rng.standard_normal((N, len(names))).astype("<f4")
+    table[:, 3:6] = 0.0                                              # normals are zeros (:628)
+    plain = "ply\nformat binary_little_endian 1.0\n" + f"element vertex {N}\n" + "".join(f"property float {n}\n" for n in names) + "end_header\n"
+    annotated = plain.replace("element vertex", "comment written by a test, not by plyfile\nobj_info none\nelement vertex")
+    path = tmp_path / "point_cloud.ply"
+    path.write_bytes(annotated.encode("ascii") + table.tobytes())
+    got = IO.load_ply_sparse_gaussian(str(path))
+    col = {n: table[:, i] for i, n in enumerate(names)}
+    assert np.array_equal(got["anchor"].numpy(), table[:, 0:3])
+    assert np.array_equal(got["opacity"].numpy()[:, 0], col["opacity"]) and np.array_equal(got["uncertainty"].numpy()[:, 0], col["uncertainty"])
+    assert np.array_equal(got["scaling"].numpy(), np.stack([col[f"scale_{i}"] for i in range(6)], 1))
+    assert np.array_equal(got["rotation"].numpy(), np.stack([col[f"rot_{i}"] for i in range(4)], 1))
+    assert np.array_equal(got["anchor_feat"].numpy(), np.stack([col[f"f_anchor_feat_{i}"] for i in range(F)], 1))
+    # f_offset_{c*K + k} = _offset[n, k, c]  (:629 `_offset.transpose(1, 2).flatten(start_dim=1)`, undone at :678-682)
+    off = got["offset"].numpy()
+    assert off.shape == (N, K, 3)
+    for c in range(3):
+        for k in range(K):
+            assert np.array_equal(off[:, k, c], col[f"f_offset_{c * K + k}"])
+    # and the writer: same header text, same record bytes
+    out = tmp_path / "written.ply"
+    IO.save_ply(str(out), got["anchor"], got["offset"], got["anchor_feat"], got["opacity"], got["uncertainty"], got["scaling"], got["rotation"])
+    assert out.read_bytes() == plain.encode("ascii") + table.tobytes()
