@@ -3,8 +3,22 @@ decodes the opaque geom / image / binning byte tensors the forward returns."""
 import torch
 
 
-SEG_MAX = 8  # GSR_SEG_MAX
+SEG1, SEG2 = 7, 8        # GSR_SEG1, GSR_SEG2 (gsr_common.h): two tiers of depth segments
+SEG_MAX = SEG1 + SEG2    # GSR_SEG_MAX: segments per tile = checkpoint slots (SEG_MAX - 1 checkpoints + the "last" slot)
 CKPT_PLANES = SEG_MAX * 6
+
+
+def seg2_len(n, L):
+    """gsr_seg2_len: tier-2 segment length of a tile whose list has n entries (L = 64 up to 4096 tiles, 128 beyond)."""
+    tail = n - SEG1 * L
+    if tail <= 0:
+        return L
+    return max(L, (tail + SEG2 * 64 - 1) // (SEG2 * 64) * 64)
+
+
+def ckpt_pos(k, L, L2):
+    """gsr_ckpt_pos: list position of checkpoint k = 0 .. SEG_MAX-2."""
+    return (k + 1) * L if k < SEG1 else SEG1 * L + (k - SEG1 + 1) * L2
 
 
 def _align(x):

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows",
 )
 NUM_STAGES = 7
-ABI_VERSION = 4  # include/gsraster.h GSR_ABI_VERSION this binding was written against
+ABI_VERSION = 5  # include/gsraster.h GSR_ABI_VERSION this binding was written against
 
 
 class Stage1Result(ctypes.Structure):
@@ -85,7 +85,7 @@ def load():
         + [_vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, ctypes.POINTER(Stage1Result), ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_backward.restype = _c_int
     lib.gsr_backward.argtypes = (
-        [_c_int] * 7 + [_vp] * 6 + [_c_float] + [_vp] * 5 + [_c_float, _c_float] + [_vp] * 3 + [_vp] * 4
+        [_c_int] * 8 + [_vp] * 6 + [_c_float] + [_vp] * 5 + [_c_float, _c_float] + [_vp] * 3 + [_vp] * 4
         + [_vp] * 9 + [ctypes.POINTER(Tuning), _c_int, _vp])
     lib.gsr_filter.restype = _c_int
     lib.gsr_filter.argtypes = [_c_int] * 3 + [_vp, _vp, _c_float] + [_vp] * 4 + [_c_float, _c_float, _c_int] + [_vp] * 3 + [_c_int, _vp]

@@ -468,7 +468,7 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
                               out_color, out_depth, out_feature, debug, stream);
 }
 
-extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity, const float* background,
+extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity, int max_tile_count, const float* background,
                             const float* means3D,
                             const int32_t* radii, const float* colors_precomp, const float* shs, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -512,7 +512,7 @@ extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binnin
     uint8_t* slot_written = bin.slot_written;
     if (R > 0)
         GSR_STAGE(GSR_STAGE_BLEND_BWD, gsr_launch_blend_backward(W, H, cam.gx, T, background, geom, image, bin, dL_dout_color, dL_dout_depth,
-                                            dL_dout_feature, slots, slot_written, heavy, stream),
+                                            dL_dout_feature, slots, slot_written, heavy, max_tile_count > 0 ? max_tile_count : -1, stream),
                   "backward blend");
     else
         GSR_HIP(hipMemsetAsync(heavy, 0, 2 * sizeof(uint32_t), stream), "heavy-group counters");

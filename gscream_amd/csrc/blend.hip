@@ -114,11 +114,23 @@ __device__ __forceinline__ float gsr_mul_exact(const float a, const float b)
 #pragma clang fp contract(off)
     return a * b;
 }
+// Sum over the wavefront, result wave-uniform: quad and row steps as DPP adds, rows combined with row_bcast:15 / :31, lane 63
+// read back (six short-latency VALU steps; the __shfl_xor butterfly is six dependent LDS-crossbar round trips).
 __device__ __forceinline__ float gsr_wave_sum(float v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    auto dpp = [](const float x, const int ctrl_tag) -> float {
+        switch (ctrl_tag) {
+            case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+            case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+            case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, true));   // row_ror:4
+            case 3: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));   // row_ror:8
+            case 4: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+            default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false)); // row_bcast:31 -> rows 2, 3
+        }
+    };
+    v += dpp(v, 0); v += dpp(v, 1); v += dpp(v, 2); v += dpp(v, 3);   // every lane: its row's sum
+    v += dpp(v, 4); v += dpp(v, 5);                                   // lane 63: the wave's sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 #endif
 
@@ -262,6 +274,16 @@ __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const floa
 // run on the same XCD).
 // ---------------------------------------------------------------------------------------------
 #define GSR_FWB 64
+// Stop threshold of the forward's fast walk (forward.cu:537 tests test_T < 0.0001f).  With the exact replay (GSR_TBAND) the fast walk
+// stops only below 1e-4 (1 - band): given that its T is within the band of the reference chain's, it then never stops BEFORE the
+// reference does; where it blends an instance the reference would have stopped at, its T ends below 1e-4 (1 + band) -- so ONE
+// compare at the end of the walk (final T < 1e-4 (1 + band)) finds every pixel whose stop could differ, at no cost inside the loop
+// (a per-blend test of the stopping test_T cost the launch 5 %).
+#if !defined(GSR_PRECISE_MATH) && !defined(GSR_NO_TREPLAY)
+#define GSR_T_STOP (0.0001f * (1.0f - GSR_TBAND))
+#else
+#define GSR_T_STOP 0.0001f
+#endif
 // Dynamic LDS requested (and never touched) per forward workgroup: it caps how many quadrant waves are resident per CU, so
 // that the rest of the 4T workgroups are handed out as earlier ones finish (the dispatcher then balances the SIMDs; with
 // every wave resident from the start a launch lasts as long as its most loaded SIMD).  Compile-time experiment knob
@@ -276,7 +298,7 @@ __device__ __forceinline__ gsr_f2 gsr_splat(float v) { gsr_f2 r = {v, v}; return
 __device__ __forceinline__ gsr_f2 gsr_fma2(gsr_f2 a, gsr_f2 b, gsr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // Checkpoint planes (gsr_common.h): slot k of a pixel = float4 {T_k (last slot: checkpoints passed), r, g, b} + float2
-// {depth, feature}; slot k < GSR_SEG_MAX-1 belongs to list position (k + 1) * segment length, the last one to the end.
+// {depth, feature}; slot k < GSR_SEG_MAX-1 belongs to list position gsr_ckpt_pos(k) (two tiers, gsr_common.h), the last one to the end.
 __device__ __forceinline__ size_t gsr_ckpt_stride(size_t HW) { return (HW + 3) & ~(size_t)3; }  // keeps the float4 slots aligned
 __device__ __forceinline__ float4* gsr_ckpt_a(float* ckpt, int k, size_t HW) { return reinterpret_cast<float4*>(ckpt + (size_t)k * 6 * gsr_ckpt_stride(HW)); }
 __device__ __forceinline__ float2* gsr_ckpt_b(float* ckpt, int k, size_t HW) { return reinterpret_cast<float2*>(ckpt + ((size_t)k * 6 + 4) * gsr_ckpt_stride(HW)); }
@@ -325,6 +347,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     // are in depth order only up to sorted_len[tile] (binning.hip): the walk ends there, and if a pixel is still
     // blending the tile is flagged and redone after a full sort.
     const int nlist = (int)(rg.y - rg.x), nsort = (int)sorted_len[tile];
+    const int seg2_len = gsr_seg2_len(nlist, seg_len);  // tier-2 segment length of this tile (gsr_common.h): from the LIST length
     const int n = (rg.y > capacity || (nsort == nlist && (uint32_t)nlist > longest_sorted)) ? 0 : min(nlist, nsort);
     const bool inside = px < W && py < H;
     const uint32_t HW = (uint32_t)H * (uint32_t)W, pid = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;  // <= 2^24 tiles (api.hip) = at most 2^32 pixels
@@ -401,12 +424,13 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
         if (base == 128) __builtin_amdgcn_s_setprio(1);
         else if (base == 256) __builtin_amdgcn_s_setprio(2);
         else if (base == 384) __builtin_amdgcn_s_setprio(3);
-        // Checkpoint at list position k * seg_len (k = 1 .. GSR_SEG_MAX-1), from which the backward starts its depth
+        // Checkpoint at list position gsr_ckpt_pos(k) (k = 0 .. GSR_SEG_MAX-2), from which the backward starts its depth
         // segment k - 1: the transmittance T_k in front of the position and the sums S_k over the segment that ends
         // there; C0.. restart from zero and the image sums are the sums of the segment sums.  (The
         // backward needs the sum BEHIND a position to a relative accuracy that final - prefix cannot give once T is
         // small: sums of small terms have to stay small.)
-        if (base > 0 && (base & (seg_len - 1)) == 0 && npass < GSR_SEG_MAX - 1) {
+        // (positions are multiples of 64 and batches end at multiples of 64: a checkpoint is always the start of a batch)
+        if (npass < GSR_SEG_MAX - 1 && base == gsr_ckpt_pos(npass, seg_len, seg2_len)) {
             if (TRAIN && inside) {  // (inference: the same restarts, so that the sums associate identically, but nothing is stored)
                 gsr_ckpt_a(ckpt, npass, HW)[pid] = make_float4(Tr, C0, C1, C2);
                 gsr_ckpt_b(ckpt, npass, HW)[pid] = make_float2(Dp, Uf);
@@ -523,12 +547,10 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             auto blend = [&](const unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
                 const float al1 = __builtin_amdgcn_fmed3f(alu, 0.99f, -3.0e38f);  // = min(0.99, alu), one instruction (no NaN canonicalisation in front)
                 const float test_T = Tr * (1.0f - al1);
-                const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & okm;
+                // (GSR_T_STOP: 1e-4, lowered by the replay band in the shipped build -- the fast walk never stops BEFORE the reference would,
+                // so every pixel whose stop could differ ends with its T inside the band, where the end-of-walk test finds it)
+                const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < GSR_T_STOP) & okm;
                 donem |= stopm;
-#if !defined(GSR_PRECISE_MATH) && !defined(GSR_NO_TREPLAY)
-                // a stop that close to 1e-4 may not be the reference's (see GSR_TBAND): remembered, replayed after the walk
-                if (stopm != 0ull) riskm |= __builtin_amdgcn_ballot_w64(test_T >= 0.0001f * (1.0f - GSR_TBAND)) & stopm;
-#endif
                 const unsigned long long okf = okm & ~stopm;
 #ifdef GSR_FWD_EXEC_MASK
                 if (__builtin_amdgcn_inverse_ballot_w64(okf)) {  // EXEC = the pixels that blend: no selects
@@ -565,8 +587,9 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
 
     int npl = npass;  // checkpoints passed, per lane: a replayed pixel's own walk may end in another segment than the wave's
 #if !defined(GSR_PRECISE_MATH) && !defined(GSR_NO_TREPLAY)
-    // ---- exact replay of the pixels near the T = 1e-4 stop (see GSR_TBAND) ----
-    // + pixels whose FINAL T lies just above 1e-4: their last blend passed the stop test by less than the band
+    // ---- exact replay of the pixels near the T = 1e-4 stop (see GSR_TBAND, GSR_T_STOP) ----
+    // final T inside the band around 1e-4 (it can lie BELOW 1e-4: the fast walk stops late rather than early): the last blend passed
+    // the reference's stop test by less than the band, or failed it by less
     riskm |= __builtin_amdgcn_ballot_w64(inside && Tr < 0.0001f * (1.0f + GSR_TBAND));
     // (a quadrant that ran off a partially sorted prefix replays at the end of its resumed walk, over the complete list: the
     // flags travel in bit 30 of n_contrib)
@@ -602,7 +625,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                 const RecRegs rc_nxt = fetch_rec(gid_nxt);
                 float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (gid_cur != 0xffffffffu) col = rec[gid_cur].c;
-                if (b0 > 0 && (b0 & (seg_len - 1)) == 0 && np2 < GSR_SEG_MAX - 1) {  // same restarts as the walk above
+                if (np2 < GSR_SEG_MAX - 1 && b0 == gsr_ckpt_pos(np2, seg_len, seg2_len)) {  // same restarts as the walk above
                     if (TRAIN && lane == 0) {
                         gsr_ckpt_a(ckpt, np2, HW)[fpid] = make_float4(Tq, S0, S1, S2);
                         gsr_ckpt_b(ckpt, np2, HW)[fpid] = make_float2(S3, S4);
@@ -627,11 +650,14 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                     // hold the sequentially rounded products.  One DPP wave shift + one multiply per step, no scalar round trips.
                     const float f = ea.blends ? ea.one_minus : 1.0f;
                     const int hi = 63 - (int)__builtin_clzll(m);
-                    float X = Tq, Y = Tq;
-                    for (int st = 0; st <= hi; st++) {
-                        Y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Tq), __float_as_int(X), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-                        X = gsr_mul_exact(Y, f);
-                    }
+                    // X starts as T_in * f (final for lane 0); a step multiplies lane i's factor onto lane i-1's value IN PLACE: the DPP
+                    // source of lane 0 is invalid, so with bound_ctrl off lane 0 is simply not written.  One v_mul_f32_dpp + the two
+                    // wait states a DPP read of a just-written VGPR needs; no fused multiply-add can form inside the asm.
+                    float X = gsr_mul_exact(Tq, f);
+                    for (int st = 0; st < hi; st++)
+                        asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(X) : "v"(f));
+                    asm volatile("s_nop 1" ::: "memory");
+                    const float Y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Tq), __float_as_int(X), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
                     // X = T behind each lane's instance, Y = T in front of it (both final for lanes <= hi); T is non-increasing, so
                     // the first blending lane whose product is below 1e-4 is where forward.cu:537 stops
                     const unsigned long long stopm = __builtin_amdgcn_ballot_w64(ea.blends && X < 0.0001f);
@@ -750,7 +776,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
     int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots,
-    uint32_t* __restrict__ heavy_groups, const uint32_t* __restrict__ need_full)
+    uint32_t* __restrict__ heavy_groups, const uint32_t* __restrict__ need_full, int nseg /* segments the grid covers per tile */)
 {
     // the per-Gaussian backward that follows appends its heavy groups to a list: this launch, which always precedes it, resets
     // the counter (gauss_bwd.hip)
@@ -774,15 +800,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const int band_first = band < br ? band * (bq + 1) : br * (bq + 1) + (band - br) * bq, band_size = bq + (band < br ? 1 : 0);
     if (band_size == 0) return;
     const int seg = slot / band_size, tile = band_first + (slot - seg * band_size);
-    if (seg >= GSR_SEG_MAX) return;
+    if (seg >= nseg) return;
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
     // Instances behind the tile's deepest contributor were blended by no pixel: they are not traversed and their
     // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots exist.
     const int nproc = min((int)(rg.y - rg.x), (int)tile_work[tile]);
-    const int seg_lo = seg * seg_len;
-    const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, seg_lo + seg_len);
+    const int seg2_len = gsr_seg2_len((int)(rg.y - rg.x), seg_len);  // the forward's choice for this tile: from the list length
+    const int seg_lo = seg == 0 ? 0 : gsr_ckpt_pos(seg - 1, seg_len, seg2_len);
+    const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, gsr_ckpt_pos(seg, seg_len, seg2_len));
     if (seg_hi <= seg_lo) return;
 #if defined(GSR_BWD_DIAG) && GSR_BWD_DIAG == 1  // diagnostic: dispatch + task lookup only
     return;
@@ -838,22 +865,28 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
             float2 fb = make_float2(0.f, 0.f);
             if (AUX) fb = gsr_ckpt_b(ckpt, GSR_SEG_MAX - 1, HW)[p];
             const int np = __float_as_int(fa.x);  // checkpoints this pixel passed (>= seg + 1 here)
-            float4 sa[GSR_SEG_MAX - 1];
-            float2 sb[GSR_SEG_MAX - 1];
-#pragma unroll
-            for (int k = 1; k < GSR_SEG_MAX - 1; k++) {
-                sa[k] = make_float4(0.f, 0.f, 0.f, 0.f); sb[k] = make_float2(0.f, 0.f);
-                if (k < np && k >= seg + 1) {
-                    sa[k] = gsr_ckpt_a(ckpt, k, HW)[p];
-                    if (AUX) sb[k] = gsr_ckpt_b(ckpt, k, HW)[p];
-                }
-            }
+            // the segments behind this one, back to front (smallest sums first), GSR_BEHIND_CHUNK slots per memory round trip: one
+            // trip for walks inside tier 1 (as before the second tier existed), up to three for the deepest
+            constexpr int GSR_BEHIND_CHUNK = GSR_SEG1 - 1;
             float t0 = fa.y, t1 = fa.z, t2 = fa.w, td = fb.x, tu = fb.y;
+            for (int khi = np - 1; khi >= seg + 1; khi -= GSR_BEHIND_CHUNK) {
+                float4 sa[GSR_BEHIND_CHUNK];
+                float2 sb[GSR_BEHIND_CHUNK];
 #pragma unroll
-            for (int k = GSR_SEG_MAX - 2; k >= 1; k--) {  // the segments behind this one, back to front
-                if (k < np && k >= seg + 1) {
-                    t0 += sa[k].y; t1 += sa[k].z; t2 += sa[k].w;
-                    if (AUX) { td += sb[k].x; tu += sb[k].y; }
+                for (int c = 0; c < GSR_BEHIND_CHUNK; c++) {
+                    const int k = khi - c;
+                    sa[c] = make_float4(0.f, 0.f, 0.f, 0.f); sb[c] = make_float2(0.f, 0.f);
+                    if (k >= seg + 1) {
+                        sa[c] = gsr_ckpt_a(ckpt, k, HW)[p];
+                        if (AUX) sb[c] = gsr_ckpt_b(ckpt, k, HW)[p];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < GSR_BEHIND_CHUNK; c++) {
+                    if (khi - c >= seg + 1) {
+                        t0 += sa[c].y; t1 += sa[c].z; t2 += sa[c].w;
+                        if (AUX) { td += sb[c].x; tu += sb[c].y; }
+                    }
                 }
             }
             const float r = 1.0f / Te;
@@ -1149,17 +1182,19 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots, uint8_t* slot_written,
-                                     uint32_t* heavy_groups, hipStream_t stream)
+                                     uint32_t* heavy_groups, int max_tile_count, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
-    // the grid covers GSR_SEG_MAX segments of every tile; workgroups of segments a tile does not have leave at once
-    const dim3 grid(8u * (uint32_t)((T + 7) / 8) * GSR_SEG_MAX);
+    // the grid covers `nseg` segments of every tile; workgroups of segments a tile does not have leave at once.  No list of the frame
+    // reaches into the second tier (longest list <= GSR_SEG1 segments): the grid stops at the first tier, as before it existed
     const int sl = gsr_seg_len(T);
+    const int nseg = (max_tile_count >= 0 && max_tile_count <= GSR_SEG1 * sl) ? GSR_SEG1 + 1 : GSR_SEG_MAX;
+    const dim3 grid(8u * (uint32_t)((T + 7) / 8) * (uint32_t)nseg);
 #define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
-                       geom.offsets, slot_written, s4, heavy_groups, image.need_full)
+                       geom.offsets, slot_written, s4, heavy_groups, image.need_full, nseg)
 #ifdef GSR_BWD_BATCH128  // long segments staged 128 instances at a time (19.5 KB of LDS: 4 waves per SIMD)
     const bool b64 = sl == 64;
 #else                    // long segments in two batches of 64 (9.7 KB: 5 waves per SIMD)

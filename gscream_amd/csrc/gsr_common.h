@@ -21,8 +21,8 @@
 //           tile_count[T] 4 B, tile_work[T] 4 B (max n_contrib per tile)
 //           sorted_len[T] 4 B  length of the depth-sorted prefix of the tile's list (partial sort of long lists),
 //           need_full[T] 4 B   1 = a pixel of the tile was still blending at the end of that prefix
-//           ckpt[GSR_SEG_MAX] slots of {float4[N'], float2[N']} (N' = N rounded up to 4): slot k-1 = list position
-//                              k * segment length (k = 1..GSR_SEG_MAX-1): {T in front of it, r, g, b}, {depth, feature}
+//           ckpt[GSR_SEG_MAX] slots of {float4[N'], float2[N']} (N' = N rounded up to 4): slot k = the checkpoint at list position
+//                              gsr_ckpt_pos(k) (k = 0..GSR_SEG_MAX-2): {T in front of it, r, g, b}, {depth, feature}
 //                              sums over the segment that ends there; last slot: {checkpoints passed, sums behind the
 //                              last one}.  Lets the backward start in the middle of a list (independent depth segments)
 //           info           16 B {R, max tile count}
@@ -53,10 +53,33 @@
 #define GSR_NEAR_CAP 2048        // longer lists are sorted only up to (at most) this many nearest instances first
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
-#ifndef GSR_SEG_MAX
-#define GSR_SEG_MAX 8            // segments per tile; the last one takes everything behind (GSR_SEG_MAX-1) * segment length
+// Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in TWO TIERS (round 5):
+//   tier 1: GSR_SEG1 segments of the launch's segment length L (64 / 128) -- the fine cut the bench-like frames live in (their
+//           pixels saturate within a few hundred instances);
+//   tier 2: whatever lies behind GSR_SEG1 * L, cut into GSR_SEG2 equal parts of L2 = a multiple of 64 chosen from the tile's LIST
+//           LENGTH (known to both kernels; the walk depth is not known before the forward has run).  Rounds 1-4 had ONE segment
+//           there: on frames whose pixels do not saturate -- the faint splats of an initialised, untrained scene walk every list to
+//           its end -- a 3000-entry list left a 2500-instance task to a single workgroup that ended up alone on its SIMD
+//           (init-state frame: backward blend 1.17 ms for 1.2 M instances).
+#define GSR_SEG1 7
+#ifndef GSR_SEG2
+#define GSR_SEG2 8
 #endif
+#define GSR_SEG_MAX (GSR_SEG1 + GSR_SEG2)   // segments per tile = checkpoint slots (GSR_SEG_MAX - 1 checkpoints + the "last" slot)
 #define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
+// tier-2 segment length of a tile whose list has n entries (L = the launch's tier-1 segment length)
+__host__ __device__ static inline int gsr_seg2_len(int n, int L)
+{
+    const int tail = n - GSR_SEG1 * L;
+    if (tail <= 0) return L;
+    const int l2 = ((tail + GSR_SEG2 * 64 - 1) / (GSR_SEG2 * 64)) * 64;
+    return l2 < L ? L : l2;
+}
+// list position of checkpoint k (k = 0 .. GSR_SEG_MAX-2) = end of segment k = start of segment k + 1
+__host__ __device__ static inline int gsr_ckpt_pos(int k, int L, int L2)
+{
+    return k < GSR_SEG1 ? (k + 1) * L : GSR_SEG1 * L + (k - GSR_SEG1 + 1) * L2;
+}
 // Segment length of a launch: small images have few tiles, so their lists are cut finer to get enough tasks for the
 // 5120 wavefront slots; large ones already have them and shorter tasks would only add fixed costs (measured both ways).
 #ifndef GSR_SEG64_MAX_TILES
@@ -240,7 +263,7 @@ hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const 
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                      const GsrImage& image, const GsrBinning& bin, const float* dL_dcolor,
                                      const float* dL_ddepth, const float* dL_dfeature, float* slots,
-                                     uint8_t* slot_written, uint32_t* heavy_groups, hipStream_t stream);
+                                     uint8_t* slot_written, uint32_t* heavy_groups, int max_tile_count /* < 0: unknown */, hipStream_t stream);
 hipError_t gsr_launch_gauss_backward(int P, int D, int M, const GsrCam& cam, const float* means3D, const int32_t* radii,
                                      const float* shs, const float* scales, const float* rotations,
                                      const float* cov3D_precomp, const GsrGeom& geom, const float* slots,

@@ -253,6 +253,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         if st is None:
             st = _occlusion_state[idx] = {"on": False, "hold": 0}
         _occlusion_next(st, P, R, occluded, was_on=bool(occ))
+    _pinned_tls.last_longest = longest  # this thread's most recent forward: the autograd node keeps it for its backward
     ls = _last_stage1
     ls["num_rendered"], ls["max_tile_count"], ls["num_slots"], ls["binning_capacity"], ls["speculative"] = R, longest, nslots, cap, done
     ls["num_occluded"] = occluded
@@ -260,7 +261,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
 
 
 def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
-                     geom, binning, img, g_color, g_depth, g_unc):
+                     geom, binning, img, g_color, g_depth, g_unc, max_tile_count=-1):
     """The work of `_C.rasterize_gaussians_backward` (DGR rasterize_points.cu:124-211)."""
     lib = _native.load()
     dev = means3D.device
@@ -298,7 +299,7 @@ def _backward_native(rs, num_rendered, binning_capacity, means3D, radii, colors_
     scratch = mk((lib.gsr_backward_scratch_bytes(P, num_rendered),), dtype=torch.uint8, device=dev)
     with _on_device(idx):
         rc = lib.gsr_backward(
-            P, int(rs.sh_degree), M, W, H, int(num_rendered), int(binning_capacity), _p(bg), means3D_c.data_ptr(),
+            P, int(rs.sh_degree), M, W, H, int(num_rendered), int(binning_capacity), int(max_tile_count), _p(bg), means3D_c.data_ptr(),
             radii.data_ptr(), _p(colors_c), _p(sh_c), _p(scales_c), float(rs.scale_modifier), _p(rot_c),
             _p(cov_c), _p(view), _p(proj), _p(campos), float(rs.tanfovx), float(rs.tanfovy), gc.data_ptr(), _p(gd), _p(gu),
             _p(geom), _p(img), _p(binning), scratch.data_ptr(),
@@ -332,6 +333,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.binning_capacity = capacity
+        ctx.max_tile_count = int(getattr(_pinned_tls, "last_longest", -1)) if num_rendered > 0 else -1  # this forward's longest list (sizes the backward's task grid)
         ctx.opacity_shape, ctx.uncertainty_shape = opacities.shape, uncertainties.shape
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
@@ -345,7 +347,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             return (None,) * 10
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         args = (rs, ctx.num_rendered, ctx.binning_capacity, means3D, radii, colors_precomp, sh, scales, rotations, cov3Ds_precomp,
-                geom, binning, img, grad_out_color, grad_out_depth, grad_out_uncertainty)
+                geom, binning, img, grad_out_color, grad_out_depth, grad_out_uncertainty, ctx.max_tile_count)
         if rs.debug:
             saved = _snapshot(args)
             try:

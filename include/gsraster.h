@@ -100,7 +100,7 @@ typedef struct gsr_profile {
 const char* gsr_version(void);
 /* Integer version of this header's binary interface: bumped whenever an entry point's argument list, a struct layout or a
  * workspace size formula changes incompatibly.  Bindings compare it with GSR_ABI_VERSION at load time. */
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
 /* Number of visible HIP devices, or a negative gsr_status. */
@@ -186,7 +186,11 @@ int gsr_forward(int P, int D, int M, int W, int H,
  * must not overlap on different streams.
  */
 int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity /* what the forward's binning
-                 workspace was sized for; = R after the two-stage forward */, const float* background,
+                 workspace was sized for; = R after the two-stage forward */,
+                 int max_tile_count /* gsr_stage1_result.max_tile_count of THAT forward (its longest per-tile list), or <= 0 if the
+                 caller did not keep it: sizes the grid of depth-segment tasks -- a frame none of whose lists reaches the second
+                 segment tier needs half the workgroups; unknown = the full grid, same results */,
+                 const float* background,
                  const float* means3D, const int32_t* radii, const float* colors_precomp, const float* shs,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* viewmatrix, const float* projmatrix, const float* campos,

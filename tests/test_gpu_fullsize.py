@@ -197,35 +197,37 @@ def test_tile_culling_changes_no_pixel(scene):
 
 
 def test_depth_checkpoints_are_consistent(scene):
-    """The forward's per-pixel depth checkpoints (gsr_common.h: 8 slots of {float4, float2}; slot k-1 = list position
-    k * segment length: {T in front of it, r, g, b} {depth, feature} summed over the segment that ends there; last slot:
+    """The forward's per-pixel depth checkpoints (gsr_common.h: GSR_SEG_MAX slots of {float4, float2}; slot k = list position
+    gsr_ckpt_pos(k): {T in front of it, r, g, b} {depth, feature} summed over the segment that ends there; last slot:
     {checkpoints passed, sums behind the last one}) must reproduce the images and be monotone in T."""
     s, dev, rs = scene
     P, W, H = s["means3D"].shape[0], s["W"], s["H"]
     R, color, depth, feat, radii, geom, binning, img, _ns = _forward_state(s, dev, rs)
     iv = _layout.image_views(img, P, W, H)
     N, Np = W * H, (W * H + 3) & ~3
-    slots = iv["ckpt"]                                   # [8][6 * Np] floats
-    a = slots[:, :4 * Np].reshape(8, Np, 4)[:, :N]        # float4 part
-    b = slots[:, 4 * Np:].reshape(8, Np, 2)[:, :N]        # float2 part
-    npass = a[7, :, 0].view(torch.int32).long()
-    assert int(npass.min()) >= 0 and int(npass.max()) <= 7
+    S = _layout.SEG_MAX
+    slots = iv["ckpt"]                                   # [S][6 * Np] floats
+    a = slots[:, :4 * Np].reshape(S, Np, 4)[:, :N]        # float4 part
+    b = slots[:, 4 * Np:].reshape(S, Np, 2)[:, :N]        # float2 part
+    npass = a[S - 1, :, 0].view(torch.int32).long()
+    assert int(npass.min()) >= 0 and int(npass.max()) <= S - 1
     T = (W + 15) // 16 * ((H + 15) // 16)
     seg = 64 if T <= 4096 else 128
     ncon = iv["n_contrib"].reshape(-1).long()
-    assert bool((npass * seg >= torch.minimum(ncon - 1, torch.full_like(ncon, 7 * seg)).clamp(min=0) // seg * seg).all()), \
+    # tier-1 checkpoints sit at multiples of the segment length (tier 2 is exercised by test_second_tier_of_depth_segments)
+    assert bool((npass * seg >= torch.minimum(ncon - 1, torch.full_like(ncon, _layout.SEG1 * seg)).clamp(min=0) // seg * seg).all()), \
         "a pixel passes every checkpoint in front of its last contributor"
-    k = torch.arange(7, device="cuda")[:, None]
+    k = torch.arange(S - 1, device="cuda")[:, None]
     live = k < npass[None, :]                             # slots the pixel really wrote
     fT = iv["final_T"].reshape(-1)
-    Tk = a[:7, :, 0]
+    Tk = a[:S - 1, :, 0]
     assert bool((~live[1:] | (Tk[1:] <= Tk[:-1] * (1 + 1e-6))).all()), "T decreases from checkpoint to checkpoint"
     assert bool((~live | ((Tk <= 1.0) & (Tk >= fT[None, :] * (1 - 1e-6)))).all()), "1 >= T_k >= final T"
-    sums = torch.where(live[:, :, None], a[:7, :, 1:], torch.zeros_like(a[:7, :, 1:])).sum(0) + a[7, :, 1:]
+    sums = torch.where(live[:, :, None], a[:S - 1, :, 1:], torch.zeros_like(a[:S - 1, :, 1:])).sum(0) + a[S - 1, :, 1:]
     bg = rs.bg.to(sums.device)
     img_from_sums = sums.t().reshape(3, H, W) + fT.reshape(1, H, W) * bg[:, None, None]
     assert (img_from_sums - color).abs().max().item() < 1e-5
-    dsum = torch.where(live[:, :, None], b[:7], torch.zeros_like(b[:7])).sum(0) + b[7]
+    dsum = torch.where(live[:, :, None], b[:S - 1], torch.zeros_like(b[:S - 1])).sum(0) + b[S - 1]
     assert (dsum[:, 0].reshape(H, W) - depth[0]).abs().max().item() < 1e-4 * max(1.0, depth.abs().max().item())
     assert (dsum[:, 1].reshape(H, W) - feat[0]).abs().max().item() < 1e-5
 
