@@ -131,6 +131,27 @@ __device__ __forceinline__ float gsr_box_min_q(float mx, float my, float A, floa
 // Skipped work contributes exactly nothing: images and gradients are unchanged.  NaNs compare false, so
 // a degenerate conic or a non-positive opacity keeps the instance.
 #define GSR_CULL_MARGIN 0.01f
+// ... plus a margin that grows with the MAGNITUDE of the quadratic form's terms (round 5).  The reference evaluates
+// power = -0.5 (A dx^2 + C dy^2) - B dx dy in fp32 (forward.cu:528); for a large, thin, tilted splat the three terms are of order
+// 1e4 - 1e6 and cancel to a power of order 1-10, so the value the REFERENCE tests against 1/255 carries an absolute error of
+// ~2e-7 x the sum of the terms' magnitudes -- 0.03 - 0.3 for such a splat, more than the fixed margin: a tile (quadrant, strip) that
+// exact arithmetic rules out may still blend in the reference.  (Found on the initialised, untrained scene of round 5 -- anchors'
+// scales up to 0.4 m next to a camera: the parity BUILD, which blends with the reference's own expression, disagreed with the oracle
+// on the same 50 gradient elements as the shipped one.)  S bounds the terms over a box of pixel offsets; GSR_CULL_ERR * S is added
+// to tau (same units as the conic passed in: natural or log2-scaled, the bound is homogeneous).
+#define GSR_CULL_ERR 1.0e-6f
+// (no contraction: the forward and the backward blend derive an instance's guard band from this value and must get the same bits
+// whatever code surrounds the call)
+__device__ __forceinline__ float gsr_terms_bound(float A, float B, float C, float DX, float DY)
+{
+#pragma clang fp contract(off)
+    const float tA = fabsf(A) * DX * DX, tC = fabsf(C) * DY * DY, tB = fabsf(B) * DX * DY;
+    return 0.5f * (tA + tC) + tB;
+}
+__device__ __forceinline__ float gsr_box_terms_bound(float mx, float my, float A, float B, float C, float bx0, float bx1, float by0, float by1)
+{
+    return gsr_terms_bound(A, B, C, fmaxf(fabsf(mx - bx0), fabsf(mx - bx1)), fmaxf(fabsf(my - by0), fabsf(my - by1)));
+}
 __device__ __forceinline__ float gsr_cull_tau(float opacity) { return logf(255.0f * opacity) + GSR_CULL_MARGIN; }
 // v_log_f32 version for the blend kernels' quadrant test (1 ulp: irrelevant next to the margin)
 __device__ __forceinline__ float gsr_cull_tau_fast(float opacity) { return __logf(255.0f * opacity) + GSR_CULL_MARGIN; }

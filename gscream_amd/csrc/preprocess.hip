@@ -138,10 +138,13 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         feat_in = features[idx];
     }
     unsigned long long mask = ~0ull;
-    float tau = 0.f;
+    float tau = 0.f, tau_plain = 0.f;
     int4 cull_box = make_int4(0, 0, 0, 0);  // tiles (x, y, w, h) of the alpha >= 1/255 ellipse box inside the rectangle
     if (radius > 0) {
-        tau = gsr_cull_tau(op_in);
+        tau_plain = gsr_cull_tau(op_in);
+        // + the rounding of the reference's own fp32 `power` over this Gaussian's rectangle (gsr_math.h GSR_CULL_ERR): |d| <= radius + a tile
+        const float reach = (float)radius + 16.0f;
+        tau = tau_plain + GSR_CULL_ERR * gsr_terms_bound(conx, cony, conz, reach, reach);
         if (tile_cull) {
             const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
             // Tiles outside the axis-aligned bounding box of the alpha >= 1/255 ellipse {q <= tau} cannot
@@ -179,6 +182,7 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
                 const int o_bx0 = __shfl(cull_box.x, owner, 64), o_by0 = __shfl(cull_box.y, owner, 64), o_bw = __shfl(cull_box.z, owner, 64);
                 const int o_x0 = __shfl(x0, owner, 64), o_y0 = __shfl(y0, owner, 64), o_wd = __shfl(wd, owner, 64);
                 const uint32_t o_bkt = occ_mass ? (uint32_t)__shfl((int)gsr_occ_bucket(__float_as_uint(viewz)), owner, 64) : 0u;
+                const float o_tau_plain = occ_mass ? __shfl(tau_plain, owner, 64) : 0.f;
                 uint32_t* const occ_xcd = occ_mass ? occ_mass + (size_t)(__builtin_amdgcn_s_getreg(63508) & 7u) * (size_t)(cam.gx * cam.gy) * GSR_OCC_BUCKETS
                                                    : nullptr;  // (XCC_ID of the hardware slot this wave runs on)
                 if (act) {
@@ -192,7 +196,8 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
                     if (i >= 64 ? occ_mass != nullptr : gsr_tile_survives(o_pix, o_piy, o_cx, o_cy, o_cz, o_rA, o_rC, o_tau, x, y, cam.W, cam.H)) {
                         if (i < 64) atomicOr(&wmask[owner], 1ull << i);
                         if (occ_mass) {  // (wave-uniform) occlusion cut-off: the instance's whole-tile mass into its (tile, depth bucket) sum
-                            const uint32_t m = gsr_tile_occlusion_mass(o_pix, o_piy, o_cx, o_cy, o_cz, o_tau - GSR_CULL_MARGIN, x, y, cam.W, cam.H);
+                            // (the EXACT threshold here, without either margin: a mass must never be over-estimated)
+                            const uint32_t m = gsr_tile_occlusion_mass(o_pix, o_piy, o_cx, o_cy, o_cz, o_tau_plain - GSR_CULL_MARGIN, x, y, cam.W, cam.H);
                             // integer adds: order-free.  Into THIS XCD's copy of the table with an L2-local (workgroup-scope)
                             // atomic: every workgroup that touches the copy runs on this XCD, i.e. behind the same L2; device-scope
                             // atomics go to memory and cost this kernel 63 us on a large-splat frame
