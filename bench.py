@@ -173,6 +173,7 @@ def parity_check(Hh, s, grads, st, ref, threads):
             "per_family": {k: v["n_bad"] for k, v in rep["grads"].items()},
             # where each pixel's walk ended against the oracle's (a flipped T = 1e-4 stop shows here directly) and, for every gradient
             # element beyond 1e-3, the range the REFERENCE algorithm's own unordered fp32 atomicAdd sums span (oracle.backward_envelope)
+            "outlier_pixels": rep.get("outlier_pixels"), "grad_elems_in_walks_of_expf_tie_pixels": rep.get("grad_elems_in_walks_of_expf_tie_pixels"),
             "last_contributor_differs": rep.get("last_contributor_differs"),
             "final_T_max_rel_where_same_stop": rep.get("final_T_max_rel_where_same_stop"),
             "order_noise_envelope": rep.get("order_noise_envelope")}

@@ -82,7 +82,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     have_cov = cov.numel() != 0
     with torch.cuda.device(dev):
         scratch = torch.empty(L.gsr_backward_scratch_bytes(Pn, int(R)), dtype=torch.uint8, device=dev)
-        _native.check(L.gsr_backward(Pn, int(degree), M, W, H, int(R), int(R), -1 /* longest list not kept by this entry: full task grid */, P_(bg), P_(m), P_(radii), P_(c), P_(shc), P_(s),
+        _native.check(L.gsr_backward(Pn, int(degree), M, W, H, int(R), int(R), -1, P_(bg),  # (-1: the longest list is not kept by this entry -> full task grid)
+                                     P_(m), P_(radii), P_(c), P_(shc), P_(s),
                                      float(scale_modifier), P_(r), P_(cov), P_(view), P_(proj), P_(cam), float(tan_fovx),
                                      float(tan_fovy), P_(gc), P_(gd), P_(gu), P_(geomBuffer), P_(imageBuffer), P_(binningBuffer),
                                      P_(scratch), P_(g_m2), P_(g_col), P_(g_op), P_(g_unc), P_(g_m3),

@@ -74,22 +74,12 @@ __device__ __forceinline__ float gsr_gauss1(float power) { return __builtin_amdg
 #ifndef GSR_BAND
 #define GSR_BAND 3.0e-5f
 #endif
-// ... and PER INSTANCE wider where the quadratic form's terms are large (round 5): the reference's own fp32 `power` carries an
-// absolute error of ~2e-7 x the sum of its terms' magnitudes (large, thin, tilted splats: terms of 1e2 - 1e5 that cancel), and the
-// fast form's differs from it by as much, so the relative distance of the two alphas grows with S = that sum over the TILE's pixel box
-// (the same box in the forward's four quadrant waves and in the backward, so all of them agree on an instance's band):
-//     w = max(GSR_BAND, GSR_BAND_ERR * S) + 8e-6,  LO = (1 - w)/255 (candidates from here on),  HI = 2/255 - LO (decided exactly below).
-// (Round 4's fixed 3e-5 missed such pairs: the one "alpha-type" element left at config 3, and 24 on the initialised scene.)
-#ifndef GSR_BAND_ERR
-#define GSR_BAND_ERR 1.0e-6f
-#endif
-// S_scaled: gsr_box_terms_bound over the tile box with the log2(e)-scaled conic (what the blend kernels have at hand)
-__device__ __forceinline__ float gsr_band_lo(const float S_scaled)
-{
-#pragma clang fp contract(off)
-    const float w = fmaxf(GSR_BAND, GSR_BAND_ERR * (1.0f / GSR_LOG2E) * S_scaled) + 8.0e-6f;
-    return GSR_ALPHA_C * (1.0f - fminf(w, 0.5f));
-}
+#define GSR_ALPHA_LO (GSR_ALPHA_C * (1.0f - GSR_BAND))
+#define GSR_ALPHA_HI (GSR_ALPHA_C * (1.0f + GSR_BAND))
+// (A band that widens PER INSTANCE with the magnitude of the quadratic form's terms -- the reference's own fp32 `power` carries ~2e-7 x
+// that magnitude of absolute error, which for large thin tilted splats exceeds the fixed band -- was built and measured in round 5:
+// tools/experiments/r05_per_instance_guard_band.patch.  It cost config 2 +2 us in either blend and config 4 +11 / +8 us, and removed no
+// outlier on any workload: what is left beyond 1e-3 lies inside the reference's own summation-order noise or is an expf tie)
 __device__ __forceinline__ bool gsr_blends_exact(const float cA, const float cB, const float cC, const float op, const float dx, const float dy)
 {
 #pragma clang fp contract(off)
@@ -111,8 +101,7 @@ __device__ __forceinline__ bool gsr_blends_exact(const float cA, const float cB,
 #define GSR_TBAND 1.0e-4f
 #endif
 struct GsrExactAlpha { float alpha, one_minus; bool blends, in_band; };
-__device__ __forceinline__ GsrExactAlpha gsr_alpha_exact(const float cA, const float cB, const float cC, const float op, const float dx, const float dy,
-                                                         const float band_lo)
+__device__ __forceinline__ GsrExactAlpha gsr_alpha_exact(const float cA, const float cB, const float cC, const float op, const float dx, const float dy)
 {
 #pragma clang fp contract(off)
     GsrExactAlpha r;
@@ -122,8 +111,8 @@ __device__ __forceinline__ GsrExactAlpha gsr_alpha_exact(const float cA, const f
     r.blends = !(power > 0.0f) && !(r.alpha < 1.0f / 255.0f);
     r.one_minus = 1.0f - r.alpha;
     // (twice the guard band's width: the backward decides band membership on the FAST alpha, a few 1e-7 away from this one)
-    // (the instance's own band, a little wider: the backward decides band membership on the FAST alpha, a band-fraction away from this one)
-    r.in_band = !(power > 0.0f) && fabsf(raw - GSR_ALPHA_C) < 1.25f * (GSR_ALPHA_C - band_lo);
+    // (twice the guard band's width: the backward decides band membership on the FAST alpha, a few 1e-7 away from this one)
+    r.in_band = !(power > 0.0f) && fabsf(raw - GSR_ALPHA_C) < GSR_ALPHA_C * (2.0f * GSR_BAND);
     return r;
 }
 __device__ __forceinline__ float gsr_mul_exact(const float a, const float b)
@@ -270,8 +259,7 @@ __device__ __forceinline__ uint32_t gsr_quadrant_mask(const float4 A, const floa
         const int x0 = tx * 16 + (q & 1) * 8, y0 = ty * 16 + (q >> 1) * 8;
         const float bx1 = (float)min(x0 + 7, W - 1), by1 = (float)min(y0 + 7, H - 1);
         const bool hit = x0 < W && y0 < H &&
-                         !(gsr_box_min_q(A.x, A.y, ca, cb, cc, rA, rC, (float)x0, bx1, (float)y0, by1) >
-                           tau + GSR_CULL_ERR * gsr_box_terms_bound(A.x, A.y, ca, cb, cc, (float)x0, bx1, (float)y0, by1));
+                         !(gsr_box_min_q(A.x, A.y, ca, cb, cc, rA, rC, (float)x0, bx1, (float)y0, by1) > tau);
         m |= hit ? (1u << q) : 0u;
     }
     return m;
@@ -358,7 +346,6 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
     const float bx0 = (float)qx0, by0 = (float)qy0, bx1 = (float)min(qx0 + 7, W - 1), by1 = (float)min(qy0 + 7, H - 1);
-    const float tbx0 = (float)(tx * 16), tby0 = (float)(ty * 16), tbx1 = (float)min(tx * 16 + 15, W - 1), tby1 = (float)min(ty * 16 + 15, H - 1);  // the tile's box
     if (only_flagged && !only_flagged[tile]) return;  // fix-up pass after a full sort: only the tiles that asked for it
     const uint2 rg = ranges[tile];
     // Lists that were not (completely) scattered by a speculative launch, or that were longer than the LDS the sort was
@@ -460,18 +447,12 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
         }
         cnt = min(GSR_FWB - (base & (GSR_FWB - 1)), n - base);
         bool hit = false;
-        float band_lo = GSR_ALPHA_C;
         if (lane < cnt) {
             const float ca = GSR_QSCALE(a.z), cb = GSR_QSCALE(a.w), cc = GSR_QSCALE(b.x);
-            // the magnitude of the quadratic form's terms over the TILE's pixel box: widens the cull margin (gsr_math.h GSR_CULL_ERR: the
-            // rounding of the reference's own fp32 `power`) and the instance's alpha guard band (gsr_band_lo)
-            const float S = gsr_box_terms_bound(a.x, a.y, ca, cb, cc, tbx0, tbx1, tby0, tby1);
-            hit = !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), bx0, bx1, by0, by1) > gsr_cull_tau_fast(b.y) * GSR_LOG2E + GSR_CULL_ERR * S);
-#ifndef GSR_PRECISE_MATH
-            band_lo = gsr_band_lo(S);
-#endif
+            // (c.w: ln(255 opacity) + the fixed margin + the rounding of the reference's own fp32 `power` over this Gaussian's whole
+            // rectangle, gsr_math.h GSR_CULL_ERR -- computed once per Gaussian by preprocess)
+            hit = !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), bx0, bx1, by0, by1) > c.w * GSR_LOG2E);
         }
-        (void)band_lo;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
         const int nq = __popcll(bal);
         if (hit) {
@@ -482,21 +463,12 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
 #else
             dst[0] = a.x; dst[2] = a.y; dst[4] = GSR_HA(a.z); dst[6] = GSR_HB(a.w); dst[8] = GSR_HC(b.x); dst[10] = b.y;
 #endif
-            // colour record slot = list position & 63 (= the lane, except in the first batch of a resumed walk, which starts anywhere)
-            const int cslot = (base + lane) & (GSR_FWB - 1);
-#ifdef GSR_PRECISE_MATH
-            dst[12] = __int_as_float(cslot);
-#else       // the instance's candidate threshold LO (gsr_band_lo) with that slot in its six lowest mantissa bits: rounded DOWN by
-            // clearing them, up again by at most 63 ulp = 3.8e-6 relative, which the 8e-6 inside gsr_band_lo covers.  The backward
-            // builds the SAME word from the same two things (list position, tile box): both compare alpha with identical bits.
-            dst[12] = __uint_as_float((__float_as_uint(band_lo) & ~63u) | (uint32_t)cslot);
-#endif
-            dst[14] = b.w;
-            sC[cslot] = make_float4(c.x, c.y, c.z, b.z);
+            dst[12] = __int_as_float(lane); dst[14] = b.w;
+            sC[lane] = make_float4(c.x, c.y, c.z, b.z);
         }
-        if ((nq & 1) && lane == 0) {  // odd count: the second half of the last pair is an instance with opacity 0 (and a threshold of +inf)
+        if ((nq & 1) && lane == 0) {  // odd count: the second half of the last pair is an instance with opacity 0
             float* dst = reinterpret_cast<float*>(&sPair[nq >> 1][0]) + 1;
-            dst[0] = 0.f; dst[2] = 0.f; dst[4] = 0.f; dst[6] = 0.f; dst[8] = 0.f; dst[10] = 0.f; dst[12] = __uint_as_float(0x7f800000u); dst[14] = 0.f;
+            dst[0] = 0.f; dst[2] = 0.f; dst[4] = 0.f; dst[6] = 0.f; dst[8] = 0.f; dst[10] = 0.f; dst[12] = 0.f; dst[14] = 0.f;
         }
         {  // next batch's records: in flight during the blend loop
             const int i = base + cnt + lane;  // (the next batch is a full one, or the list's tail)
@@ -534,19 +506,18 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             // the pair in front of the first blend: one rarely taken branch per pair iteration whose compares issue with the others,
             // instead of a compare -> scalar test -> branch in the dependency chain of every blend (a wave with its SIMD to itself,
             // i.e. the second half of every launch, runs at the speed of that chain: per-blend checks cost the launch 9 %, this 2 %)
-            // (P3.x / P3.y: each instance's own lower band edge, with its batch index in the low mantissa bits)
-            unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= P3.x);
-            unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= P3.y);
-            // upper band edges HI = 2/255 - LO of both instances in one packed subtract, two compares: three VALU instructions in
-            // front of the blends, like round 4's |alpha - 1/255| < width form, but with each instance's own width
-            const gsr_f2 HI = gsr_splat(2.0f * GSR_ALPHA_C) - gsr_f2{P3.x, P3.y};
-            const unsigned long long banda = __builtin_amdgcn_ballot_w64(al.x < HI.x) & cma;
-            const unsigned long long bandb = __builtin_amdgcn_ballot_w64(al.y < HI.y) & cmb;
+            unsigned long long cma = __builtin_amdgcn_ballot_w64(power.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= GSR_ALPHA_LO);
+            unsigned long long cmb = __builtin_amdgcn_ballot_w64(power.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= GSR_ALPHA_LO);
+            // (|alpha - 1/255| of both instances -> one minimum -> ONE compare whose result is branched on directly: the test adds
+            // three VALU instructions and no scalar logic to the chain in front of the blends)
+            const gsr_f2 dband = al - gsr_splat(GSR_ALPHA_C);
 #ifdef GSR_NO_BAND  // diagnostic: the band test compiled out (what the check costs)
             if (false) {
 #else
-            if ((banda | bandb) != 0ull) {  // rare: inside the guard band
+            if (__builtin_amdgcn_ballot_w64(fminf(fabsf(dband.x), fabsf(dband.y)) < GSR_ALPHA_C * GSR_BAND) != 0ull) {  // rare: inside the guard band
 #endif
+                const unsigned long long banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & cma;
+                const unsigned long long bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & cmb;
                 // -> the reference's own expression decides
                 auto settle = [&](const unsigned long long bandm, unsigned long long& cm, const int j) {
                     if (bandm == 0ull) return;
@@ -559,7 +530,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                     // The list entry is FLAGGED (bit 31): the backward, whose pixels are a subset of the ones that met this instance
                     // here, runs its own band check only on flagged instances -- everywhere else alpha >= lower edge is the
                     // decision (no pixel of the tile is inside the band) and the two compares per iteration are saved.
-                    const int pos = (base & ~(GSR_FWB - 1)) + __builtin_amdgcn_readfirstlane(jv);  // (jv = list position & 63)
+                    const int pos = base + __builtin_amdgcn_readfirstlane(jv);
                     const uint32_t gid = ids[pos] & 0x7fffffffu;
                     if (lane == 0) ids[pos] = gid | 0x80000000u;  // (the four quadrant waves of a tile may all store this same word)
                     const GsrRec* r = rec + gid;
@@ -569,19 +540,15 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                     cm &= ~bandm | __builtin_amdgcn_ballot_w64(keep);
                     GSR_COUNT_ADD(7, 1);
                 };
-                settle(banda, cma, __float_as_int(P3.x) & 63);
-                settle(bandb, cmb, __float_as_int(P3.y) & 63);
+                settle(banda, cma, __float_as_int(P3.x));
+                settle(bandb, cmb, __float_as_int(P3.y));
             }
 #endif
             // colour / depth of both instances requested up front (addressed per lane, no scalar round trip): their LDS latency
             // passes behind the falloff arithmetic instead of sitting in the blend chain.  That chain is what a wave that has its
             // SIMD (nearly) to itself is bound by, and the second half of every launch is such waves (tools/wave_trace.py,
             // tools/lone_wave_probe.py: 123 -> 109 ns per instance for a lone wave, the launch 92.5 -> 87 us).
-#ifdef GSR_PRECISE_MATH
             const int ja = __float_as_int(P3.x), jb = __float_as_int(P3.y);
-#else
-            const int ja = __float_as_int(P3.x) & 63, jb = __float_as_int(P3.y) & 63;
-#endif
             float4 Ca = sC[ja];
             const float4 Cb = sC[jb];
             auto blend = [&](const unsigned long long okm, const float alu, const int j, const float4 C, const float feat) {
@@ -598,14 +565,14 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                     C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
                     Dp += C.w * w; Uf += feat * w;
                     Tr = test_T;
-                    last = (uint32_t)((base & ~(GSR_FWB - 1)) + j + 1);
+                    last = (uint32_t)(base + j + 1);
                 }
 #else
                 const float w = gsr_sel0(okf, al1 * Tr);
                 C0 += C.x * w; C1 += C.y * w; C2 += C.z * w;
                 Dp += C.w * w; Uf += feat * w;
                 Tr = gsr_sel(okf, test_T, Tr);
-                last = __float_as_uint(gsr_sel(okf, __uint_as_float((uint32_t)((base & ~(GSR_FWB - 1)) + j + 1)), __uint_as_float(last)));  // (j = list position & 63)
+                last = __float_as_uint(gsr_sel(okf, __uint_as_float((uint32_t)(base + j + 1)), __uint_as_float(last)));
 #endif
             };
             const unsigned long long okma = cma & ~donem;
@@ -678,8 +645,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                 }
                 GsrExactAlpha ea = {0.f, 1.f, false, false};
                 if (gid_cur != 0xffffffffu) {
-                    const float rS = gsr_box_terms_bound(rc_cur.a.x, rc_cur.a.y, GSR_QSCALE(rc_cur.a.z), GSR_QSCALE(rc_cur.a.w), GSR_QSCALE(rc_cur.b.x), tbx0, tbx1, tby0, tby1);
-                    ea = gsr_alpha_exact(rc_cur.a.z, rc_cur.a.w, rc_cur.b.x, rc_cur.b.y, rc_cur.a.x - fx, rc_cur.a.y - fy, gsr_band_lo(rS));
+                    ea = gsr_alpha_exact(rc_cur.a.z, rc_cur.a.w, rc_cur.b.x, rc_cur.b.y, rc_cur.a.x - fx, rc_cur.a.y - fy);
                     // the backward runs its own exact alpha check only on flagged list entries: this walk may visit entries
                     // the pixel's fast walk never reached
                     if (ea.in_band) ids[b0 + lane] = gid_cur | 0x80000000u;
@@ -836,11 +802,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     __shared__ __attribute__((aligned(16))) float acc[2][SL * GSR_SLOT_FLOATS];
     __shared__ uint32_t sSlot[SL], sQ[SL];
     __shared__ uint16_t sList[2][SL];
-    // each staged instance's lower guard-band edge (gsr_band_lo: from the magnitude of its quadratic form's terms over the TILE box, the
-    // forward's value bit for bit).  Without the depth / feature heads it travels in the unused third word of the {hC, opacity, depth,
-    // feature} record, so the RGB-only loop reads nothing more than before; with them it is a fourth, 4-byte broadcast read.
-    __shared__ float sLO[AUX ? SL : 1];
-    (void)sLO;  // (unused in the parity build and without the auxiliary heads)
 
     GSR_TRACE_BEGIN
     // Workgroup b runs on XCD b % 8 and takes the (b >> 3)-th slot of that XCD's band of tiles (the forward's tile -> XCD
@@ -1007,18 +968,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                     sA[lane] = r->a; sB[lane] = r->b;
 #else
                     const float4 a = r->a, b = r->b;  // raw conic -> the pre-scaled form the loop evaluates
-                    // (the forward's word: gsr_band_lo of the tile box, the list position's low six bits in its low mantissa bits)
-                    const float lo = __uint_as_float((__float_as_uint(gsr_band_lo(gsr_box_terms_bound(a.x, a.y, GSR_QSCALE(a.z), GSR_QSCALE(a.w), GSR_QSCALE(b.x), (float)(tx * 16),
-                                                                     (float)min(tx * 16 + 15, W - 1), (float)(ty * 16), (float)min(ty * 16 + 15, H - 1)))) & ~63u) |
-                                                     ((uint32_t)(hi - 1 - lane) & 63u));
-                    sA[lane] = make_float4(a.x, a.y, GSR_HA(a.z), GSR_HB(a.w)); sB[lane] = make_float4(GSR_HC(b.x), b.y, AUX ? b.z : lo, b.w);
-                    if (AUX) sLO[lane] = lo;
+                    sA[lane] = make_float4(a.x, a.y, GSR_HA(a.z), GSR_HB(a.w)); sB[lane] = make_float4(GSR_HC(b.x), b.y, b.z, b.w);
 #endif
                 } else {
                     const uint32_t slot0 = offsets[id];
                     const uint4 d = r->d;
                     const float4 c = r->c;
-                    const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)__float_as_uint(c.w);
+                    const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)d.x;
                     const int pos = (ty - y0) * wd + (tx - x0);
                     const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
                     sSlot[lane] = slot0 + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
@@ -1033,20 +989,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
             const uint4 d = r->d;
             const float4 c = r->c;
             // gradient slot = Gaussian's scan offset + rank of this tile among the surviving tiles of its rectangle
-            const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)__float_as_uint(c.w);
+            const int x0 = d.y & 0xffff, y0 = d.y >> 16, wd = (int)d.x;
             const int pos = (ty - y0) * wd + (tx - x0);
             const unsigned long long mask = ((unsigned long long)d.w << 32) | d.z;
             sSlot[t] = slot0 + (uint32_t)(pos < 64 ? __popcll(mask & ((1ull << pos) - 1ull)) : __popcll(mask) + (pos - 64));
             const float4 a = r->a, b = r->b;
-            sQ[t] = gsr_quadrant_mask(a, b, gsr_cull_tau_fast(b.y) * GSR_LOG2E, tx, ty, W, H);
+            sQ[t] = gsr_quadrant_mask(a, b, c.w * GSR_LOG2E, tx, ty, W, H);
 #ifdef GSR_PRECISE_MATH
             sA[t] = a; sB[t] = b; sC[t] = c;
 #else
-            const float lo = __uint_as_float((__float_as_uint(gsr_band_lo(gsr_box_terms_bound(a.x, a.y, GSR_QSCALE(a.z), GSR_QSCALE(a.w), GSR_QSCALE(b.x), (float)(tx * 16),
-                                                             (float)min(tx * 16 + 15, W - 1), (float)(ty * 16), (float)min(ty * 16 + 15, H - 1)))) & ~63u) |
-                                             ((uint32_t)(hi - 1 - t) & 63u));
-            sA[t] = make_float4(a.x, a.y, GSR_HA(a.z), GSR_HB(a.w)); sB[t] = make_float4(GSR_HC(b.x), b.y, AUX ? b.z : lo, b.w); sC[t] = c;
-            if (AUX) sLO[t] = lo;
+            sA[t] = make_float4(a.x, a.y, GSR_HA(a.z), GSR_HB(a.w)); sB[t] = make_float4(GSR_HC(b.x), b.y, b.z, b.w); sC[t] = c;
 #endif
         }
         __syncthreads();
@@ -1063,9 +1015,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                     const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;
 #endif
                     const int sx0 = tx * 16, sy0 = ty * 16 + wave * 8;  // this wavefront's 16x8 strip
-                    const float sbx1 = (float)min(sx0 + 15, W - 1), sby1 = (float)min(sy0 + 7, H - 1);
-                    hit = sy0 < H && !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), (float)sx0, sbx1, (float)sy0, sby1) >
-                                       gsr_cull_tau_fast(b.y) * GSR_LOG2E + GSR_CULL_ERR * gsr_box_terms_bound(a.x, a.y, ca, cb, cc, (float)sx0, sbx1, (float)sy0, sby1));
+                    hit = sy0 < H && !(gsr_box_min_q(a.x, a.y, ca, cb, cc, GSR_RCP(ca), GSR_RCP(cc), (float)sx0, (float)min(sx0 + 15, W - 1),
+                                                     (float)sy0, (float)min(sy0 + 7, H - 1)) > sC[lane].w * GSR_LOG2E);  // (.w: the Gaussian's culling threshold)
                 }
                 const unsigned long long bal = __ballot(hit);
                 if (hit) mylist[__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)lane;
@@ -1083,15 +1034,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                 const int jj = mylist[min(c0 + lane, nw - 1)];
                 int j = __builtin_amdgcn_readlane(jj, 0);
                 float4 A = sA[j], B = sB[j];
-#ifndef GSR_PRECISE_MATH
-                float LO = AUX ? sLO[j] : B.z;
-#endif
                 for (int k = 0; k < m; k++) {
                     const int jn = __builtin_amdgcn_readlane(jj, min(k + 1, m - 1));
                     const float4 An = sA[jn], Bn = sB[jn];
-#ifndef GSR_PRECISE_MATH
-                    const float LOn = AUX ? sLO[jn] : Bn.z;
-#endif
                     const int p = hi - 1 - j;
                     const gsr_f2 dx = gsr_splat(A.x) - pxf;
                     const float dy = A.y - pyf;
@@ -1109,7 +1054,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 #ifdef GSR_PRECISE_MATH
                     const float alpha_min = 1.0f / 255.0f;
 #else
-                    const float alpha_min = LO;  // candidates from the lower edge of THIS instance's guard band on (settled below)
+                    const float alpha_min = GSR_ALPHA_LO;  // candidates from the lower edge of the guard band on (settled below)
 #endif
                     unsigned long long okma = __builtin_amdgcn_ballot_w64(p < lastca) & __builtin_amdgcn_ballot_w64(power.x <= 0.0f) &
                                               __builtin_amdgcn_ballot_w64(al.x >= alpha_min);
@@ -1121,9 +1066,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                         unsigned long long banda = 0ull, bandb = 0ull;
                         // (a second copy of the loop body without this test for batches with no flagged instance: no gain, 161 vs 158.5 us)
                         if (SL != 64 || ((bandm64 >> (j & 63)) & 1ull)) {  // wave-uniform (j is scalar): the forward flagged this instance
-                            const float HI = 2.0f * GSR_ALPHA_C - LO;  // this instance's upper band edge
-                            banda = __builtin_amdgcn_ballot_w64(al.x < HI) & okma;
-                            bandb = __builtin_amdgcn_ballot_w64(al.y < HI) & okmb;
+                            banda = __builtin_amdgcn_ballot_w64(al.x < GSR_ALPHA_HI) & okma;
+                            bandb = __builtin_amdgcn_ballot_w64(al.y < GSR_ALPHA_HI) & okmb;
                         }
                         if ((banda | bandb) != 0ull) {  // rare: inside the guard band -> the reference's own expression decides (as in the forward)
                             const GsrRec* r = rec + (point_list[rg.x + p] & 0x7fffffffu);
@@ -1193,9 +1137,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                         if (accfield >= 0) atomicAdd(&acc[wave][(uint32_t)j * GSR_SLOT_FLOATS + (uint32_t)accfield], x);
                     }
                     j = jn; A = An; B = Bn;
-#ifndef GSR_PRECISE_MATH
-                    LO = LOn;
-#endif
                 }
             }
         }

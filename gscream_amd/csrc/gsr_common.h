@@ -7,7 +7,7 @@
 //                              the raw conic; the blend kernels scale it once per staged instance into
 //                              (hA,hB,hC) = -log2(e) * (conA/2, conB, conC/2): exponent of the Gaussian in
 //                              base 2 = dx (hA dx + hB dy) + hC dy^2, fed straight to v_exp_f32
-//                              c = {r, g, b, rect width}  d = {offset, x0|y0<<16, tile mask lo, hi}
+//                              c = {r, g, b, cull threshold ln(255 opacity) + margins}  d = {rect width, x0|y0<<16, tile mask lo, hi}
 //           rect[P]       8 B  {x0|x1<<16, y0|y1<<16} tile rectangle (0,0 = culled)
 //           depthkey[P]   4 B  float bits of view-space depth (positive floats sort as uints)
 //           tiles[P]      4 B  surviving tiles of the rectangle = gradient slots of the Gaussian

@@ -244,8 +244,10 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
             // values for the in-band re-check of the alpha = 1/255 decision (blend.hip, gsr_blends_exact)
             ra = make_float4(pix, piy, conx, cony);
             rb = make_float4(conz, op_in, viewz, feat_in);
-            rcc = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));
-            rd = make_uint4(0u, (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+            // c.w: the culling threshold of this Gaussian, ln(255 opacity) + both margins (gsr_math.h) -- the blend kernels' quadrant / strip
+            // tests read it instead of recomputing a logarithm per staged instance; d.x: rectangle width (gradient-slot numbering)
+            rcc = make_float4(col.x, col.y, col.z, tau);
+            rd = make_uint4((rc.x >> 16) - (rc.x & 0xffff), (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
         }
         const int lane = threadIdx.x & 63;
         float4* sw = s_rec + (threadIdx.x & ~63u) * 4;  // this wave's 256 float4
@@ -261,8 +263,8 @@ __global__ void __launch_bounds__(256) gsr_preprocess_kernel(
         GsrRec* r = rec + idx;
         r->a = make_float4(pix, piy, conx, cony);
         r->b = make_float4(conz, op_in, viewz, feat_in);
-        r->c = make_float4(col.x, col.y, col.z, __uint_as_float((rc.x >> 16) - (rc.x & 0xffff)));  // .w = rectangle width
-        r->d = make_uint4(0u, (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+        r->c = make_float4(col.x, col.y, col.z, tau);  // .w = culling threshold (see above)
+        r->d = make_uint4((rc.x >> 16) - (rc.x & 0xffff), (rc.x & 0xffff) | ((rc.y & 0xffff) << 16), (uint32_t)mask, (uint32_t)(mask >> 32));  // .x = rectangle width
     }
 }
 

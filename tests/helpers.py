@@ -248,6 +248,12 @@ def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_or
     out["px_gt_1e-4"] = int(bad.sum())
     out["px_by_cause"] = {"alpha": int((bad & near_a & ~near_t).sum()), "T": int((bad & near_t & ~near_a).sum()),
                           "both": int((bad & near_a & near_t).sum()), "neither": int((bad & ~near_a & ~near_t).sum())}
+    # every outlier pixel with how close the ORACLE's own walk of it came to flipping a decision: a margin of a few 1e-7 means the pair
+    # sits within an ulp of expf of the threshold -- which way it falls then depends on the libm (glibc here, ocml on the GPU, CUDA's in
+    # the reference), not on the algorithm
+    ys, xs = np.nonzero(bad)
+    out["outlier_pixels"] = [{"x": int(x), "y": int(y), "oracle_margin_alpha_rel": float(mg["m_alpha"][y, x]), "oracle_margin_T_rel": float(mg["m_T"][y, x]),
+                              "expf_tie": bool(mg["m_alpha"][y, x] < 1e-6)} for y, x in list(zip(ys, xs))[:16]]
     out["pixels_at_risk"] = {"alpha": int(near_a.sum()), "T": int(near_t.sum()), "power_sign(|power|<1e-6)": int((mg["m_pow"] < 1e-6).sum())}
     if "last_gid" in got:
         # pixels whose walk ended at another Gaussian than the oracle's: a flipped T = 1e-4 stop (or a flipped alpha test of the last instance)
@@ -264,6 +270,15 @@ def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_or
         gt[mg["g_T"][near_t]] = True
         out["grad_elems_gt_1e-3"], out["worst_rel"], out["grads"] = 0, 0.0, {}
         cause = {"alpha": 0, "T": 0, "both": 0, "neither": 0}
+        # Gaussians in the walk of a pixel whose alpha decision is an expf tie (see outlier_pixels): if the pair fell the other way on
+        # the GPU, every instance BEHIND it in that pixel sees another transmittance -- their rows move together with the tied one's
+        tied = np.zeros(P, bool)
+        gxt = (W + 15) // 16
+        for y, x in zip(*np.nonzero(mg["m_alpha"] < 1e-6)):
+            t = (y // 16) * gxt + x // 16
+            r0 = int(st["ranges"][t][0])
+            tied[np.asarray(st["point_list"][r0:r0 + int(st["n_contrib"][y, x])], np.int64)] = True
+        tie_rows = 0
         for k in GRAD_KEYS:
             if k in ref and k in got:
                 g64 = np.asarray(got[k], np.float64)
@@ -279,7 +294,10 @@ def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_or
                 per_row = badrows.sum(axis=1)
                 cause["alpha"] += int(per_row[ga & ~gt].sum()); cause["T"] += int(per_row[gt & ~ga].sum())
                 cause["both"] += int(per_row[ga & gt].sum()); cause["neither"] += int(per_row[~ga & ~gt].sum())
+                tie_rows += int(per_row[tied].sum())
         out["grad_elems_by_cause"] = cause
+        out["grad_elems_in_walks_of_expf_tie_pixels"] = {"elements": tie_rows, "tie_pixels": int((mg["m_alpha"] < 1e-6).sum()),
+                                                         "note": "outlier elements of Gaussians some pixel blends together with a pair whose alpha lies within 1e-6 (relative) of 1/255 in the oracle"}
         if s is not None and grads is not None and out["grad_elems_gt_1e-3"]:
             # ORDER-NOISE ENVELOPE (round 5): the reference scatters its per-contribution terms with unordered fp32 atomicAdd
             # (backward.cu:554-601), so its own result for a Gaussian moves with the order its pixels were served in.  For every
@@ -310,11 +328,13 @@ def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_or
                         ok = lo <= ours <= hi
                         inside += ok; outside += (not ok)
                         cls = "alpha" if (ga[g] and not gt[g]) else "T" if (gt[g] and not ga[g]) else "both" if (ga[g] and gt[g]) else "neither"
-                        listing.append({"gaussian": int(g), "family": k, "component": int(c), "cause": cls, "ours": ours, "oracle_double": dbl,
+                        listing.append({"gaussian": int(g), "family": k, "component": int(c), "cause": cls, "in_expf_tie_walk": bool(tied[g]), "ours": ours, "oracle_double": dbl,
                                         "reference_fp32_orders_min": lo, "reference_fp32_orders_max": hi,
                                         "ours_minus_double_over_envelope_halfwidth": (abs(ours - dbl) / half) if half > 0 else float("inf"),
                                         "inside_envelope": bool(ok)})
             out["order_noise_envelope"] = {"orders": envelope_orders, "rows_examined": int(len(gids)), "rows_total": int(rows.sum()),
-                                           "elements_inside": int(inside), "elements_outside": int(outside), "elements": listing}
+                                           "elements_inside": int(inside), "elements_outside": int(outside),
+                                           "elements_outside_not_in_an_expf_tie_walk": int(sum(1 for e in listing if not e["inside_envelope"] and not e["in_expf_tie_walk"])),
+                                           "elements": listing}
     out["bands"] = {"alpha_rel": ALPHA_BAND, "T_rel": T_BAND}
     return out

@@ -27,7 +27,6 @@ pytestmark = pytest.mark.gpu
 # expf on BOTH sides (libm in the oracle, ocml on the GPU), but the two expf differ in the last ulp on a small fraction of
 # arguments, so among the ~1e8 (pixel, Gaussian) pairs of a 1M-Gaussian frame a few still land on opposite sides of
 # alpha = 1/255.  Bounds = measured counts on the GPU box with head-room (DESIGN 6 has the measured numbers).
-PRECISE_MAX_PIXELS = 4
 PRECISE_MAX_GRAD_ELEMS = 12
 
 CONFIGS = {"config2_1M_1008x567": (1, 1_000_000, 1008, 567), "config4_2M_1920x1080": (3, 2_000_000, 1920, 1080)}
@@ -273,15 +272,12 @@ def _full_size_report(lib, seed, P, W, H, use):
 def test_full_size_element_wise_parity(seed, P, W, H, use, build):
     """Direct element-wise parity at BASELINE's size: the OpenMP oracle does 1M Gaussians @1008x567 in about a second
     per pass on the GPU box's host cores.  Radii bit-exact for every Gaussian.
-    shipped build (v_exp_f32 / v_rcp_f32 / pre-scaled quadratic form + the alpha = 1/255 GUARD BAND of round 4: a pair whose
-      alpha lies within 3e-5 relative of the threshold is decided by the reference's own expression, blend.hip): since round 4 it
-      is held to the PARITY build's bounds -- at most 4 pixels beyond 1e-4 per map and 12 gradient elements beyond 1e-3 per
-      family; every outlier is classified by the decision its pixel / Gaussian sits next to in the oracle's walk (alpha = 1/255
-      vs T = 1e-4: helpers.parity_report) and the two kinds are printed separately.  Measured with the band: 0 pixels on all
-      three configs (max 3.3e-5); gradient elements 11 / 3 / 1, of which alpha-type 0 / 1 / 0 (without the band: 60 / 18 / 11,
-      alpha-type 32 / 15 / 10).  What is left are T = 1e-4 flips: the transmittance is accumulated state and differs by ulps.
-    parity build (libgsraster_precise.so: the reference's own expression, libm expf, IEEE division, no contraction): the
-      north-star's bar on EVERY element -- see the assertion below for what is left at this size."""
+    shipped build: v_exp_f32 / v_rcp_f32 / pre-scaled quadratic form, with both discontinuous decisions of the walk settled by the
+      reference's own expressions -- alpha = 1/255 inside a guard band (round 4), the T = 1e-4 stop by an exact replay of the pixels
+      that end near it (round 5; blend.hip).  Measured: 0 pixels beyond 1e-4 on all three configs, 0 pixels whose walk ends at
+      another Gaussian than the oracle's (4 / 1 / 6 without the replay), 1 - 4 gradient elements beyond 1e-3, every one of them inside
+      the reference algorithm's own summation-order range.
+    parity build (libgsraster_precise.so: the reference's own expression, libm expf, IEEE division, no contraction): the same gate."""
     r = _full_size_report("libgsraster_precise.so" if build == "precise" else None, seed, P, W, H, use)
     assert r["lib"] == ("libgsraster_precise.so" if build == "precise" else "libgsraster.so")
     assert r["radii_equal"]
@@ -289,12 +285,24 @@ def test_full_size_element_wise_parity(seed, P, W, H, use, build):
     print(f"[{build}] gradients: " + ", ".join(f"{k}: {v['n_bad']} > 1e-3 (max {v['max']:.2e})" for k, v in r["grads"].items()))
     pc = r["parity_check"]
     print(f"[{build}] by cause: pixels {pc['px_by_cause']}, gradient elements {pc['grad_elems_by_cause']}; pixels at risk {pc['pixels_at_risk']}")
-    # both builds, the same bounds (the shipped build since the guard band of round 4)
+    # Round 5: the gate is the BAR, with the two things no implementation can pin against an fp32 / unordered-atomic reference named
+    # and measured instead of being given a blanket allowance:
+    #  * a pixel may differ by more than 1e-4 only if the ORACLE's own walk of it holds a pair within 1e-6 (relative) of alpha = 1/255:
+    #    an expf tie, decided by the libm (glibc in the oracle, ocml on the GPU, CUDA's in the reference);
+    #  * a gradient element may differ by more than 1e-3 only if our value lies INSIDE the range the reference algorithm's own
+    #    unordered fp32 atomicAdd sums span (oracle.backward_envelope, 256 random orders), or its Gaussian is blended by such a tie pixel;
+    #  * no pixel's walk may end at another Gaussian than the oracle's (the T = 1e-4 replay of the shipped build; the parity build's
+    #    chain is the reference's by construction, up to one expf tie).
+    ties = sum(1 for p_ in pc["outlier_pixels"] if p_["expf_tie"])
+    assert pc["px_gt_1e-4"] <= ties <= 2, (pc["px_gt_1e-4"], pc["outlier_pixels"])
     for k, v in r["images"].items():
-        assert v["gt_1e-4"] <= PRECISE_MAX_PIXELS and v["max"] < 5e-3, (k, v)
+        assert v["max"] < 5e-3, (k, v)
     for k, v in r["grads"].items():
         assert v["n_bad"] <= PRECISE_MAX_GRAD_ELEMS and v["p999"] <= 1e-4, (k, v)
-    # alpha = 1/255 flips are what the guard band (shipped) / the reference expression (parity build) remove: a handful at most
-    # (the two expf implementations differ in the last ulp on a small fraction of arguments)
-    assert pc["px_by_cause"]["alpha"] + pc["px_by_cause"]["both"] <= PRECISE_MAX_PIXELS, pc
-    assert pc["grad_elems_by_cause"]["alpha"] + pc["grad_elems_by_cause"]["both"] <= PRECISE_MAX_GRAD_ELEMS, pc
+    assert pc["last_contributor_differs"]["pixels"] <= (0 if build == "shipped" else 1) + ties, pc["last_contributor_differs"]
+    env = pc.get("order_noise_envelope")
+    if env:
+        print(f"[{build}] order-noise envelope: {env['elements_inside']} of {env['elements_inside'] + env['elements_outside']} elements beyond 1e-3 lie inside the "
+              f"reference algorithm's own fp32 summation-order range")
+        assert env["rows_examined"] == env["rows_total"], "more outlier rows than the envelope examines"
+        assert env["elements_outside_not_in_an_expf_tie_walk"] == 0, [e for e in env["elements"] if not e["inside_envelope"] and not e["in_expf_tie_walk"]]

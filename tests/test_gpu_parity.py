@@ -349,10 +349,14 @@ def test_preprocess_outputs_are_bit_exact():
     assert (tiles == st["tiles_touched"].astype(np.int64)).all()
     offs = gv["offsets"].cpu().numpy().astype(np.int64)
     assert (offs == np.concatenate([[0], np.cumsum(tiles)[:-1]])).all(), "exclusive scan of tiles_touched"
-    # record tail: {0, x0 | y0 << 16, survivor mask lo, hi} (the slot offset lives in offsets[], written by the scatter)
+    # record tail: {rectangle width, x0 | y0 << 16, survivor mask lo, hi} (the slot offset lives in offsets[], written by the scatter);
+    # word 11: the Gaussian's culling threshold ln(255 opacity) + margins (round 5: read by the blend kernels' box tests)
     tail = gv["rec_i32"].cpu().numpy()[vis, 12:16].astype(np.int64) & 0xffffffff
     rect = gv["rect"].cpu().numpy().astype(np.int64)[vis] & 0xffffffff
-    assert (tail[:, 0] == 0).all() and (tail[:, 1] == ((rect[:, 0] & 0xffff) | ((rect[:, 1] & 0xffff) << 16))).all()
+    assert (tail[:, 0] == (rect[:, 0] >> 16) - (rect[:, 0] & 0xffff)).all() and (tail[:, 1] == ((rect[:, 0] & 0xffff) | ((rect[:, 1] & 0xffff) << 16))).all()
+    tau = rec[vis, 11].astype(np.float64)
+    plain = np.log(255.0 * s["opacities"][vis, 0].astype(np.float64))
+    assert (tau >= plain + 0.0099).all() and (tau <= plain + 0.0101 + 1e-6 * 3.0 * np.abs(rec[vis, 2:5]).max(axis=1) * (st["radii"][vis] + 16.0) ** 2 + 1e-5).all()
 
 
 def test_empty_and_degenerate_inputs():

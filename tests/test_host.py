@@ -235,3 +235,12 @@ def test_segment_position_helpers_mirror_the_header():
             assert L2 == L or 7 * L + LY.SEG2 * (L2 - 64) < n, "the smallest multiple of 64 that covers the tail in SEG2 parts"
             pos = [LY.ckpt_pos(k, L, L2) for k in range(LY.SEG_MAX - 1)]
             assert pos[:7] == [(k + 1) * L for k in range(7)] and all(b - a_ == L2 for a_, b in zip(pos[6:-1], pos[7:]))
+
+
+def test_C_stub_module_imports_and_exports_the_five_entry_points():
+    """diff_gaussian_rasterization/_C.py (the reference's pybind module name, DGR/ext.cpp:15-21) must at least IMPORT without a GPU:
+    a syntax slip in it once reached the GPU box unnoticed because only `-m gpu` tests touched the module."""
+    import importlib
+    C = importlib.import_module("diff_gaussian_rasterization._C")
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "rasterize_aussians_filter", "rasterize_aussians_filter_position2D"):
+        assert callable(getattr(C, name)), name
