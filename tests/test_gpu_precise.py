@@ -40,3 +40,29 @@ def test_parity_build_has_no_outliers_and_shipped_build_only_threshold_flips(nat
         assert a["radii_equal"], k
         assert a["pixels_gt_1e-4"] <= max(2, 2e-5 * a["pixels"]), (k, a)
         assert a["grad_gt_1e-3"] <= max(8, 2e-4 * a["grad_elems"]) and a["grad_max_rel"] <= 0.05, (k, a)
+
+
+def test_replay_path_on_every_stopping_pixel(native_lib):
+    """libgsraster_replayall.so = the shipped sources with GSR_TBAND = 0.9: nearly every pixel that stops is walked a second time by the
+    exact replay of blend.hip (all 64 lanes on one pixel, the reference's expressions, the T chain as a DPP ripple), which the shipped
+    band (1e-4) takes on ~0.2 % of the pixels.  The thirteen cases (eleven goldens, config 1, the 60k slab) through it: radii bit-equal,
+    every pixel within 1e-4, gradients within the shipped build's bounds -- i.e. what the replay writes (outputs, final T, contributor
+    counts, depth checkpoints) is what the backward needs."""
+    assert os.path.exists(os.path.join(ROOT, "gscream_amd", "libgsraster_replayall.so")), "build() makes the replay test build"
+    rep = _run("libgsraster_replayall.so")
+    assert rep["lib"] == "libgsraster_replayall.so"
+    for k, a in rep["cases"].items():
+        assert a["radii_equal"], k
+        assert a["pixels_gt_1e-4"] == 0, (k, a)
+        assert a["grad_gt_1e-3"] <= max(8, 2e-4 * a["grad_elems"]) and a["grad_max_rel"] <= 0.05, (k, a)
+
+
+def test_replay_build_through_the_state_machine_tests(native_lib):
+    """... and the tests of the forward's state machine -- partially sorted lists with resumed quadrants, the second tier of depth
+    segments, the inference forward, occlusion cut-off, scatter bands -- re-run in a child process on the replay test build."""
+    env = dict(os.environ, GSR_LIB=os.path.join(ROOT, "gscream_amd", "libgsraster_replayall.so"))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "partial_sort or second_tier or inference or occlusion or bands or golden or stack or ties"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    assert " passed" in p.stdout and "libgsraster_replayall" not in p.stderr
