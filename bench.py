@@ -67,7 +67,7 @@ WORKLOADS = {
 }
 
 _SCENE_CACHE = {}
-NUMA_INFO = {"pinned": False, "why": "single process: not pinned (the CPU-baseline leg wants every core)"}
+NUMA_INFO = {"pinned": False, "why": "not pinned: a single process (the CPU-baseline leg wants every core) or the oversubscribed test mode (ranks share a GPU)"}
 
 
 def scene_for(workload, seed, P, W, H):

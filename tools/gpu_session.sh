@@ -3,31 +3,20 @@
 # tools/gpu_ab.sh, tools/snapshot.sh, tools/pmc_run.sh -- are the reusable ones).  usage: gpurun -- 'bash tools/gpu_session.sh'
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_s7; mkdir -p "$OUT"
-timeout 3000 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^\[Gloo\]" | grep -E "passed|failed|rror|assert|threshold flips" | tail -30 > "$OUT/pytest_all.txt"
-TAG=r5_s7 WORKLOADS="config2 config3 config4" REPEAT=2 bash tools/gpu_ab.sh notreplay > /dev/null 2>&1
-bash tools/snapshot.sh r05_config2 config2 > "$OUT/snap2.log" 2>&1
-bash tools/snapshot.sh r05_config3 config3 > "$OUT/snap3.log" 2>&1
-bash tools/snapshot.sh r05_config4 config4 > "$OUT/snap4.log" 2>&1
-for wl in surfaces init_state; do timeout 900 python bench.py --workload $wl --no-strict-parity 2>>"$OUT/err.log" | tail -1 > "$OUT/bench_$wl.json"; done
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_s8; mkdir -p "$OUT"
+timeout 3000 python -m pytest tests -m gpu -q 2>&1 | grep -v "^\[Gloo\]" | tail -25 > "$OUT/pytest_all.txt"
+python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.txt" 2>&1
+timeout 900 python bench.py 2>>"$OUT/err.log" | tail -1 > "$OUT/bench_config2.json"
 timeout 900 python bench.py --workload config5 --steps 50 --warmup 10 2>>"$OUT/err.log" | tail -1 > "$OUT/bench_config5_1gpu.json"
-cat "$OUT/pytest_all.txt" "$OUT/ab.txt"
+timeout 900 python bench.py --gpus 2 --oversubscribe --backend gloo --no-cpu-baseline --no-next-rows 2>>"$OUT/err.log" | tail -1 > "$OUT/bench_2ranks_testmode.json"
+cat "$OUT/pytest_all.txt"; tail -3 "$OUT/smoke.txt"
 python - <<'EOF'
 import json, os
-o = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/"
-for tag in ("r05_config2", "r05_config3", "r05_config4"):
-    try:
-        d = json.load(open(o + f"snap_{tag}/bench.json"))
-        pc = d.get("parity_check", {})
-        print(tag, d["value"], d["ms_per_step"], "roofline", d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], "whole", d["whole_iteration"]["frac_of_hbm_peak"],
-              "parity px", pc.get("px_gt_1e-4"), "grad", pc.get("grad_elems_gt_1e-3"), pc.get("grad_elems_by_cause"), pc.get("last_contributor_differs"),
-              "env", (pc.get("order_noise_envelope") or {}).get("elements_inside"), (pc.get("order_noise_envelope") or {}).get("elements_outside"))
-    except Exception as ex:
-        print(tag, "error", ex)
-for wl in ("surfaces", "init_state", "config5_1gpu"):
-    try:
-        d = json.load(open(o + f"r5_s7/bench_{wl}.json"))
-        print(wl, d["value"], d["ms_per_step"], d.get("wall_clock"), {k: round(x["avg_ms"] * 1e3, 1) for k, x in d.get("stages", {}).items()})
-    except Exception as ex:
-        print(wl, "error", ex)
+o = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r5_s8/"
+d = json.load(open(o + "bench_config2.json"))
+print("config2", d["value"], d["ms_per_step"], "roofline", {k: d["roofline"].get(k) for k in ("frac", "avg_launch_ms", "traffic")}, "valu", d["roofline"].get("valu"))
+c = json.load(open(o + "bench_config5_1gpu.json"))
+print("config5", c["value"], c["wall_clock"], c["per_rank"])
+t = json.load(open(o + "bench_2ranks_testmode.json"))
+print("2 ranks", t["value"], t["per_rank"])
 EOF

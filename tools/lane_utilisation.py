@@ -62,6 +62,7 @@ def main():
     trav = 0
     windows = (1, 4, 8, None)
     pair_now, pair_single, pair_after = 0, 0, {w: 0 for w in windows}
+    box_iters = box_pixels = box_instances = 0
     seg_len = 64 if gx * gy <= 4096 else 128
     for t in tiles:
         tx, ty = t % gx, t // gx
@@ -78,6 +79,20 @@ def main():
         alpha = np.minimum(0.99, con[ids, 3][:, None, None] * np.exp(power))
         blend = (power <= 0) & (alpha >= 1 / 255) & (np.arange(depth)[:, None, None] < nc[None])   # [n,16,16]
         tot_pairs += int(blend.sum())
+        # Box-mapped lanes (round 5, modelled only): one wave per (tile, segment) whose 64 lanes are laid over the bounding box of the
+        # instance's BLENDING pixels in the tile (width rounded up to a power of two so that lane -> pixel is shift / mask; pixel
+        # state lives in LDS because a lane's pixel changes with every instance): iterations = ceil(box pixels / 64) per instance
+        any_px = blend.any(axis=0)
+        for i in range(depth):
+            b = blend[i]
+            if not b.any():
+                continue
+            ys_, xs_ = np.nonzero(b)
+            w = int(xs_.max() - xs_.min() + 1); h = int(ys_.max() - ys_.min() + 1)
+            w2 = 1 << (w - 1).bit_length()
+            box_iters += -(-(w2 * h) // 64)
+            box_pixels += int(b.sum())
+            box_instances += 1
         # opposite-half pairing, per (strip, depth segment): the backward walks back to front, the count does not depend on direction
         for strip in range(2):
             left = blend[:, strip * 8:strip * 8 + 8, 0:8].any(axis=(1, 2))
@@ -105,6 +120,8 @@ def main():
         p = acc[k]["pairs"]
         print(f"  {k:5s}: (instance, block) pairs per tile {p / ntiles:8.0f}   lane utilisation {tot_pairs / (p * bw * bh):.3f}   "
               f"4-block wave iterations per tile {acc[k]['iters4'] / ntiles:8.0f}  (balance {p / 4 / max(acc[k]['iters4'], 1):.2f})")
+    print(f"box-mapped lanes ({wl}): {box_instances / ntiles:.0f} blending (instance, tile) pairs per tile, {box_iters / ntiles:.0f} 64-lane iterations per tile "
+          f"({box_iters / max(box_instances, 1):.2f} per pair), lane utilisation {box_pixels / max(box_iters * 64, 1):.3f}")
     print(f"opposite-half pairing ({wl}, segments of {seg_len}): blending (instance, strip) iterations per tile {pair_now / ntiles:.0f}, "
           f"{pair_single / max(pair_now, 1):.1%} of them touch one 8x8 half only")
     for w in windows:
