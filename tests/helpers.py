@@ -186,7 +186,7 @@ def grad_report(got, ref, tol=GRAD_REL_TOL):
     return dict(max=float(rel.max()), p999=float(np.quantile(rel, 0.999)), n_bad=int((rel > tol).sum()), n=int(rel.size))
 
 
-def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-5, min_bad_allowed=4, max_rel=0.02):
+def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", max_bad_frac=2e-5, min_bad_allowed=4, max_rel=0.01):
     """Every gradient family within `tol` rel (denominator |ref| + 1e-3 max|ref|) on all but a bounded
     handful of elements.  The handful exists because a (pixel, Gaussian) pair whose alpha sits within an
     ulp of 1/255 (or whose T sits at 1e-4) can be blended by one implementation and skipped by the other
@@ -197,7 +197,11 @@ def assert_grads_close(got, ref, keys=GRAD_KEYS, tol=GRAD_REL_TOL, context="", m
     `max_rel` (0.02: one flipped pixel of one Gaussian; the parity build libgsraster_precise.so, which evaluates the
     reference's own expression, has NO element beyond `tol` on the same cases -- tests/test_gpu_precise.py).
     Round 4 (guard band around alpha = 1/255 in both blend loops): the whole GPU suite prints ONE such element (1.1e-3, dL/drot);
-    bounds tightened from 2e-4 of the elements / 0.05 to 2e-5 / 0.02 -- what remains are T = 1e-4 flips."""
+    bounds tightened from 2e-4 of the elements / 0.05 to 2e-5 / 0.02 -- what remained were T = 1e-4 flips.
+    Round 5 (exact replay of the pixels that end near T = 1e-4): those are gone too; the suite prints one family with two elements at
+    1.3e-3 (dL/drot of a 180k-Gaussian slab: fp32 summation order, the kind the full-size tests show to lie inside the reference's own
+    order noise) -- worst element 0.02 -> 0.01; the handful stays for expf ties (a pair within an ulp of alpha = 1/255 falls as the
+    libm decides: glibc in the oracle, ocml on the GPU), which the full-size gate names one by one."""
     rep = {}
     for k in keys:
         if k not in ref or k not in got:
