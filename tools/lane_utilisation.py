@@ -10,7 +10,7 @@ the RIGHT half; an instance that blends only left pixels and one that blends onl
 two could share ONE packed iteration; instances that blend in both halves are barriers.  Per (tile, strip, 64-position depth
 segment) -- the backward's work unit -- the walk's sequence of blending instances is classified L / R / both and the iterations
 that vanish are counted for pairing windows of 1, 4, 8 and unbounded (greedy zip of the L and R sub-sequences between barriers).
-usage: python tools/lane_utilisation.py [ntiles] [workload: config2 | config3 | config4 | surfaces]"""
+usage: python tools/lane_utilisation.py [ntiles] [workload: config2 | config3 | config4 | surfaces | init_state]"""
 import os
 import sys
 
@@ -49,8 +49,22 @@ def main():
     ntiles = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     wl = sys.argv[2] if len(sys.argv) > 2 else "config2"
     seed, P, W, H = {"config2": (1, 1_000_000, 1008, 567), "config3": (2, 1_000_000, 1008, 567), "config4": (3, 2_000_000, 1920, 1080),
-                     "surfaces": (1, 1_000_000, 1008, 567)}[wl]
-    s = (S.scene_surfaces if wl == "surfaces" else S.scene_slab)(seed, P, W, H)
+                     "surfaces": (1, 1_000_000, 1008, 567), "init_state": (1, 0, 1008, 567)}[wl]
+    if wl == "init_state":  # GScream's iteration-0 frame, decoded with the float64 decode ORACLE on the CPU (the product decode needs a GPU)
+        import torch
+        from gscream_amd import standin_model as SM
+        from oracle import decode_oracle as DO
+        from oracle import knn_oracle as KO
+        pts = SM.voxelize(S.surface_point_cloud(1, 200_000, 0.6, H / W), 0.001)
+        m = SM.Model.from_pcd(torch.from_numpy(pts).float(), torch.from_numpy(np.maximum(KO.mean_dist2(pts), 1e-7)).float(), K=10, seed=1)
+        m.eval()
+        view, proj, campos = S.camera_matrices(0.6, 0.6 * H / W)
+        with torch.no_grad():
+            xyz, color, opacity, unc, scaling, rot = DO.generate_neural_gaussians(SM.Camera(torch.from_numpy(campos)), m, None, False)
+        s = dict(means3D=xyz.numpy(), scales=scaling.numpy(), rotations=rot.numpy(), opacities=opacity.numpy().reshape(-1, 1), uncertainties=unc.numpy().reshape(-1, 1),
+                 colors=color.numpy(), W=W, H=H, tanfovx=0.6, tanfovy=0.6 * H / W, viewmatrix=view, projmatrix=proj, campos=campos, bg=np.zeros(3, np.float32), scale_modifier=1.0)
+    else:
+        s = (S.scene_surfaces if wl == "surfaces" else S.scene_slab)(seed, P, W, H)
     st = Hh.oracle_forward(s, nthreads=os.cpu_count())
     gx, gy = (W + 15) // 16, (H + 15) // 16
     rng = np.random.default_rng(0)
