@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_scan_kernel(int T, const uint32
     }
     if (threadIdx.x == 0) {
         info[0] = total; info[1] = gmax; info[2] = drop_total;  // (the barrier between the atomics and here: the scan's __syncthreads)
+        info[3] = 0u;  // quadrant walks that go beyond the first tier of depth segments: counted by the forward blend, read by the backward blend
         // the host's copy, written straight into its pinned (device-mapped) buffer: no copy kernel in the stream
         if (info_host) { info_host[0] = total; info_host[1] = gmax; info_host[2] = drop_total; }
     }
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(GSR_HIST_THREADS) gsr_scatter_kernel(
             __syncthreads();
             if (threadIdx.x == 0) {
                 const uint32_t dropped = chunk_first;
-                fs.info[0] = total; fs.info[1] = gmax; fs.info[2] = dropped;
+                fs.info[0] = total; fs.info[1] = gmax; fs.info[2] = dropped; fs.info[3] = 0u;  // ([3]: see gsr_tile_scan_kernel)
                 if (fs.info_host) { fs.info_host[0] = total; fs.info_host[1] = gmax; fs.info_host[2] = dropped; }
             }
         }

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted,
     const uint32_t* __restrict__ sorted_len, uint32_t* __restrict__ need_full, const uint32_t* __restrict__ only_flagged,
-    uint32_t* __restrict__ qresume)
+    uint32_t* __restrict__ qresume, uint32_t* __restrict__ deep_walks /* info[3]: quadrant waves that entered the second tier */)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
@@ -442,6 +442,9 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                 gsr_ckpt_b(ckpt, npass, HW)[pid] = make_float2(Dp, Uf);
             }
             npass++;
+            // entering the second tier of depth segments: counted (one fire-and-forget atomic per quadrant wave that gets there), so
+            // that the backward knows whether its big tasks are the rule or the exception on this frame
+            if (TRAIN && npass == GSR_SEG1 && lane == 0) atomicAdd(deep_walks, 1u);
             sAcc[0][lane] += C0; sAcc[1][lane] += C1; sAcc[2][lane] += C2; sAcc[3][lane] += Dp; sAcc[4][lane] += Uf;
             C0 = 0.f; C1 = 0.f; C2 = 0.f; Dp = 0.f; Uf = 0.f;
         }
@@ -789,7 +792,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ ckpt, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
     int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots,
-    uint32_t* __restrict__ heavy_groups, const uint32_t* __restrict__ need_full, int nseg /* segments the grid covers per tile */)
+    uint32_t* __restrict__ heavy_groups, const uint32_t* __restrict__ need_full, int nseg /* segments the grid covers per tile */,
+    const uint32_t* __restrict__ deep_walks /* info[3] of the forward */)
 {
     // the per-Gaussian backward that follows appends its heavy groups to a list: this launch, which always precedes it, resets
     // the counter (gauss_bwd.hip)
@@ -812,8 +816,22 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const int bq = T >> 3, br = T & 7;
     const int band_first = band < br ? band * (bq + 1) : br * (bq + 1) + (band - br) * bq, band_size = bq + (band < br ? 1 : 0);
     if (band_size == 0) return;
-    const int seg = slot / band_size, tile = band_first + (slot - seg * band_size);
-    if (seg >= nseg) return;
+    // Launch order = heaviest tasks first.  On a frame whose pixels saturate, the FIRST segments are the heaviest (every pixel still
+    // blends) and the grid runs first segments first, as in rounds 2-4.  On a frame whose long lists are walked to their ends the
+    // second-tier segments are up to GSR_SEG2 x longer than a first-tier one and lead the grid instead (with them at the END the launch
+    // drained through them: init-state frame 570 -> 480 us).  Which kind of frame this is, the forward says: info[3] = the number of
+    // quadrant walks that entered the second tier; "the rule" = more than one quadrant in sixteen.  (Leading unconditionally, or
+    // whenever ONE walk got there -- config 2's deepest ends at 463 of 448 --, cost config 2 +5 us, config 4 +8 us: empty workgroups in
+    // front of the real ones.)
+    const int rank = slot / band_size, tile = band_first + (slot - rank * band_size);
+    if (rank >= nseg) return;
+    const int nbig = nseg - GSR_SEG1;  // segments behind the first tier
+#ifdef GSR_BWD_BIG_FIRST  // (A/B knob: force one order)
+    const bool big_first = GSR_BWD_BIG_FIRST;
+#else
+    const bool big_first = *deep_walks * 4u >= (uint32_t)T;  // (wave-uniform scalar load)
+#endif
+    const int seg = big_first ? (rank < nbig ? GSR_SEG1 + rank : rank - nbig) : rank;
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
@@ -1185,7 +1203,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
     hipLaunchKernelGGL(gsr_blend_fwd_kernel<TR>, dim3(4 * T), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
-                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume)
+                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume, image.info + 3)
     if (inference) GSR_FWD_LAUNCH(false);
     else GSR_FWD_LAUNCH(true);
 #undef GSR_FWD_LAUNCH
@@ -1207,7 +1225,7 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 #define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
-                       geom.offsets, slot_written, s4, heavy_groups, image.need_full, nseg)
+                       geom.offsets, slot_written, s4, heavy_groups, image.need_full, nseg, image.info + 3)
 #ifdef GSR_BWD_BATCH128  // long segments staged 128 instances at a time (19.5 KB of LDS: 4 waves per SIMD)
     const bool b64 = sl == 64;
 #else                    // long segments in two batches of 64 (9.7 KB: 5 waves per SIMD)

@@ -25,7 +25,7 @@
 //                              gsr_ckpt_pos(k) (k = 0..GSR_SEG_MAX-2): {T in front of it, r, g, b}, {depth, feature}
 //                              sums over the segment that ends there; last slot: {checkpoints passed, sums behind the
 //                              last one}.  Lets the backward start in the middle of a list (independent depth segments)
-//           info           16 B {R, max tile count}
+//           info           16 B {R, max tile count, instances the occlusion cut-off dropped, quadrant walks that entered depth tier 2}
 //           qresume[4T]    4 B  forward blend: where a quadrant ran off its tile's sorted prefix (resume point of the fix-up)
 //   binning: point_list[R] 4 B Gaussian ids per tile segment; bit 31 = "a pixel met this instance inside the alpha = 1/255 guard
 //            band" (set by the forward blend, read by the backward blend) (unsorted after the scatter, sorted in place by the
@@ -119,7 +119,7 @@ struct GsrImage {
     uint32_t* need_full;   // per tile: 1 = the forward ran off the sorted prefix with pixels still blending
     float* ckpt;           // [GSR_CKPT_PLANES][N], see the header comment
     size_t N;
-    uint32_t* info;  // [0] = R, [1] = max tile count
+    uint32_t* info;  // [0] = R, [1] = max tile count, [2] = dropped by the occlusion cut-off, [3] = quadrant walks that entered the second tier of depth segments (forward blend)
     uint32_t* qresume;  // [4 T] per 8x8 quadrant: list position at which the forward ran off the sorted prefix (0 = it did not)
     // conservative occlusion cut-off (gsr_tuning.occlusion_cut; preprocess.hip / binning.hip)
     uint32_t* occ_mass;  // [GSR_OCC_COPIES][T][GSR_OCC_BUCKETS] fixed-point (2^-12) sums of -log2(1 - alpha_min) of the whole-tile
