@@ -182,10 +182,26 @@ extern "C" int gsr_debug_counters(void* host_dst, int reset)
 __device__ __forceinline__ float gsr_sel(unsigned long long m, float if_set, float if_clear) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : if_clear; }
 __device__ __forceinline__ float gsr_sel0(unsigned long long m, float if_set) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : 0.0f; }
 
-__device__ __forceinline__ int gsr_tile_of_block(int b, int T)
+// Tile -> XCD.  Workgroup b of a launch runs on XCD b % 8 whatever it does, so the blend kernels choose which TILES an XCD gets:
+// chunks of GSR_XCD_CHUNK consecutive tiles (raster order) dealt round-robin, XCD x's i-th tile = chunk x + 8 (i / c), tile i % c of it.
+// Rounds 1-4 gave every XCD one contiguous band of T / 8 tiles (neighbouring tiles share Gaussian records: one L2 fetches them); on a
+// scene whose density varies over the image the bands' work differs and the launch lasts as long as the heaviest band --
+// tools/wave_trace.py on the init-state frame: the first XCD ran dry at 233 us of a 506 us backward, the last three at 380 / 430 / 506.
+// Dealt in chunks of four (profiles/r05_xcd_mapping_ab.txt): that backward 480 -> 349 us, `surfaces` forward 54 -> 50 / backward 167 ->
+// 164, config 3 -1 %, config 2 +-0, config 4 +0.3 % (its uniform slab had nothing to balance and loses some L2 sharing between
+// rows); chunks of 1 / 16 / one row and 4x4-tile blocks on a skewed XCD pattern measured the same or worse.  Index arithmetic with
+// compile-time divisors only: every workgroup of the grid runs it, the empty ones too.
+#ifndef GSR_XCD_CHUNK
+#define GSR_XCD_CHUNK 4
+#endif
+__host__ __device__ __forceinline__ int gsr_xcd_tiles(int T)  // tile slots per XCD (the last chunks may be partly or wholly beyond T)
 {
-    const int xcd = b & 7, i = b >> 3, q = T >> 3, r = T & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    return (((T + GSR_XCD_CHUNK - 1) / GSR_XCD_CHUNK + 7) / 8) * GSR_XCD_CHUNK;
+}
+__device__ __forceinline__ int gsr_xcd_tile(int xcd, int i, int T)  // the i-th tile of XCD `xcd`, -1 = none
+{
+    const int t = (xcd + 8 * (i / GSR_XCD_CHUNK)) * GSR_XCD_CHUNK + i % GSR_XCD_CHUNK;
+    return t < T ? t : -1;
 }
 
 template <int CTRL>
@@ -337,8 +353,10 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     __shared__ float4 sC[GSR_FWB];
 
     GSR_TRACE_BEGIN
-    const int u = gsr_tile_of_block(blockIdx.x, 4 * T);  // quadrant tasks in tile order, one contiguous band per XCD
-    const int tile = u >> 2, quad = u & 3;
+    // quadrant tasks: workgroup b = quadrant (b >> 3) & 3 of the (b >> 5)-th tile of XCD b & 7 (gsr_xcd_tile)
+    const int tile = gsr_xcd_tile((int)(blockIdx.x & 7u), (int)(blockIdx.x >> 5), T), quad = (int)(blockIdx.x >> 3) & 3;
+    if (tile < 0) return;
+    const int u = 4 * tile + quad;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
@@ -793,7 +811,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dfeature, const uint32_t* __restrict__ tile_work,
     int T, int seg_len, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ slot_written, float4* __restrict__ slots,
     uint32_t* __restrict__ heavy_groups, const uint32_t* __restrict__ need_full, int nseg /* segments the grid covers per tile */,
-    const uint32_t* __restrict__ deep_walks /* info[3] of the forward */)
+    const uint32_t* __restrict__ deep_walks /* info[3] of the forward */, int xcd_tiles /* gsr_xcd_tiles(T) */)
 {
     // the per-Gaussian backward that follows appends its heavy groups to a list: this launch, which always precedes it, resets
     // the counter (gauss_bwd.hip)
@@ -808,14 +826,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     __shared__ uint16_t sList[2][SL];
 
     GSR_TRACE_BEGIN
-    // Workgroup b runs on XCD b % 8 and takes the (b >> 3)-th slot of that XCD's band of tiles (the forward's tile -> XCD
-    // map, so a tile's records are in the L2 that fetched them).  Slot i = (depth segment i / band size, tile i % band
-    // size): all first segments come first, then all second ones, ...; a tile has min(GSR_SEG_MAX, ceil(tile_work /
-    // segment length)) segments and the workgroups of the ones it does not have leave at once.
+    // Workgroup b runs on XCD b % 8 and takes the (b >> 3)-th slot of that XCD: slot i = (depth segment rank i / xcd_tiles, the
+    // XCD's (i % xcd_tiles)-th tile, gsr_xcd_tile: the forward's tile -> XCD map): all tasks of one rank come first, then the next
+    // rank's, ...; a tile has min(GSR_SEG_MAX, ...) segments and the workgroups of the ones it does not have leave at once.
     const int band = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
-    const int bq = T >> 3, br = T & 7;
-    const int band_first = band < br ? band * (bq + 1) : br * (bq + 1) + (band - br) * bq, band_size = bq + (band < br ? 1 : 0);
-    if (band_size == 0) return;
     // Launch order = heaviest tasks first.  On a frame whose pixels saturate, the FIRST segments are the heaviest (every pixel still
     // blends) and the grid runs first segments first, as in rounds 2-4.  On a frame whose long lists are walked to their ends the
     // second-tier segments are up to GSR_SEG2 x longer than a first-tier one and lead the grid instead (with them at the END the launch
@@ -823,8 +837,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     // quadrant walks that entered the second tier; "the rule" = more than one quadrant in sixteen.  (Leading unconditionally, or
     // whenever ONE walk got there -- config 2's deepest ends at 463 of 448 --, cost config 2 +5 us, config 4 +8 us: empty workgroups in
     // front of the real ones.)
-    const int rank = slot / band_size, tile = band_first + (slot - rank * band_size);
-    if (rank >= nseg) return;
+    const int rank = slot / xcd_tiles, tile = gsr_xcd_tile(band, slot - rank * xcd_tiles, T);
+    if (rank >= nseg || tile < 0) return;
     const int nbig = nseg - GSR_SEG1;  // segments behind the first tier
 #ifdef GSR_BWD_BIG_FIRST  // (A/B knob: force one order)
     const bool big_first = GSR_BWD_BIG_FIRST;
@@ -1200,7 +1214,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
 {
     if (T <= 0) return hipSuccess;
 #define GSR_FWD_LAUNCH(TR)                                                                                                             \
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel<TR>, dim3(4 * T), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H, \
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel<TR>, dim3(32 * gsr_xcd_tiles(T)), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
                        image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume, image.info + 3)
@@ -1221,11 +1235,11 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
     // reaches into the second tier (longest list <= GSR_SEG1 segments): the grid stops at the first tier, as before it existed
     const int sl = gsr_seg_len(T);
     const int nseg = (max_tile_count >= 0 && max_tile_count <= GSR_SEG1 * sl) ? GSR_SEG1 + 1 : GSR_SEG_MAX;
-    const dim3 grid(8u * (uint32_t)((T + 7) / 8) * (uint32_t)nseg);
+    const dim3 grid(8u * (uint32_t)gsr_xcd_tiles(T) * (uint32_t)nseg);
 #define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, bg, image.final_T, image.n_contrib, image.ckpt, dL_dcolor, GD, GF, image.tile_work, T, sl,            \
-                       geom.offsets, slot_written, s4, heavy_groups, image.need_full, nseg, image.info + 3)
+                       geom.offsets, slot_written, s4, heavy_groups, image.need_full, nseg, image.info + 3, gsr_xcd_tiles(T))
 #ifdef GSR_BWD_BATCH128  // long segments staged 128 instances at a time (19.5 KB of LDS: 4 waves per SIMD)
     const bool b64 = sl == 64;
 #else                    // long segments in two batches of 64 (9.7 KB: 5 waves per SIMD)

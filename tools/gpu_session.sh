@@ -3,4 +3,10 @@
 # tools/gpu_ab.sh, tools/snapshot.sh, tools/pmc_run.sh -- are the reusable ones).  usage: gpurun -- 'bash tools/gpu_session.sh'
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=r5_s13 WORKLOADS="init_state config2 config3 config4 surfaces" REPEAT=2 TESTS="tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_precise.py" bash tools/gpu_ab.sh first big
+OUT=gpurun_out/r5_s18; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -8 > $OUT/pytest.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
+for wl in config2 config3 config4; do bash tools/snapshot.sh r05_$wl $wl > $OUT/snap_$wl.log 2>&1; done
+for wl in init_state surfaces; do timeout 900 python bench.py --workload $wl 2> $OUT/bench_$wl.err | tail -1 > $OUT/bench_$wl.json; done
+cp profiles/pmc_latest.json $OUT/pmc_latest.json
+tail -3 $OUT/pytest.txt $OUT/smoke.txt

@@ -19,7 +19,8 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "config2"
 P, W, H, seed, gsel, desc = bench.WORKLOADS[wl]
 dev = torch.device("cuda", 0)
 lib = _native.load()
-s = S.scene_slab(seed, P, W, H)
+s = bench.scene_for(wl, seed, P, W, H)
+P = s["means3D"].shape[0]
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 leaves = [t(s[k]).requires_grad_(True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")]
 means3D, opac, unc, colors, scales, rots = leaves
@@ -50,7 +51,7 @@ t0 = st.min()
 st, en = (st - t0) / 100.0, (en - t0) / 100.0  # microseconds
 life = en - st
 q = [0, 5, 25, 50, 75, 95, 100]
-print("waves", len(rows), "tiles", T, "span us", en.max())
+print("waves", len(rows), "tiles", T, "span us", en.max(), " sum of wave lifetimes / (span x 1024 SIMDs): %.2f waves per SIMD on average" % (life.sum() / (en.max() * 1024)))
 print("start us  pct", q, np.round(np.percentile(st, q), 1))
 print("end us    pct", q, np.round(np.percentile(en, q), 1))
 print("life us   pct", q, np.round(np.percentile(life, q), 1), "mean", round(life.mean(), 1))
