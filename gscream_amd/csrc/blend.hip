@@ -336,6 +336,30 @@ __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, si
 #define GSR_FWD_ATTR
 #endif
 
+// -DGSR_FWD_ORDER (experiment): the quadrant tasks of an XCD are dispatched deepest-walk-first, the depth being what the SAME quadrant
+// walked in the previous forward (library-global buffers: an experiment, not product state)
+#ifdef GSR_FWD_ORDER
+__device__ uint32_t gsr_qdepth_hint[4 * 36864];
+__device__ uint32_t gsr_qorder[8 * 4 * 5120];
+__global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int T, int xt)
+{
+    // XCD x's 4 * xt quadrant-task slots (slot i = quadrant i & 3 of gsr_xcd_tile(x, i >> 2)); counting sort by depth / 8, deepest first
+    __shared__ uint32_t hist[256], start[256];
+    const int x = blockIdx.x, size = 4 * xt;
+    for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+    __syncthreads();
+    auto bucket = [&](int i) -> uint32_t {
+        const int tile = gsr_xcd_tile(x, i >> 2, T);
+        return tile < 0 ? 255u : 255u - min(gsr_qdepth_hint[4 * tile + (i & 3)] >> 3, 255u);  // (slots without a tile go last)
+    };
+    for (int i = threadIdx.x; i < size; i += 1024) atomicAdd(&hist[bucket(i)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 256; i++) { start[i] = run; run += hist[i]; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < size; i += 1024) gsr_qorder[(size_t)x * 4 * 5120 + atomicAdd(&start[bucket(i)], 1u)] = (uint32_t)i;
+}
+#endif
+
 // TRAIN = false: the inference forward (gsr_tuning.inference; render under no_grad): no depth checkpoints are stored (the sums
 // still restart at the segment boundaries, so that they associate as in the training forward), and final T, the last
 // contributor and the running sums are stored only by a quadrant that ran off a partially sorted prefix (its resume state);
@@ -354,7 +378,12 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
 
     GSR_TRACE_BEGIN
     // quadrant tasks: workgroup b = quadrant (b >> 3) & 3 of the (b >> 5)-th tile of XCD b & 7 (gsr_xcd_tile)
+#ifdef GSR_FWD_ORDER
+    const int qslot = only_flagged ? (int)(blockIdx.x >> 3) : (int)gsr_qorder[(size_t)(blockIdx.x & 7u) * 4 * 5120 + (blockIdx.x >> 3)];
+    const int tile = gsr_xcd_tile((int)(blockIdx.x & 7u), qslot >> 2, T), quad = qslot & 3;
+#else
     const int tile = gsr_xcd_tile((int)(blockIdx.x & 7u), (int)(blockIdx.x >> 5), T), quad = (int)(blockIdx.x >> 3) & 3;
+#endif
     if (tile < 0) return;
     const int u = 4 * tile + quad;
     const int tx = tile % gx, ty = tile / gx;
@@ -611,6 +640,9 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     }
 
     // ran off the sorted prefix with pixels still blending: the tile is sorted completely and this quadrant resumes at n
+#ifdef GSR_FWD_ORDER
+    if (lane == 0 && !only_flagged) gsr_qdepth_hint[u] = (uint32_t)min(base + GSR_FWB, n);  // list positions this walk covered
+#endif
     const bool ran_off = nsort < nlist && rg.y <= capacity && donem != full;
 
     int npl = npass;  // checkpoints passed, per lane: a replayed pixel's own walk may end in another segment than the wave's
@@ -1218,6 +1250,9 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
                        image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume, image.info + 3)
+#ifdef GSR_FWD_ORDER
+    if (!only_flagged) hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, T, gsr_xcd_tiles(T));
+#endif
     if (inference) GSR_FWD_LAUNCH(false);
     else GSR_FWD_LAUNCH(true);
 #undef GSR_FWD_LAUNCH
