@@ -52,6 +52,20 @@ def geom_views(buf, P):
 OCC_BUCKETS = 160
 
 
+XCD_CHUNK = 4   # gsr_common.h GSR_XCD_CHUNK: consecutive tiles an XCD gets at a time
+
+
+def xcd_tiles(T):
+    """Tile slots per XCD (gsr_common.h gsr_xcd_tiles)."""
+    return (((T + XCD_CHUNK - 1) // XCD_CHUNK + 7) // 8) * XCD_CHUNK
+
+
+def xcd_tile(xcd, i, T):
+    """The i-th tile of XCD `xcd`, -1 = none (gsr_common.h gsr_xcd_tile)."""
+    t = (xcd + 8 * (i // XCD_CHUNK)) * XCD_CHUNK + i % XCD_CHUNK
+    return t if t < T else -1
+
+
 def image_views(buf, P, W, H):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T, N = max(gx * gy, 1), max(W * H, 1)
@@ -73,6 +87,8 @@ def image_views(buf, P, W, H):
     off += _align(max(CKPT_PLANES * Np * 4, nocc * 4))
     out["info"] = _take(buf, off, 16, torch.int32, (4,)); off += _align(16)
     out["qresume"] = _take(buf, off, 4 * T * 4, torch.int32, (4 * T,)); off += _align(4 * T * 4)
+    nq = 32 * xcd_tiles(T)   # dispatch order of the forward's quadrant tasks (gsr_tuning.walk_depths)
+    out["qorder"] = _take(buf, off, nq * 4, torch.int32, (8, nq // 8)); off += _align(nq * 4)
     out["occ_cut"] = _take(buf, off, T * 4, torch.int32, (T,)); off += _align(T * 4)
     out["occ_drop"] = _take(buf, off, 256 * 4, torch.int32, (256,)); off += _align(256 * 4)
     out["tile_group"] = _take(buf, off, (T // 64 + 1) * 4, torch.int32, (T // 64 + 1,)); off += _align((T // 64 + 1) * 4)

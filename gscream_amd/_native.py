@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows",
 )
 NUM_STAGES = 7
-ABI_VERSION = 5  # include/gsraster.h GSR_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # include/gsraster.h GSR_ABI_VERSION this binding was written against
 
 
 class Stage1Result(ctypes.Structure):
@@ -33,7 +33,8 @@ class Stage1Result(ctypes.Structure):
 class Tuning(ctypes.Structure):
     _fields_ = [("disable_tile_cull", ctypes.c_int32), ("disable_speculation", ctypes.c_int32),
                 ("disable_partial_sort", ctypes.c_int32), ("inference", ctypes.c_int32), ("scatter_bands", ctypes.c_int32),
-                ("occlusion_cut", ctypes.c_int32), ("heavy_groups", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("occlusion_cut", ctypes.c_int32), ("heavy_groups", ctypes.c_int32), ("walk_depths_valid", ctypes.c_int32),
+                ("walk_depths", ctypes.c_uint64)]
 
 
 class Profile(ctypes.Structure):

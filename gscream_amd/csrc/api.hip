@@ -134,6 +134,14 @@ extern "C" size_t gsr_backward_scratch_bytes(int P, int num_slots)
 static bool gsr_partial_sort(const gsr_tuning* tuning) { return !(tuning && tuning->disable_partial_sort); }
 static bool gsr_inference(const gsr_tuning* tuning) { return tuning && tuning->inference; }
 static int gsr_forced_bands(const gsr_tuning* tuning) { return tuning ? tuning->scatter_bands : 0; }
+// per-view walk depths of the forward blend (gsraster.h): the caller's array + whether it already holds a previous visit's
+struct GsrWalkHint { uint32_t* depths; bool valid; };
+static GsrWalkHint gsr_walk_hint(const gsr_tuning* tuning)
+{
+    GsrWalkHint h = { nullptr, false };
+    if (tuning && tuning->walk_depths) { h.depths = reinterpret_cast<uint32_t*>((uintptr_t)tuning->walk_depths); h.valid = tuning->walk_depths_valid != 0; }
+    return h;
+}
 // the occlusion cut-off works on the tile-cull masks and keeps its table in LDS beside the histogram
 static bool gsr_occlusion(const gsr_tuning* tuning, int T)
 {
@@ -344,7 +352,7 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
 // tile asked for it; not enqueued at all when no list was long enough to be partially sorted.
 static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_count, const float* background, void* geom_ws,
                              void* image_ws, void* binning_ws, float* out_color, float* out_depth, float* out_feature,
-                             bool inference, int debug, hipStream_t stream)
+                             bool inference, GsrWalkHint walk, int debug, hipStream_t stream)
 {
     if (max_tile_count <= GSR_NEAR_CAP) return GSR_OK;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
@@ -353,14 +361,14 @@ static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_cou
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_sort_fixup(T, capacity, max_tile_count, image, bin, inference, stream), "tile sort (fix-up)");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, true, inference, stream),
+                                                            out_feature, capacity, max_tile_count, true, inference, walk.depths, walk.valid, stream),
               "forward blend (fix-up)");
     return GSR_OK;
 }
 
 static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, bool inference, int forced_bands, const float* background,
                               void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
-                              float* out_feature, int debug, hipStream_t stream)
+                              float* out_feature, GsrWalkHint walk, int debug, hipStream_t stream)
 {
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
@@ -369,12 +377,12 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, capacity, forced_bands, false, nullptr, inference, false, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, inference, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, false, inference, stream),
+                                                            out_feature, capacity, max_tile_count, false, inference, walk.depths, walk.valid, stream),
               "forward blend");
     // longest list known (two-stage form): the fix-up can follow at once; the one-call form enqueues it after the read-back
     if (partial && max_tile_count >= 0)
         return gsr_enqueue_fixup(P, W, H, capacity, max_tile_count, background, geom_ws, image_ws, binning_ws, out_color,
-                                 out_depth, out_feature, inference, debug, stream);
+                                 out_depth, out_feature, inference, walk, debug, stream);
     return GSR_OK;
 }
 
@@ -417,6 +425,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                             image_ws, radii, &info, &info_dev, fold_tile_scan, tuning, debug, stream);
     if (rc) return rc;
     const bool partial = gsr_partial_sort(tuning), inference = gsr_inference(tuning);
+    const GsrWalkHint walk = gsr_walk_hint(tuning);
     // (speculative: the sort variants are chosen from the hint; with partial sorting the hint only sizes the LDS of the
     // lists up to GSR_NEAR_CAP)
     {
@@ -433,7 +442,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, inference, geom, image, bin, stream),
                   "tile sort");
         GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                                out_feature, binning_capacity, hint, false, inference, stream),
+                                                                out_feature, binning_capacity, hint, false, inference, walk.depths, walk.valid, stream),
                   "forward blend");
     }
     if (rc) return rc;
@@ -449,7 +458,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     if (!ok) return GSR_NEED_CAPACITY;
     if (partial)
         return gsr_enqueue_fixup(P, W, H, binning_capacity, result_host->max_tile_count, background, geom_ws, image_ws,
-                                 binning_ws, out_color, out_depth, out_feature, inference, debug, stream);
+                                 binning_ws, out_color, out_depth, out_feature, inference, walk, debug, stream);
     return GSR_OK;
 }
 
@@ -465,7 +474,7 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
     return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), gsr_inference(tuning), gsr_forced_bands(tuning), background, geom_ws, image_ws, binning_ws,
-                              out_color, out_depth, out_feature, debug, stream);
+                              out_color, out_depth, out_feature, gsr_walk_hint(tuning), debug, stream);
 }
 
 extern "C" int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity, int max_tile_count, const float* background,

@@ -182,28 +182,6 @@ extern "C" int gsr_debug_counters(void* host_dst, int reset)
 __device__ __forceinline__ float gsr_sel(unsigned long long m, float if_set, float if_clear) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : if_clear; }
 __device__ __forceinline__ float gsr_sel0(unsigned long long m, float if_set) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : 0.0f; }
 
-// Tile -> XCD.  Workgroup b of a launch runs on XCD b % 8 whatever it does, so the blend kernels choose which TILES an XCD gets:
-// chunks of GSR_XCD_CHUNK consecutive tiles (raster order) dealt round-robin, XCD x's i-th tile = chunk x + 8 (i / c), tile i % c of it.
-// Rounds 1-4 gave every XCD one contiguous band of T / 8 tiles (neighbouring tiles share Gaussian records: one L2 fetches them); on a
-// scene whose density varies over the image the bands' work differs and the launch lasts as long as the heaviest band --
-// tools/wave_trace.py on the init-state frame: the first XCD ran dry at 233 us of a 506 us backward, the last three at 380 / 430 / 506.
-// Dealt in chunks of four (profiles/r05_xcd_mapping_ab.txt): that backward 480 -> 349 us, `surfaces` forward 54 -> 50 / backward 167 ->
-// 164, config 3 -1 %, config 2 +-0, config 4 +0.3 % (its uniform slab had nothing to balance and loses some L2 sharing between
-// rows); chunks of 1 / 16 / one row and 4x4-tile blocks on a skewed XCD pattern measured the same or worse.  Index arithmetic with
-// compile-time divisors only: every workgroup of the grid runs it, the empty ones too.
-#ifndef GSR_XCD_CHUNK
-#define GSR_XCD_CHUNK 4
-#endif
-__host__ __device__ __forceinline__ int gsr_xcd_tiles(int T)  // tile slots per XCD (the last chunks may be partly or wholly beyond T)
-{
-    return (((T + GSR_XCD_CHUNK - 1) / GSR_XCD_CHUNK + 7) / 8) * GSR_XCD_CHUNK;
-}
-__device__ __forceinline__ int gsr_xcd_tile(int xcd, int i, int T)  // the i-th tile of XCD `xcd`, -1 = none
-{
-    const int t = (xcd + 8 * (i / GSR_XCD_CHUNK)) * GSR_XCD_CHUNK + i % GSR_XCD_CHUNK;
-    return t < T ? t : -1;
-}
-
 template <int CTRL>
 __device__ __forceinline__ float gsr_dpp(float v)
 {
@@ -336,29 +314,52 @@ __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, si
 #define GSR_FWD_ATTR
 #endif
 
-// -DGSR_FWD_ORDER (experiment): the quadrant tasks of an XCD are dispatched deepest-walk-first, the depth being what the SAME quadrant
-// walked in the previous forward (library-global buffers: an experiment, not product state)
-#ifdef GSR_FWD_ORDER
-__device__ uint32_t gsr_qdepth_hint[4 * 36864];
-__device__ uint32_t gsr_qorder[8 * 4 * 5120];
-__global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int T, int xt)
+// Deepest walks first (gsr_tuning.walk_depths).  A forward launch has 4 T quadrant waves for ~6 k wave slots: the last third starts when
+// the first waves end, and the launch lasts until the deepest of those late starters is through (tools/wave_trace.py: config 2, started at
+// 42-47 us of 105, 55-63 us of life).  How deep a quadrant will walk is not in this frame's data (list length: correlation 0.01 on the
+// bench scene) but it barely changes between two visits of the same VIEW, and training revisits its views every epoch: a caller that keeps
+// one array of 4 T words per view gets its tasks dispatched in the order of what each quadrant walked last time, per XCD (the tile -> XCD
+// map stays).  Measured with the previous step's depths (the same view again = what an epoch later looks like): forward blend config 2
+// 104 -> 97 us, config 3 109 -> 98, config 4 229 -> 225, init-state 2 x 200 -> 2 x 168, `surfaces` 51.5 -> 52.7 (incl. this launch).
+// One workgroup per XCD: counting sort of its task slots by depth / 8 (256 classes).  Every slot's class is read ONCE into a register and
+// used for both passes, so `order` is a permutation of the slots whatever the array holds (garbage, or another stream writing it).
+__global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int T, int xt, const uint32_t* __restrict__ walk_depths, uint32_t* __restrict__ order)
 {
-    // XCD x's 4 * xt quadrant-task slots (slot i = quadrant i & 3 of gsr_xcd_tile(x, i >> 2)); counting sort by depth / 8, deepest first
+    constexpr int PER = 8;  // slots per thread: 4 * gsr_xcd_tiles(T) <= 8192, i.e. up to 16 k tiles (beyond: the launcher does not order)
     __shared__ uint32_t hist[256], start[256];
     const int x = blockIdx.x, size = 4 * xt;
     for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
     __syncthreads();
-    auto bucket = [&](int i) -> uint32_t {
-        const int tile = gsr_xcd_tile(x, i >> 2, T);
-        return tile < 0 ? 255u : 255u - min(gsr_qdepth_hint[4 * tile + (i & 3)] >> 3, 255u);  // (slots without a tile go last)
-    };
-    for (int i = threadIdx.x; i < size; i += 1024) atomicAdd(&hist[bucket(i)], 1u);
+    uint32_t cls[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = (int)threadIdx.x + k * 1024;
+        cls[k] = 255u;  // slots without a tile go last
+        if (i < size) {
+            const int tile = gsr_xcd_tile(x, i >> 2, T);
+            if (tile >= 0) cls[k] = 255u - min(walk_depths[4 * tile + (i & 3)] >> 3, 255u);
+            atomicAdd(&hist[cls[k]], 1u);
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 256; i++) { start[i] = run; run += hist[i]; } }
+    if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave
+        uint32_t v[4], run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = hist[threadIdx.x * 4 + k]; run += v[k]; }
+        uint32_t incl = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)threadIdx.x >= d) incl += o; }
+        uint32_t base = incl - run;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { start[threadIdx.x * 4 + k] = base; base += v[k]; }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < size; i += 1024) gsr_qorder[(size_t)x * 4 * 5120 + atomicAdd(&start[bucket(i)], 1u)] = (uint32_t)i;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = (int)threadIdx.x + k * 1024;
+        if (i < size) order[(size_t)x * size + atomicAdd(&start[cls[k]], 1u)] = (uint32_t)i;
+    }
 }
-#endif
 
 // TRAIN = false: the inference forward (gsr_tuning.inference; render under no_grad): no depth checkpoints are stored (the sums
 // still restart at the segment boundaries, so that they associate as in the training forward), and final T, the last
@@ -371,19 +372,17 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     float* __restrict__ out_feature, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted,
     const uint32_t* __restrict__ sorted_len, uint32_t* __restrict__ need_full, const uint32_t* __restrict__ only_flagged,
-    uint32_t* __restrict__ qresume, uint32_t* __restrict__ deep_walks /* info[3]: quadrant waves that entered the second tier */)
+    uint32_t* __restrict__ qresume, uint32_t* __restrict__ deep_walks /* info[3]: quadrant waves that entered the second tier */,
+    const uint32_t* __restrict__ qorder /* dispatch order of the XCDs' task slots, or NULL */, uint32_t* __restrict__ walk_out /* gsr_tuning.walk_depths or NULL */)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
 
     GSR_TRACE_BEGIN
     // quadrant tasks: workgroup b = quadrant (b >> 3) & 3 of the (b >> 5)-th tile of XCD b & 7 (gsr_xcd_tile)
-#ifdef GSR_FWD_ORDER
-    const int qslot = only_flagged ? (int)(blockIdx.x >> 3) : (int)gsr_qorder[(size_t)(blockIdx.x & 7u) * 4 * 5120 + (blockIdx.x >> 3)];
+    // (the order array: gsr_fwd_order_kernel; without one -- no per-view depths, or the fix-up pass -- slot b >> 3 is the task itself)
+    const int qslot = qorder ? (int)qorder[(size_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)] : (int)(blockIdx.x >> 3);
     const int tile = gsr_xcd_tile((int)(blockIdx.x & 7u), qslot >> 2, T), quad = qslot & 3;
-#else
-    const int tile = gsr_xcd_tile((int)(blockIdx.x & 7u), (int)(blockIdx.x >> 5), T), quad = (int)(blockIdx.x >> 3) & 3;
-#endif
     if (tile < 0) return;
     const int u = 4 * tile + quad;
     const int tx = tile % gx, ty = tile / gx;
@@ -640,9 +639,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     }
 
     // ran off the sorted prefix with pixels still blending: the tile is sorted completely and this quadrant resumes at n
-#ifdef GSR_FWD_ORDER
-    if (lane == 0 && !only_flagged) gsr_qdepth_hint[u] = (uint32_t)min(base + GSR_FWB, n);  // list positions this walk covered
-#endif
+    if (walk_out && lane == 0) walk_out[u] = (uint32_t)min(base + GSR_FWB, n);  // list positions this walk covered (a resumed walk: up to its end)
     const bool ran_off = nsort < nlist && rg.y <= capacity && donem != full;
 
     int npl = npass;  // checkpoints passed, per lane: a replayed pixel's own walk may end in another segment than the wave's
@@ -1242,17 +1239,23 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 // ---------------------------------------------------------------------------------------------
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference, hipStream_t stream)
+                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference,
+                                    uint32_t* walk_depths, bool walk_depths_valid, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
+    // per-view walk depths: order the tasks by the previous visit's (not in the fix-up pass: a few flagged tiles), record this visit's
+    const int xt = gsr_xcd_tiles(T);
+    const uint32_t* qorder = nullptr;
+    if (walk_depths && walk_depths_valid && !only_flagged && 4 * xt <= 8192) {
+        hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, T, xt, walk_depths, image.qorder);
+        qorder = image.qorder;
+    }
 #define GSR_FWD_LAUNCH(TR)                                                                                                             \
-    hipLaunchKernelGGL(gsr_blend_fwd_kernel<TR>, dim3(32 * gsr_xcd_tiles(T)), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H, \
+    hipLaunchKernelGGL(gsr_blend_fwd_kernel<TR>, dim3(32 * xt), dim3(64), GSR_FWD_LDS_PAD, stream, image.ranges, bin.point_list, geom.rec, W, H, \
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
-                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume, image.info + 3)
-#ifdef GSR_FWD_ORDER
-    if (!only_flagged) hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, T, gsr_xcd_tiles(T));
-#endif
+                       image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume, image.info + 3,        \
+                       qorder, walk_depths)
     if (inference) GSR_FWD_LAUNCH(false);
     else GSR_FWD_LAUNCH(true);
 #undef GSR_FWD_LAUNCH

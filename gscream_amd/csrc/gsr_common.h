@@ -27,6 +27,7 @@
 //                              last one}.  Lets the backward start in the middle of a list (independent depth segments)
 //           info           16 B {R, max tile count, instances the occlusion cut-off dropped, quadrant walks that entered depth tier 2}
 //           qresume[4T]    4 B  forward blend: where a quadrant ran off its tile's sorted prefix (resume point of the fix-up)
+//           qorder[~4T]    4 B  forward blend: dispatch order of the quadrant tasks when the caller keeps per-view walk depths
 //   binning: point_list[R] 4 B Gaussian ids per tile segment; bit 31 = "a pixel met this instance inside the alpha = 1/255 guard
 //            band" (set by the forward blend, read by the backward blend) (unsorted after the scatter, sorted in place by the
 //            tile sort)   seg_keys[R] 8 B key scratch, touched only for lists longer than the LDS sort capacity
@@ -51,6 +52,28 @@
 #define GSR_SORT_CAP_SMALL 4096  // per-tile list length sorted in 32 KiB of LDS
 #define GSR_SORT_CAP_LARGE 16384 // ... in 128 KiB of LDS; longer lists use the global-memory path
 #define GSR_NEAR_CAP 2048        // longer lists are sorted only up to (at most) this many nearest instances first
+
+// Tile -> XCD.  Workgroup b of a launch runs on XCD b % 8 whatever it does, so the blend kernels choose which TILES an XCD gets:
+// chunks of GSR_XCD_CHUNK consecutive tiles (raster order) dealt round-robin, XCD x's i-th tile = chunk x + 8 (i / c), tile i % c of it.
+// Rounds 1-4 gave every XCD one contiguous band of T / 8 tiles (neighbouring tiles share Gaussian records: one L2 fetches them); on a
+// scene whose density varies over the image the bands' work differs and the launch lasts as long as the heaviest band --
+// tools/wave_trace.py on the init-state frame: the first XCD ran dry at 233 us of a 506 us backward, the last three at 380 / 430 / 506.
+// Dealt in chunks of four (profiles/r05_xcd_mapping_ab.txt): that backward 480 -> 349 us, `surfaces` forward 54 -> 50 / backward 167 ->
+// 164, config 3 -1 %, config 2 +-0, config 4 +0.3 % (its uniform slab had nothing to balance and loses some L2 sharing between
+// rows); chunks of 1 / 16 / one row and 4x4-tile blocks on a skewed XCD pattern measured the same or worse.  Index arithmetic with
+// compile-time divisors only: every workgroup of the grid runs it, the empty ones too.
+#ifndef GSR_XCD_CHUNK
+#define GSR_XCD_CHUNK 4
+#endif
+static __host__ __device__ __forceinline__ int gsr_xcd_tiles(int T)  // tile slots per XCD (the last chunks may be partly or wholly beyond T)
+{
+    return (((T + GSR_XCD_CHUNK - 1) / GSR_XCD_CHUNK + 7) / 8) * GSR_XCD_CHUNK;
+}
+static __host__ __device__ __forceinline__ int gsr_xcd_tile(int xcd, int i, int T)  // the i-th tile of XCD `xcd`, -1 = none
+{
+    const int t = (xcd + 8 * (i / GSR_XCD_CHUNK)) * GSR_XCD_CHUNK + i % GSR_XCD_CHUNK;
+    return t < T ? t : -1;
+}
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
 // Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in TWO TIERS (round 5):
@@ -121,6 +144,7 @@ struct GsrImage {
     size_t N;
     uint32_t* info;  // [0] = R, [1] = max tile count, [2] = dropped by the occlusion cut-off, [3] = quadrant walks that entered the second tier of depth segments (forward blend)
     uint32_t* qresume;  // [4 T] per 8x8 quadrant: list position at which the forward ran off the sorted prefix (0 = it did not)
+    uint32_t* qorder;   // [8][4 gsr_xcd_tiles(T)] forward blend: the quadrant-task slots of every XCD, deepest previous walk first (gsr_tuning.walk_depths)
     // conservative occlusion cut-off (gsr_tuning.occlusion_cut; preprocess.hip / binning.hip)
     uint32_t* occ_mass;  // [GSR_OCC_COPIES][T][GSR_OCC_BUCKETS] fixed-point (2^-12) sums of -log2(1 - alpha_min) of the whole-tile
                          // instances, one copy per XCD (its workgroups add with L2-local atomics), summed by the cut-off kernel
@@ -208,6 +232,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     }
     im.info = (uint32_t*)(b + off); off += gsr_align(16);
     im.qresume = (uint32_t*)(b + off); off += gsr_align(4 * T * 4);
+    im.qorder = (uint32_t*)(b + off); off += gsr_align((size_t)32 * gsr_xcd_tiles((int)T) * 4);
     im.occ_cut = (uint32_t*)(b + off); off += gsr_align(T * 4);
     im.occ_drop = (uint32_t*)(b + off); off += gsr_align((size_t)GSR_MAX_CHUNKS * 4);
     im.tile_group = (uint32_t*)(b + off); off += gsr_align((T / 64 + 1) * 4);
@@ -257,7 +282,8 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
                                 const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
-                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference, hipStream_t stream);
+                                    float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference,
+                                    uint32_t* walk_depths, bool walk_depths_valid, hipStream_t stream);
 hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
                                  bool inference, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,

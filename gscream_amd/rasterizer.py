@@ -14,6 +14,7 @@ Underneath, instead of the pybind module `_C` (DGR/ext.cpp:15-21) the calls go t
 through the C ABI of include/gsraster.h (gscream_amd/_native.py).  PyTorch only provides device
 memory (caching allocator), the current HIP stream and autograd plumbing.
 """
+import collections
 import threading
 from typing import NamedTuple
 
@@ -44,11 +45,41 @@ _pinned_tls = threading.local()  # per host thread and device: (pinned int32[4] 
 _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 
+# Per-view walk depths (gsr_tuning.walk_depths): one int32[4 T] per (view, image size, device), keyed by the address of the view matrix --
+# GScream's cameras keep theirs for the whole run (scene/cameras.py:64: world_view_transform is made once per Camera; train.py:414-416 pops a stack of
+# those objects every epoch).  A key that is reused for another camera only costs that frame its dispatch order.  Per host thread (one per
+# device), least recently used out first.
+_view_cache_on = [True]
+_view_cache_tls = threading.local()
+_VIEW_CACHE_MAX = 1024
+
+
+def _walk_depths(rs, dev, W, H):
+    """-> (tensor or None, valid): the array this view's forward records its quadrants' walk depths in, and whether it holds a previous
+    visit's already."""
+    vm = rs.viewmatrix
+    if not _view_cache_on[0] or not isinstance(vm, torch.Tensor):
+        return None, 0
+    cache = getattr(_view_cache_tls, "cache", None)
+    if cache is None:
+        cache = _view_cache_tls.cache = collections.OrderedDict()
+    key = (vm.data_ptr(), W, H, dev.index)
+    hit = cache.get(key)
+    if hit is not None:
+        cache.move_to_end(key)
+        return hit, 1
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    t = cache[key] = torch.empty((4 * max(T, 1),), dtype=torch.int32, device=dev)
+    if len(cache) > _VIEW_CACHE_MAX:
+        cache.popitem(last=False)
+    return t, 0
+
+
 _occlusion_mode = [None]  # None = automatic (per device, from the previous frames), True / False = forced
 _occlusion_state = {}     # per device: {"on": bool, "hold": frames left before the next probe}
 
 
-def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_bands=0, occlusion_cut=None, heavy_groups=None):
+def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_bands=0, occlusion_cut=None, heavy_groups=None, view_cache=True):
     """Performance knobs.  Images, radii and gradients do not depend on them.
     partial_sort=False sorts every per-tile list completely (the reference's lists); by default lists longer than 2048
     entries are depth-sorted only as far as the blend is expected to walk, with a complete sort as fall-back.
@@ -65,6 +96,11 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_band
     # heavy_groups: None = automatic, True / False = always / never launch the per-Gaussian backward's cooperative kernel for groups of
     # large splats (gsr_tuning.heavy_groups)
     _tuning.heavy_groups = 0 if heavy_groups is None else 1 if heavy_groups else 2
+    # view_cache: keep every view's walk depths between its visits so that the forward dispatches its deepest walks first
+    # (gsr_tuning.walk_depths; ~36 KB per 1008x567 view, at most _VIEW_CACHE_MAX views per host thread)
+    _view_cache_on[0] = bool(view_cache)
+    if getattr(_view_cache_tls, "cache", None) is not None:
+        _view_cache_tls.cache.clear()
     _occlusion_mode[0] = occlusion_cut
     _occlusion_state.clear()
     _sync_tuning_variants()
@@ -198,7 +234,13 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
     occ = _occlusion_mode[0]
     if occ is None:
         occ = _occlusion_state.get(idx, _OCC_OFF)["on"]
-    tuning = _tuning_variant_refs[(1 if inference else 0, 1 if occ else 0)]  # nothing shared is written per call
+    variant = (1 if inference else 0, 1 if occ else 0)
+    tuning = _tuning_variant_refs[variant]  # nothing shared is written per call
+    walk, walk_valid = _walk_depths(rs, dev, W, H)
+    if walk is not None:  # this call's own copy of the knobs + the view's array
+        tun = _native.Tuning.from_buffer_copy(_tuning_variants[variant])
+        tun.walk_depths, tun.walk_depths_valid = walk.data_ptr(), walk_valid
+        tuning = _native.ctypes.byref(tun)
     common = (P, int(rs.sh_degree), M, W, H, means3D_c.data_ptr(), _p(scales_c), float(rs.scale_modifier),
               _p(rot_c), _p(opac_c), _p(unc_c), _p(sh_c), _p(cov_c), _p(colors_c), _p(view), _p(proj), _p(campos),
               float(rs.tanfovx), float(rs.tanfovy), 1 if rs.prefiltered else 0)

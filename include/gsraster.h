@@ -85,7 +85,15 @@ typedef struct gsr_tuning {
     int32_t heavy_groups; /* per-Gaussian backward, groups of 64 Gaussians with more than 1024 gradient slots (large splats).  0 = automatic:
                                   a second, cooperative kernel takes them when the caller's previous backwards met enough of them to pay for
                                   its launch; 1 = always launch it, 2 = never (the one-wave kernel does them).  Same bits in every mode */
-    int32_t reserved;
+    int32_t walk_depths_valid; /* see walk_depths: 1 = the array holds a previous visit's depths (order by them), 0 = only record */
+    uint64_t walk_depths; /* device address of 4 * ceil(W/16) * ceil(H/16) uint32 the caller keeps PER VIEW (camera), or 0.  The forward's
+                                  launch lasts as long as its deepest walks, and the ones that start late are what it waits for; how deep a
+                                  quadrant walks hardly changes between two visits of one view, and training revisits its views every
+                                  epoch.  With this array the forward records the list depth every 8x8 quadrant walked, and -- when
+                                  walk_depths_valid says the array holds a previous visit's -- first dispatches its tasks deepest first
+                                  (forward blend -7 % config 2, -11 % config 3, -16 % on GScream's iteration-0 frame).  Any content is safe:
+                                  images and gradients do not depend on it.  The array must not be written by other work while the
+                                  forward runs. */
 } gsr_tuning;
 
 /* Pipeline stages, for the optional per-stage timing below. */
@@ -100,7 +108,7 @@ typedef struct gsr_profile {
 const char* gsr_version(void);
 /* Integer version of this header's binary interface: bumped whenever an entry point's argument list, a struct layout or a
  * workspace size formula changes incompatibly.  Bindings compare it with GSR_ABI_VERSION at load time. */
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
 /* Number of visible HIP devices, or a negative gsr_status. */

@@ -64,7 +64,7 @@ def hip_settings(s, device="cuda", debug=False):
         sh_degree=s.get("sh_degree", 1), campos=t(s["campos"]), prefiltered=False, debug=debug)
 
 
-def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False):
+def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False, rs=None):
     """Forward (+ backward if `grads`) through the public API, exactly like gaussian_renderer.render():
     means2D is a zero tensor that only carries the screen-space gradient."""
     import torch
@@ -72,7 +72,7 @@ def hip_run(s, grads=None, device="cuda", debug=False, keep_state=False):
     from gscream_amd import rasterizer as RZ
     t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a)).to(device).requires_grad_(rg)
     rg = grads is not None
-    rs = hip_settings(s, device, debug)
+    rs = hip_settings(s, device, debug) if rs is None else rs   # (rs given: the SAME view again -- the view cache keys on its matrix)
     inp = dict(means3D=t(s["means3D"], rg), opacities=t(s["opacities"], rg), uncertainties=t(s["uncertainties"], rg))
     kw = {}
     if "cov3D_precomp" in s:

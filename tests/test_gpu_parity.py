@@ -886,3 +886,58 @@ def test_init_state_frame_against_the_oracle():
     env = rep.get("order_noise_envelope")
     assert env is None or env["elements_outside_not_in_an_expf_tie_walk"] == 0, [e for e in env["elements"] if not e["inside_envelope"] and not e["in_expf_tie_walk"]]
     assert rep["grad_elems_gt_1e-3"] <= 16 + 64 * ties
+
+
+def test_view_cache_orders_the_forward_and_changes_nothing():
+    """Round 5: per-view walk depths (gsr_tuning.walk_depths, rasterizer._walk_depths).  The second visit of a view dispatches the
+    forward's quadrant tasks deepest-first from what the first visit recorded; images, radii, gradients and the state the backward reads
+    are bit-identical to a forward without the cache, whatever the array holds (a scribbled one included); the dispatch order is a
+    permutation of every XCD's task slots; the recorded depths are the walks."""
+    import torch
+    from gscream_amd import rasterizer as RZ, _layout
+    s = S.scene_config1(seed=23, P=30000, W=400, H=208)      # 25 x 13 = 325 tiles
+    grads = S.upstream_grads(23, s["W"], s["H"])
+    P, W, H = s["means3D"].shape[0], s["W"], s["H"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    try:
+        RZ.set_tuning(view_cache=False, occlusion_cut=False)   # (the automatic cut-off would shorten the lists between two visits)
+        base = Hh.hip_run(s, grads)
+        RZ.set_tuning(view_cache=True, occlusion_cut=False)
+        rs = Hh.hip_settings(s)
+        first = Hh.hip_run(s, grads, rs=rs)                  # records
+        cache = RZ._view_cache_tls.cache
+        assert len(cache) == 1
+        walk = next(iter(cache.values()))
+        assert walk.shape == (4 * T,) and walk.dtype == torch.int32
+        recorded = walk.clone()
+        second = Hh.hip_run(s, grads, rs=rs)                 # orders by the recorded depths
+        assert len(cache) == 1 and next(iter(cache.values())) is walk
+        diff = (walk != recorded).nonzero().flatten().cpu().numpy()
+        assert len(diff) == 0, ("the same view walks the same depths", len(diff), diff[:8], walk[diff[:8]].cpu().numpy(), recorded[diff[:8]].cpu().numpy())
+        keep = Hh.hip_run(s, None, keep_state=True, rs=rs)
+        iv = _layout.image_views(keep["img"], P, W, H)
+        xt = _layout.xcd_tiles(T)
+        order = iv["qorder"].cpu().numpy()
+        assert order.shape == (8, 4 * xt)
+        for x in range(8):
+            assert np.array_equal(np.sort(order[x]), np.arange(4 * xt)), f"XCD {x}: the dispatch order is a permutation of its task slots"
+            d = np.array([int(recorded[4 * _layout.xcd_tile(x, i >> 2, T) + (i & 3)]) >> 3 if _layout.xcd_tile(x, i >> 2, T) >= 0 else -1
+                          for i in order[x]])
+            assert (np.diff(np.minimum(d, 255)) <= 0).all(), f"XCD {x}: deepest recorded walks first, slots without a tile last"
+        # the recorded depth of a quadrant covers its deepest contributor (and is a multiple of the 64-instance batch or the list end)
+        ncon = (iv["n_contrib"].cpu().numpy().astype(np.int64) & 0x3fffffff).reshape(H, W)
+        rec = recorded.cpu().numpy().astype(np.int64)
+        gx = (W + 15) // 16
+        for t in range(0, T, 7):
+            for q in range(4):
+                y0, x0 = (t // gx) * 16 + (q >> 1) * 8, (t % gx) * 16 + (q & 1) * 8
+                if y0 < H and x0 < W:
+                    assert rec[4 * t + q] >= ncon[y0:y0 + 8, x0:x0 + 8].max(), (t, q)
+        walk.random_(0, 1 << 30)                             # garbage in the array: still the same frame
+        third = Hh.hip_run(s, grads, rs=rs)
+        for other, what in ((first, "recording visit"), (second, "ordered visit"), (third, "scribbled depths")):
+            for k in ("out_color", "out_depth", "out_unc", "radii", "final_T") + tuple(Hh.GRAD_KEYS):
+                if k in base:
+                    assert np.array_equal(base[k], other[k]), f"{what}: {k} differs from the forward without the view cache"
+    finally:
+        RZ.set_tuning()

@@ -27,11 +27,13 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 
 def test_tuning_struct_layout_and_the_inference_twin():
-    """gsr_tuning keeps its 32 bytes (the `inference` field took a reserved word); set_tuning keeps the inference twin of the
-    knobs in step; a forward whose inputs need no gradient is routed outside the autograd node."""
+    """gsr_tuning: seven knobs + the per-view walk-depth array (ABI 6: `walk_depths_valid` took the reserved word, the 64-bit address
+    follows at offset 32); set_tuning keeps the inference twin of the knobs in step; a forward whose inputs need no gradient is routed
+    outside the autograd node."""
     import ctypes
     from gscream_amd import _native, rasterizer as RZ
-    assert ctypes.sizeof(_native.Tuning) == 32 and _native.Tuning.inference.offset == 12
+    assert ctypes.sizeof(_native.Tuning) == 40 and _native.Tuning.inference.offset == 12
+    assert _native.Tuning.walk_depths_valid.offset == 28 and _native.Tuning.walk_depths.offset == 32 and _native.ABI_VERSION == 6
     RZ.set_tuning(tile_cull=False, partial_sort=False)
     try:
         assert RZ._tuning_variants[(1, 0)].inference == 1 and RZ._tuning.inference == 0 and RZ._tuning_variants[(0, 1)].occlusion_cut == 1
@@ -244,3 +246,41 @@ def test_C_stub_module_imports_and_exports_the_five_entry_points():
     C = importlib.import_module("diff_gaussian_rasterization._C")
     for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "rasterize_aussians_filter", "rasterize_aussians_filter_position2D"):
         assert callable(getattr(C, name)), name
+
+
+def test_tile_to_xcd_map_and_view_cache():
+    """Round 5: (1) chunks of four consecutive tiles dealt round-robin to the XCDs (gsr_common.h gsr_xcd_tile, mirrored in _layout): every
+    tile is some XCD's slot exactly once, for image sizes with and without a remainder.  (2) the per-view walk-depth cache of the mirror:
+    keyed by the view matrix's address + image size, first visit records (valid 0), later visits order (valid 1), least recently used
+    out first, off on request."""
+    import torch
+    from gscream_amd import _layout, rasterizer as RZ
+    for T in (1, 3, 4, 31, 32, 33, 2268, 8160, 36864):
+        xt = _layout.xcd_tiles(T)
+        assert xt % _layout.XCD_CHUNK == 0 and 8 * xt >= T and 8 * xt < T + 8 * _layout.XCD_CHUNK + 8
+        seen = [t for x in range(8) for t in (_layout.xcd_tile(x, i, T) for i in range(xt)) if t >= 0]
+        assert sorted(seen) == list(range(T)), T
+    Rs = lambda vm: RZ.GaussianRasterizationSettings(image_height=48, image_width=64, tanfovx=1.0, tanfovy=1.0, bg=None, scale_modifier=1.0,
+                                                     viewmatrix=vm, projmatrix=None, sh_degree=0, campos=None, prefiltered=False, debug=False)
+    cpu = torch.device("cpu")
+    saved, RZ._VIEW_CACHE_MAX = RZ._VIEW_CACHE_MAX, 3
+    try:
+        RZ.set_tuning()
+        a, b = torch.eye(4), torch.eye(4)
+        wa, va = RZ._walk_depths(Rs(a), cpu, 64, 48)
+        assert va == 0 and wa.shape == (4 * 4 * 3,) and wa.dtype == torch.int32
+        wa2, va2 = RZ._walk_depths(Rs(a), cpu, 64, 48)
+        assert va2 == 1 and wa2 is wa, "second visit of the view: the same array, now valid"
+        wb, vb = RZ._walk_depths(Rs(b), cpu, 64, 48)
+        assert vb == 0 and wb is not wa, "another view matrix: another array"
+        assert RZ._walk_depths(Rs(a), cpu, 128, 48)[1] == 0, "another image size: another array"
+        others = [torch.eye(4) for _ in range(3)]
+        for o in others:
+            RZ._walk_depths(Rs(o), cpu, 64, 48)
+        assert len(RZ._view_cache_tls.cache) == 3 and RZ._walk_depths(Rs(a), cpu, 64, 48)[1] == 0, "evicted: recorded afresh"
+        assert RZ._walk_depths(Rs(None), cpu, 64, 48) == (None, 0)
+        RZ.set_tuning(view_cache=False)
+        assert RZ._walk_depths(Rs(a), cpu, 64, 48) == (None, 0) and len(RZ._view_cache_tls.cache) == 0
+    finally:
+        RZ._VIEW_CACHE_MAX = saved
+        RZ.set_tuning()
