@@ -278,7 +278,8 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
                               const float* colors_precomp, const float* viewmatrix, const float* projmatrix,
                               const float* campos, float tan_fovx, float tan_fovy, void* geom_ws, void* image_ws,
                               int32_t* radii, volatile uint32_t** info_pinned, uint32_t** info_mapped_dev, bool defer_tile_scan,
-                              const gsr_tuning* tuning, int debug, hipStream_t stream)
+                              const gsr_tuning* tuning, bool* ordered /* out (or NULL): the forward blend's dispatch order was computed
+                              beside the column scan (gsr_tuning.walk_depths) */, int debug, hipStream_t stream)
 {
     if (!means3D || !opacities || !features || !viewmatrix || !projmatrix || !geom_ws || !image_ws || !radii)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
@@ -305,7 +306,9 @@ static int gsr_enqueue_stage1(int P, int D, int M, int W, int H, const float* me
     rc = gsr_info_buffer(info_pinned, &mapped_dev);
     if (rc) return rc;
     if (info_mapped_dev) *info_mapped_dev = mapped_dev;
-    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, defer_tile_scan, occlusion, stream), "tile count / scans");
+    const GsrWalkHint walk = gsr_walk_hint(tuning);
+    GSR_STAGE(GSR_STAGE_COUNT_SCAN, gsr_launch_count(P, T, cam.gx, geom, image, mapped_dev, defer_tile_scan, occlusion,
+                                                     (ordered && walk.valid) ? walk.depths : nullptr, ordered, stream), "tile count / scans");
     return GSR_OK;
 }
 
@@ -340,7 +343,7 @@ extern "C" int gsr_forward_stage1(int P, int D, int M, int W, int H, const float
     volatile uint32_t* info = nullptr;  // pinned words the scan kernel writes {R, max} into
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, &info, nullptr, false, tuning, debug, stream);
+                            image_ws, radii, &info, nullptr, false, tuning, nullptr, debug, stream);
     if (rc) return rc;
     GSR_HIP(hipStreamSynchronize(stream), "read num_rendered");
     uint32_t got[3] = { info[0], info[1], info[2] };
@@ -361,7 +364,7 @@ static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_cou
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_sort_fixup(T, capacity, max_tile_count, image, bin, inference, stream), "tile sort (fix-up)");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, true, inference, walk.depths, walk.valid, stream),
+                                                            out_feature, capacity, max_tile_count, true, inference, walk.depths, walk.valid, false, stream),
               "forward blend (fix-up)");
     return GSR_OK;
 }
@@ -377,7 +380,7 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, capacity, forced_bands, false, nullptr, inference, false, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, inference, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, false, inference, walk.depths, walk.valid, stream),
+                                                            out_feature, capacity, max_tile_count, false, inference, walk.depths, walk.valid, false, stream),
               "forward blend");
     // longest list known (two-stage form): the fix-up can follow at once; the one-call form enqueues it after the read-back
     if (partial && max_tile_count >= 0)
@@ -420,9 +423,10 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
     // num_rendered"): the scatter's staging (and its bands, binning.hip) is sized for the expectation, not for the provision
     const int expected_R = (int)(0.8 * (double)binning_capacity);
     const bool fold_tile_scan = true;
+    bool ordered = false;
     rc = gsr_enqueue_stage1(P, D, M, W, H, means3D, scales, scale_modifier, rotations, opacities, features, shs,
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
-                            image_ws, radii, &info, &info_dev, fold_tile_scan, tuning, debug, stream);
+                            image_ws, radii, &info, &info_dev, fold_tile_scan, tuning, &ordered, debug, stream);
     if (rc) return rc;
     const bool partial = gsr_partial_sort(tuning), inference = gsr_inference(tuning);
     const GsrWalkHint walk = gsr_walk_hint(tuning);
@@ -442,7 +446,7 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, inference, geom, image, bin, stream),
                   "tile sort");
         GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                                out_feature, binning_capacity, hint, false, inference, walk.depths, walk.valid, stream),
+                                                                out_feature, binning_capacity, hint, false, inference, walk.depths, walk.valid, ordered, stream),
                   "forward blend");
     }
     if (rc) return rc;

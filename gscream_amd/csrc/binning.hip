@@ -163,9 +163,19 @@ __global__ void __launch_bounds__(256) gsr_occ_cut_kernel(int T, const uint32_t*
 #endif
 __global__ void __launch_bounds__(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS) gsr_table_colscan_kernel(int T, int nchunks, uint32_t* __restrict__ table,
                                                                                     uint32_t* __restrict__ tile_count,
-                                                                                    uint32_t* __restrict__ group_total)
+                                                                                    uint32_t* __restrict__ group_total, int nscan, int xt,
+                                                                                    const uint32_t* __restrict__ walk_depths,
+                                                                                    uint32_t* __restrict__ qorder)
 {
     __shared__ uint32_t part[GSR_COLSCAN_GROUPS][GSR_COLSCAN_TILES];
+    // workgroups behind the scan's own: the forward blend's dispatch order, one XCD's each (gsr_common.h gsr_fwd_order_block) -- a
+    // launch of its own in front of the blend cost the forward 4.6 us; here it runs beside the scan
+    if ((int)blockIdx.x >= nscan) {
+        uint32_t* l = &part[0][0];
+        static_assert(GSR_COLSCAN_GROUPS * GSR_COLSCAN_TILES >= 512, "LDS for the ordering's two 256-word arrays");
+        gsr_fwd_order_block<GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS>((int)blockIdx.x - nscan, T, xt, walk_depths, qorder, l, l + 256);
+        return;
+    }
     const int tl = threadIdx.x % GSR_COLSCAN_TILES, grp = threadIdx.x / GSR_COLSCAN_TILES;
     const int tile = blockIdx.x * GSR_COLSCAN_TILES + tl;
     const int per = (nchunks + GSR_COLSCAN_GROUPS - 1) / GSR_COLSCAN_GROUPS;
@@ -1018,9 +1028,10 @@ static hipError_t gsr_allow_big_lds()
 }
 
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
-                            bool defer_tile_scan, bool occlusion_cut, hipStream_t stream)
+                            bool defer_tile_scan, bool occlusion_cut, const uint32_t* walk_depths, bool* ordered, hipStream_t stream)
 {
     const int nchunks = gsr_num_chunks(P);
+    if (ordered) *ordered = false;
     hipError_t e;
     const GsrOcclusion oc = { image.occ_cut, geom.depthkey, geom.tmask, geom.tiles, geom.rec, image.occ_drop };
     if (T > GSR_MAX_TILES_LDS) {
@@ -1041,8 +1052,11 @@ hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const Gsr
         hipLaunchKernelGGL((gsr_tile_hist_kernel<false, false>), dim3(nchunks), dim3(GSR_HIST_THREADS), (size_t)T * 4, stream, P, T, gx,
                            nchunks, geom.rect, geom.tmask, image.table, geom.scan_sums, oc);
         // (2) column scan -> per-(chunk, tile) offsets + tile totals
-        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3((T + GSR_COLSCAN_TILES - 1) / GSR_COLSCAN_TILES), dim3(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
-                           image.tile_count, image.tile_group);
+        const int nscan = (T + GSR_COLSCAN_TILES - 1) / GSR_COLSCAN_TILES, xt = gsr_xcd_tiles(T);
+        const bool order = walk_depths != nullptr && ordered != nullptr && 4 * xt <= GSR_ORDER_MAX_SLOTS;  // + 8 workgroups: the forward's dispatch order
+        hipLaunchKernelGGL(gsr_table_colscan_kernel, dim3(nscan + (order ? 8 : 0)), dim3(GSR_COLSCAN_TILES * GSR_COLSCAN_GROUPS), 0, stream, T, nchunks, image.table,
+                           image.tile_count, image.tile_group, nscan, xt, walk_depths, image.qorder);
+        if (order) *ordered = true;
     }
     // (3) tile scan -> ranges, info.  The one-call forward folds it into the scatter kernel (gsr_launch_scatter with
     // fused_info_host): one launch less on the critical path; the host then learns R when the scatter has started.

@@ -321,44 +321,12 @@ __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, si
 // one array of 4 T words per view gets its tasks dispatched in the order of what each quadrant walked last time, per XCD (the tile -> XCD
 // map stays).  Measured with the previous step's depths (the same view again = what an epoch later looks like): forward blend config 2
 // 104 -> 97 us, config 3 109 -> 98, config 4 229 -> 225, init-state 2 x 200 -> 2 x 168, `surfaces` 51.5 -> 52.7 (incl. this launch).
-// One workgroup per XCD: counting sort of its task slots by depth / 8 (256 classes).  Every slot's class is read ONCE into a register and
-// used for both passes, so `order` is a permutation of the slots whatever the array holds (garbage, or another stream writing it).
+// The ordering itself: gsr_common.h gsr_fwd_order_block -- eight workgroups beside the binning's column scan in the one-call forward,
+// this launch of its own (4.6 us in front of the blend) in the two-stage form.
 __global__ void __launch_bounds__(1024) gsr_fwd_order_kernel(int T, int xt, const uint32_t* __restrict__ walk_depths, uint32_t* __restrict__ order)
 {
-    constexpr int PER = 8;  // slots per thread: 4 * gsr_xcd_tiles(T) <= 8192, i.e. up to 16 k tiles (beyond: the launcher does not order)
     __shared__ uint32_t hist[256], start[256];
-    const int x = blockIdx.x, size = 4 * xt;
-    for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
-    __syncthreads();
-    uint32_t cls[PER];
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int i = (int)threadIdx.x + k * 1024;
-        cls[k] = 255u;  // slots without a tile go last
-        if (i < size) {
-            const int tile = gsr_xcd_tile(x, i >> 2, T);
-            if (tile >= 0) cls[k] = 255u - min(walk_depths[4 * tile + (i & 3)] >> 3, 255u);
-            atomicAdd(&hist[cls[k]], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave
-        uint32_t v[4], run = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = hist[threadIdx.x * 4 + k]; run += v[k]; }
-        uint32_t incl = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)threadIdx.x >= d) incl += o; }
-        uint32_t base = incl - run;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { start[threadIdx.x * 4 + k] = base; base += v[k]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int i = (int)threadIdx.x + k * 1024;
-        if (i < size) order[(size_t)x * size + atomicAdd(&start[cls[k]], 1u)] = (uint32_t)i;
-    }
+    gsr_fwd_order_block<1024>((int)blockIdx.x, T, xt, walk_depths, order, hist, start);
 }
 
 // TRAIN = false: the inference forward (gsr_tuning.inference; render under no_grad): no depth checkpoints are stored (the sums
@@ -1240,14 +1208,15 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
                                     float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference,
-                                    uint32_t* walk_depths, bool walk_depths_valid, hipStream_t stream)
+                                    uint32_t* walk_depths, bool walk_depths_valid, bool already_ordered, hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     // per-view walk depths: order the tasks by the previous visit's (not in the fix-up pass: a few flagged tiles), record this visit's
     const int xt = gsr_xcd_tiles(T);
     const uint32_t* qorder = nullptr;
-    if (walk_depths && walk_depths_valid && !only_flagged && 4 * xt <= 8192) {
-        hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, T, xt, walk_depths, image.qorder);
+    if (walk_depths && walk_depths_valid && !only_flagged && 4 * xt <= GSR_ORDER_MAX_SLOTS) {
+        if (!already_ordered)  // (the one-call forward had the column scan's launch do it)
+            hipLaunchKernelGGL(gsr_fwd_order_kernel, dim3(8), dim3(1024), 0, stream, T, xt, walk_depths, image.qorder);
         qorder = image.qorder;
     }
 #define GSR_FWD_LAUNCH(TR)                                                                                                             \

@@ -74,6 +74,53 @@ static __host__ __device__ __forceinline__ int gsr_xcd_tile(int xcd, int i, int 
     const int t = (xcd + 8 * (i / GSR_XCD_CHUNK)) * GSR_XCD_CHUNK + i % GSR_XCD_CHUNK;
     return t < T ? t : -1;
 }
+
+// Forward blend, deepest walks first (gsr_tuning.walk_depths; blend.hip has the why).  One workgroup of NT threads orders the 4 xt
+// quadrant-task slots of XCD x (slot i = quadrant i & 3 of tile gsr_xcd_tile(x, i >> 2)) by what each walked at the view's previous visit:
+// counting sort on depth / 8 (256 classes, deepest first, slots without a tile last).  Every slot's class is read ONCE into a register and
+// used for both passes, so `order` is a permutation of the slots whatever the array holds (garbage, or another stream writing it).
+// Runs as eight extra workgroups of the column-scan launch (one-call forward: off the critical path) or as its own launch (blend.hip).
+#define GSR_ORDER_MAX_SLOTS 8192  // 4 * gsr_xcd_tiles(T) an ordering workgroup takes (16 k tiles); beyond: natural order
+template <int NT>
+__device__ __forceinline__ void gsr_fwd_order_block(int x, int T, int xt, const uint32_t* __restrict__ walk_depths, uint32_t* __restrict__ order,
+                                                    uint32_t* hist /* LDS [256] */, uint32_t* start /* LDS [256] */)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    constexpr int PER = GSR_ORDER_MAX_SLOTS / NT;
+    const int size = 4 * xt, t = (int)threadIdx.x;
+    for (int i = t; i < 256; i += NT) hist[i] = 0;
+    __syncthreads();
+    uint32_t cls[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = t + k * NT;
+        cls[k] = 255u;
+        if (i < size) {
+            const int tile = gsr_xcd_tile(x, i >> 2, T);
+            if (tile >= 0) { const uint32_t d = walk_depths[4 * tile + (i & 3)] >> 3; cls[k] = 255u - (d < 255u ? d : 255u); }
+            atomicAdd(&hist[cls[k]], 1u);
+        }
+    }
+    __syncthreads();
+    if (t < 64) {  // exclusive scan of the 256 counts by one wave
+        uint32_t v[4], run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = hist[t * 4 + k]; run += v[k]; }
+        uint32_t incl = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (t >= d) incl += o; }
+        uint32_t base = incl - run;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { start[t * 4 + k] = base; base += v[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = t + k * NT;
+        if (i < size) order[(size_t)x * size + atomicAdd(&start[cls[k]], 1u)] = (uint32_t)i;
+    }
+#endif
+}
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
 // Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in TWO TIERS (round 5):
@@ -273,7 +320,8 @@ hipError_t gsr_launch_prefiltered_check(int P, const float* means3D, const float
 hipError_t gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                    hipStream_t stream);
 hipError_t gsr_launch_count(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, uint32_t* info_host_mapped,
-                            bool defer_tile_scan, bool occlusion_cut, hipStream_t stream);
+                            bool defer_tile_scan, bool occlusion_cut, const uint32_t* walk_depths /* order the forward's tasks by them, or NULL */,
+                            bool* ordered /* out: image.qorder was written by this launch */, hipStream_t stream);
 int gsr_scatter_bands(int P, int T, int gx, int expected_instances, int forced);  // bands of tile rows per chunk in the scatter launch (binning.hip)
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
                               int capacity, int expected_instances, int forced_bands, bool fused_tile_scan, uint32_t* fused_info_host, bool inference,
@@ -283,7 +331,7 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
                                     float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference,
-                                    uint32_t* walk_depths, bool walk_depths_valid, hipStream_t stream);
+                                    uint32_t* walk_depths, bool walk_depths_valid, bool already_ordered, hipStream_t stream);
 hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
                                  bool inference, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
