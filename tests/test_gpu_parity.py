@@ -935,7 +935,16 @@ def test_view_cache_orders_the_forward_and_changes_nothing():
                     assert rec[4 * t + q] >= ncon[y0:y0 + 8, x0:x0 + 8].max(), (t, q)
         walk.random_(0, 1 << 30)                             # garbage in the array: still the same frame
         third = Hh.hip_run(s, grads, rs=rs)
-        for other, what in ((first, "recording visit"), (second, "ordered visit"), (third, "scribbled depths")):
+        # the two-stage form (no speculation): the ordering is a launch of its own in front of the blend instead of eight workgroups
+        # of the column scan
+        RZ.set_tuning(view_cache=True, occlusion_cut=False, speculative=False)
+        rs2 = Hh.hip_settings(s)
+        Hh.hip_run(s, grads, rs=rs2)
+        fourth = Hh.hip_run(s, grads, rs=rs2)
+        keep2 = Hh.hip_run(s, None, keep_state=True, rs=rs2)
+        order2 = _layout.image_views(keep2["img"], P, W, H)["qorder"].cpu().numpy()
+        assert np.array_equal(np.sort(order2, axis=1), np.tile(np.arange(4 * xt), (8, 1))) and not np.array_equal(order2, np.tile(np.arange(4 * xt), (8, 1)))
+        for other, what in ((first, "recording visit"), (second, "ordered visit"), (third, "scribbled depths"), (fourth, "two-stage form")):
             for k in ("out_color", "out_depth", "out_unc", "radii", "final_T") + tuple(Hh.GRAD_KEYS):
                 if k in base:
                     assert np.array_equal(base[k], other[k]), f"{what}: {k} differs from the forward without the view cache"
