@@ -82,6 +82,24 @@ for tt in np.linspace(0, en.max(), 21)[:-1]:
     res = (st <= tt) & (en > tt)
     act = len(set(key[res].tolist()))
     print("  t=%6.1f us  resident waves %5d  SIMDs with >=1 wave %4d  mean waves on those %.2f" % (tt, int(res.sum()), act, res.sum() / max(act, 1)))
+if which == "bwd":
+    # which tasks make the tail: every row is one wavefront of workgroup b = rows' index // 2 (slot b >> 3 of XCD b & 7)
+    idx = np.nonzero(half.reshape(-1, 4)[:, 1] > 0)[0]
+    blk = idx // 2
+    from gscream_amd import _layout
+    xt = _layout.xcd_tiles(T)
+    rank = (blk >> 3) // xt
+    order = np.argsort(-en)
+    print("the 30 waves that end last: start, end, life, segment rank, XCD")
+    for i in order[:30]:
+        print("   %6.1f %6.1f %6.1f %3d %d" % (st[i], en[i], life[i], rank[i], blk[i] & 7))
+    for r in range(int(rank.max()) + 1):
+        sel = rank == r
+        if sel.sum():
+            print("  rank %2d: waves %5d  start pct(5,50,95) %s  life pct(5,50,95) %s" % (r, int(sel.sum()), np.round(np.percentile(st[sel], [5, 50, 95]), 1), np.round(np.percentile(life[sel], [5, 50, 95]), 1)))
+    for xcd in range(8):
+        sel = (blk & 7) == xcd
+        print("  XCD %d: waves %5d  sum of lifetimes %.0f us  last end %.1f" % (xcd, int(sel.sum()), life[sel].sum(), en[sel].max()))
 if which == "fwd":
     nlist = (xcc >> 8) & 0xffffff
     deep = (rows[:, 3] >> np.uint64(32)).astype(np.int64)
