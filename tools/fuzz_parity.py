@@ -2,7 +2,7 @@
 random sizes (not multiples of 16), cameras, scales (tiny splats to ones covering > 64 tiles), depth ties, all
 three upstream gradient maps on or off.  usage: python tools/fuzz_parity.py [n_cases] [seed0]
 FUZZ_KNOBS=1: every case is also run with the occlusion cut-off forced on + the scatter forced into bands + the two-stage forward,
-and must come out bit-identical (images, radii, gradients)."""
+and must come out bit-identical (images, radii, gradients); so must two more visits of the view with the per-view walk-depth cache."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +46,13 @@ def main():
                 for k in got:
                     assert np.array_equal(got[k], alt[k]), (c, knobs, k)
             set_tuning(tile_cull=bool(c % 2))
+            # round 5: the same view twice more through ONE settings object -- the per-view walk depths are recorded, then order the
+            # forward's tasks (rasterizer._walk_depths); not one output bit may move
+            rs = Hh.hip_settings(s)
+            for visit in range(2):
+                alt = Hh.hip_run(s, grads, rs=rs)
+                for k in got:
+                    assert np.array_equal(got[k], alt[k]), (c, "view cache, visit", visit, k)
         assert (got["radii"] == st["radii"]).all(), (c, "radii")
         for k in ("out_color", "out_depth", "out_unc"):
             Hh.assert_images_close(got[k], st[k], f"case{c}/{k}")

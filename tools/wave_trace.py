@@ -45,7 +45,10 @@ which = sys.argv[2] if len(sys.argv) > 2 else "bwd"
 half = buf[: 4 * 4 * 36864] if which == "bwd" else buf[4 * 4 * 36864:]
 print("kernel:", which)
 rows = half.reshape(-1, 4)
-rows = rows[rows[:, 1] > 0]
+live = rows[:, 1] > 0
+# (the buffer keeps the rows of earlier, larger launches -- another grid size, the fix-up pass: only the last launch's waves count)
+live &= rows[:, 0].astype(np.int64) >= rows[live, 0].astype(np.int64).max() - 100 * 2000   # started within 2 ms of the last wave to start
+rows = rows[live]
 st, en, hw, xcc = (rows[:, i].astype(np.int64) for i in range(4))
 t0 = st.min()
 st, en = (st - t0) / 100.0, (en - t0) / 100.0  # microseconds
@@ -84,7 +87,7 @@ for tt in np.linspace(0, en.max(), 21)[:-1]:
     print("  t=%6.1f us  resident waves %5d  SIMDs with >=1 wave %4d  mean waves on those %.2f" % (tt, int(res.sum()), act, res.sum() / max(act, 1)))
 if which == "bwd":
     # which tasks make the tail: every row is one wavefront of workgroup b = rows' index // 2 (slot b >> 3 of XCD b & 7)
-    idx = np.nonzero(half.reshape(-1, 4)[:, 1] > 0)[0]
+    idx = np.nonzero(live)[0]
     blk = idx // 2
     from gscream_amd import _layout
     xt = _layout.xcd_tiles(T)
