@@ -3,9 +3,7 @@
 # tools/gpu_ab.sh, tools/snapshot.sh, tools/pmc_run.sh -- are the reusable ones).  usage: gpurun -- 'bash tools/gpu_session.sh'
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r5_s28; mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -6 > $OUT/pytest.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
-for wl in config2 config3 config4 init_state surfaces; do timeout 900 python bench.py --workload $wl 2> $OUT/bench_$wl.err | tail -1 > $OUT/bench_$wl.json; done
-GSR_LIB=$PWD/gscream_amd/libgsraster_trace.so GSR_SKIP_ABI_CHECK=1 timeout 600 python tools/wave_trace.py config2 fwd > $OUT/trace_config2_fwd.txt 2>&1
-tail -3 $OUT/pytest.txt $OUT/smoke.txt
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_s33; mkdir -p $OUT
+FUZZ_SINGLE_KNOBS=1 FUZZ_ONLY=49 FUZZ_KNOBS=1 FUZZ_KEEP_GOING=1 timeout 900 python tools/fuzz_parity.py 60 5000 2>&1 | grep "KNOB MISMATCH.*out_color\|^case\|Error" > $OUT/fuzz49_single.txt
+FUZZ_KNOBS=1 FUZZ_KEEP_GOING=1 timeout 1500 python tools/fuzz_parity.py 60 5000 2>&1 | grep "KNOB MISMATCH.*out_\|^case\|Error\|worst\|flagged" > $OUT/fuzz_all.txt
+cat $OUT/fuzz49_single.txt | cut -c1-220; grep -c "^case" $OUT/fuzz_all.txt; grep "MISMATCH" $OUT/fuzz_all.txt | cut -c1-200 | head -20
