@@ -8,17 +8,18 @@ SEG_MAX = SEG1 + SEG2    # GSR_SEG_MAX: segments per tile = checkpoint slots (SE
 CKPT_PLANES = SEG_MAX * 6
 
 
+SEG2_ENDS = (8, 10, 13, 17, 23, 31, 43)   # ends of the second tier's segments in units of L (lengths 1, 2, 3, 4, 6, 8, 12; gsr_common.h)
+
+
 def seg2_len(n, L):
-    """gsr_seg2_len: tier-2 segment length of a tile whose list has n entries (L = 64 up to 4096 tiles, 128 beyond)."""
-    tail = n - SEG1 * L
-    if tail <= 0:
-        return L
-    return max(L, (tail + SEG2 * 64 - 1) // (SEG2 * 64) * 64)
+    """gsr_seg2_len: the unit of the second tier's boundaries = the launch's segment length L (64 up to 4096 tiles, 128 beyond),
+    whatever the list length n."""
+    return L
 
 
-def ckpt_pos(k, L, L2):
-    """gsr_ckpt_pos: list position of checkpoint k = 0 .. SEG_MAX-2."""
-    return (k + 1) * L if k < SEG1 else SEG1 * L + (k - SEG1 + 1) * L2
+def ckpt_pos(k, L, unit):
+    """gsr_ckpt_pos: list position of checkpoint k = 0 .. SEG_MAX-2 (fixed positions: they do not depend on the list)."""
+    return (k + 1) * L if k < SEG1 else unit * SEG2_ENDS[k - SEG1]
 
 
 def _align(x):

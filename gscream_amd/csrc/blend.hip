@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     // are in depth order only up to sorted_len[tile] (binning.hip): the walk ends there, and if a pixel is still
     // blending the tile is flagged and redone after a full sort.
     const int nlist = (int)(rg.y - rg.x), nsort = (int)sorted_len[tile];
-    const int seg2_len = gsr_seg2_len(nlist, seg_len);  // tier-2 segment length of this tile (gsr_common.h): from the LIST length
+    const int seg2_len = gsr_seg2_len(nlist, seg_len);  // unit of the second tier's (fixed) boundaries (gsr_common.h)
     const int n = (rg.y > capacity || (nsort == nlist && (uint32_t)nlist > longest_sorted)) ? 0 : min(nlist, nsort);
     const bool inside = px < W && py < H;
     const uint32_t HW = (uint32_t)H * (uint32_t)W, pid = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;  // <= 2^24 tiles (api.hip) = at most 2^32 pixels
@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const int band = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
     // Launch order = heaviest tasks first.  On a frame whose pixels saturate, the FIRST segments are the heaviest (every pixel still
     // blends) and the grid runs first segments first, as in rounds 2-4.  On a frame whose long lists are walked to their ends the
-    // second-tier segments are up to GSR_SEG2 x longer than a first-tier one and lead the grid instead (with them at the END the launch
+    // second-tier segments are up to 12 x longer than a first-tier one and lead the grid instead (with them at the END the launch
     // drained through them: init-state frame 570 -> 480 us).  Which kind of frame this is, the forward says: info[3] = the number of
     // quadrant walks that entered the second tier; "the rule" = more than one quadrant in sixteen.  (Leading unconditionally, or
     // whenever ONE walk got there -- config 2's deepest ends at 463 of 448 --, cost config 2 +5 us, config 4 +8 us: empty workgroups in
@@ -842,14 +842,19 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 #else
     const bool big_first = *deep_walks * 4u >= (uint32_t)T;  // (wave-uniform scalar load)
 #endif
+#ifdef GSR_BWD_TIER2_ASCENDING  // (A/B knob: second-tier segments in list order instead of longest first)
     const int seg = big_first ? (rank < nbig ? GSR_SEG1 + rank : rank - nbig) : rank;
+#else
+    // (the second tier's segments grow with depth: the deepest -- longest -- one first)
+    const int seg = big_first ? (rank < nbig ? nseg - 1 - rank : rank - nbig) : rank;
+#endif
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint2 rg = ranges[tile];
     // Instances behind the tile's deepest contributor were blended by no pixel: they are not traversed and their
     // gradient slots are NOT written; slot_written[] (zeroed per call) tells the per-Gaussian kernel which slots exist.
     const int nproc = min((int)(rg.y - rg.x), (int)tile_work[tile]);
-    const int seg2_len = gsr_seg2_len((int)(rg.y - rg.x), seg_len);  // the forward's choice for this tile: from the list length
+    const int seg2_len = gsr_seg2_len((int)(rg.y - rg.x), seg_len);  // unit of the second tier's (fixed) boundaries, as in the forward
     const int seg_lo = seg == 0 ? 0 : gsr_ckpt_pos(seg - 1, seg_len, seg2_len);
     const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, gsr_ckpt_pos(seg, seg_len, seg2_len));
     if (seg_hi <= seg_lo) return;

@@ -126,29 +126,29 @@ __device__ __forceinline__ void gsr_fwd_order_block(int x, int T, int xt, const 
 // Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in TWO TIERS (round 5):
 //   tier 1: GSR_SEG1 segments of the launch's segment length L (64 / 128) -- the fine cut the bench-like frames live in (their
 //           pixels saturate within a few hundred instances);
-//   tier 2: whatever lies behind GSR_SEG1 * L, cut into GSR_SEG2 equal parts of L2 = a multiple of 64 chosen from the tile's LIST
-//           LENGTH (known to both kernels; the walk depth is not known before the forward has run).  Rounds 1-4 had ONE segment
-//           there: on frames whose pixels do not saturate -- the faint splats of an initialised, untrained scene walk every list to
-//           its end -- a 3000-entry list left a 2500-instance task to a single workgroup that ended up alone on its SIMD
-//           (init-state frame: backward blend 1.17 ms for 1.2 M instances).
+//   tier 2: GSR_SEG2 segments of GROWING length behind GSR_SEG1 * L -- 1, 2, 3, 4, 6, 8, 12 x L, then whatever is left (with L = 64:
+//           boundaries at 512, 640, 832, 1088, 1472, 1984, 2752).  Rounds 1-4 had ONE segment there: on frames whose pixels do not
+//           saturate -- the faint splats of an initialised, untrained scene walk every list to its end -- a 3000-entry list left a
+//           2500-instance task to a single workgroup that ended up alone on its SIMD (init-state frame: backward blend 1.17 ms for
+//           1.2 M instances).  The boundaries are FIXED list positions: the first version of this tier cut the tail into eight equal
+//           parts of a length chosen from the tile's list length, and the occlusion cut-off -- which only removes instances behind
+//           everything that blends -- then moved the boundaries, i.e. changed how the forward's segment sums associate: images and
+//           gradients differed in the last bit with the knob (tools/fuzz_parity.py, case 5049).
 #define GSR_SEG1 7
 #ifndef GSR_SEG2
 #define GSR_SEG2 8
 #endif
 #define GSR_SEG_MAX (GSR_SEG1 + GSR_SEG2)   // segments per tile = checkpoint slots (GSR_SEG_MAX - 1 checkpoints + the "last" slot)
 #define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
-// tier-2 segment length of a tile whose list has n entries (L = the launch's tier-1 segment length)
-__host__ __device__ static inline int gsr_seg2_len(int n, int L)
-{
-    const int tail = n - GSR_SEG1 * L;
-    if (tail <= 0) return L;
-    const int l2 = ((tail + GSR_SEG2 * 64 - 1) / (GSR_SEG2 * 64)) * 64;
-    return l2 < L ? L : l2;
-}
+// (kept for the call sites: the unit of the second tier's boundaries is the launch's segment length, whatever the list length)
+__host__ __device__ static inline int gsr_seg2_len(int /* n */, int L) { return L; }
 // list position of checkpoint k (k = 0 .. GSR_SEG_MAX-2) = end of segment k = start of segment k + 1
-__host__ __device__ static inline int gsr_ckpt_pos(int k, int L, int L2)
+__host__ __device__ static inline int gsr_ckpt_pos(int k, int L, int unit)
 {
-    return k < GSR_SEG1 ? (k + 1) * L : GSR_SEG1 * L + (k - GSR_SEG1 + 1) * L2;
+    static_assert(GSR_SEG1 == 7 && GSR_SEG2 == 8, "the table below");
+    // ends of the second tier's segments in units of L: lengths 1, 2, 3, 4, 6, 8, 12 behind position 7
+    return k < GSR_SEG1 ? (k + 1) * L
+         : unit * (k == 7 ? 8 : k == 8 ? 10 : k == 9 ? 13 : k == 10 ? 17 : k == 11 ? 23 : k == 12 ? 31 : 43);
 }
 // Segment length of a launch: small images have few tiles, so their lists are cut finer to get enough tasks for the
 // 5120 wavefront slots; large ones already have them and shorter tasks would only add fixed costs (measured both ways).

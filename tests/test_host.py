@@ -225,18 +225,19 @@ def test_init_state_generator_follows_create_from_pcd():
 
 
 def test_segment_position_helpers_mirror_the_header():
-    """gscream_amd/_layout.py seg2_len / ckpt_pos = gsr_common.h gsr_seg2_len / gsr_ckpt_pos (values checked here against the rule's
-    definition; the GPU kernels and this mirror are compared through the checkpoints in test_second_tier_of_depth_segments)."""
+    """gscream_amd/_layout.py seg2_len / ckpt_pos = gsr_common.h gsr_seg2_len / gsr_ckpt_pos: seven segments of L, then segments of
+    1, 2, 3, 4, 6, 8, 12 x L at FIXED list positions (they must not follow the list length: the occlusion cut-off shortens lists behind
+    everything that blends, and moving boundaries would re-associate the forward's sums), then the rest.  (The GPU kernels and this
+    mirror are compared through the checkpoints in test_second_tier_of_depth_segments.)"""
     from gscream_amd import _layout as LY
     assert LY.SEG_MAX == LY.SEG1 + LY.SEG2 == 15
     for L in (64, 128):
-        assert LY.seg2_len(7 * L, L) == L and LY.seg2_len(10, L) == L
-        for n in (7 * L + 1, 7 * L + 8 * 64, 7 * L + 8 * 64 + 1, 3238, 14000):
-            L2 = LY.seg2_len(n, L)
-            assert L2 % 64 == 0 and L2 >= L and 7 * L + LY.SEG2 * L2 >= n, (n, L, L2)
-            assert L2 == L or 7 * L + LY.SEG2 * (L2 - 64) < n, "the smallest multiple of 64 that covers the tail in SEG2 parts"
-            pos = [LY.ckpt_pos(k, L, L2) for k in range(LY.SEG_MAX - 1)]
-            assert pos[:7] == [(k + 1) * L for k in range(7)] and all(b - a_ == L2 for a_, b in zip(pos[6:-1], pos[7:]))
+        for n in (10, 7 * L, 7 * L + 1, 3238, 14000):
+            assert LY.seg2_len(n, L) == L
+        pos = [LY.ckpt_pos(k, L, L) for k in range(LY.SEG_MAX - 1)]
+        assert pos[:7] == [(k + 1) * L for k in range(7)]
+        assert [b - a for a, b in zip(pos[6:-1], pos[7:])] == [m * L for m in (1, 2, 3, 4, 6, 8, 12)]
+        assert pos[-1] == 43 * L and all(p % 64 == 0 for p in pos)
 
 
 def test_C_stub_module_imports_and_exports_the_five_entry_points():
