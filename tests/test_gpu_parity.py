@@ -755,7 +755,7 @@ def test_banded_scatter_gives_the_same_lists(bands):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["stack_of_big_splats", "mixed", "bench_like"])
+@pytest.mark.parametrize("case", ["stack_of_big_splats", "mixed", "bench_like", "walks_into_the_second_tier"])
 def test_occlusion_cutoff_changes_no_output_bit(case):
     """gsr_tuning.occlusion_cut: instances behind the depth bucket at which a tile's whole-tile alphas already put every pixel's
     transmittance below 1e-4 are never binned.  Conservative by construction (DGR forward.cu:537 stops those pixels before them):
@@ -767,6 +767,14 @@ def test_occlusion_cutoff_changes_no_output_bit(case):
         s = S.scene_config1(seed=33, P=14_000, W=32, H=32, lateral=0.3)
         s["scales"] *= np.float32(6.0)
         s["opacities"] = np.maximum(s["opacities"], np.float32(0.6))
+    elif case == "walks_into_the_second_tier":
+        # case 5049 of tools/fuzz_parity.py (round 5): huge faint-ish splats, walks that go past list position 448 AND a cut-off that
+        # shortens the lists -- with second-tier boundaries chosen from the list length the images moved in the last bit
+        rng = np.random.default_rng(5049)
+        rng.choice([1, 7, 64, 65, 300, 1500, 4000, 12000]); rng.integers(17, 700); rng.integers(17, 500)   # (the sweep's draws before the camera)
+        s = S.scene_config1(seed=5049, P=12000, W=84, H=378)
+        s["scales"] = (s["scales"] * np.float32(6.0)).astype(np.float32)
+        s["viewmatrix"], s["projmatrix"], s["campos"] = S.camera_matrices(s["tanfovx"], s["tanfovy"], S.random_w2c(rng))
     elif case == "mixed":                  # big opaque splats in front of / between many small ones, partial last tile row
         s = S.scene_config1(seed=92, P=9000, W=200, H=150, lateral=0.5)
         s["scales"][:1500] *= np.float32(10.0)
@@ -793,7 +801,9 @@ def test_occlusion_cutoff_changes_no_output_bit(case):
     if case == "bench_like":
         assert on["occluded"] <= 0.01 * off["R"]
     else:
-        assert on["occluded"] > (0.5 if case == "stack_of_big_splats" else 0.1) * off["R"], (on["occluded"], off["R"])
+        assert on["occluded"] > (0.5 if case == "stack_of_big_splats" else 0.0 if case == "walks_into_the_second_tier" else 0.1) * off["R"], (on["occluded"], off["R"])
+    if case == "walks_into_the_second_tier":
+        assert (off["n_contrib"].astype(np.int64) & 0x3fffffff).max() > 7 * 64, "some walk must pass the first tier of depth segments"
     for k in ("final_T", "n_contrib", "tile_work", "radii", "color", "depth", "unc"):
         assert np.array_equal(on[k], off[k]), k
     for k in Hh.GRAD_KEYS:
@@ -806,8 +816,8 @@ def test_occlusion_cutoff_changes_no_output_bit(case):
 
 
 def test_second_tier_of_depth_segments():
-    """Round 5: lists longer than seven tier-1 segments are cut into GSR_SEG2 more segments from the tile's list length
-    (gsr_common.h gsr_seg2_len / gsr_ckpt_pos) instead of leaving everything behind position 448 to ONE backward task.  A frame of
+    """Round 5: lists longer than seven tier-1 segments are cut into GSR_SEG2 more segments at fixed list positions
+    (gsr_common.h gsr_ckpt_pos) instead of leaving everything behind position 448 to ONE backward task.  A frame of
     faint splats -- nothing saturates, every list is walked to its end, like an initialised, untrained scene -- with lists well
     beyond 448 entries: images and gradients against the oracle, the checkpoints a pixel wrote sit where the two-tier rule puts them
     (the sums of the closed segments + the open one reproduce the image), and the backward stays bit-reproducible."""
