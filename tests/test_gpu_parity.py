@@ -811,7 +811,10 @@ def test_occlusion_cutoff_changes_no_output_bit(case):
     for t in range(off["rng"].shape[0]):   # every tile: the kept list is the FRONT of the full one (the cut-off is a depth)
         a, b = off["pl"][off["rng"][t, 0]:off["rng"][t, 1]], on["pl"][on["rng"][t, 0]:on["rng"][t, 1]]
         keep = np.isin(a, b)
-        assert np.array_equal(a[keep], b), f"tile {t}: not an order-preserving subset"
+        if len(a) <= 2048:   # (a longer list is in depth order only as far as the blend walks it, binning.hip: the sets are compared, not the order)
+            assert np.array_equal(a[keep], b), f"tile {t}: not an order-preserving subset"
+        else:
+            assert np.array_equal(np.sort(a[keep]), np.sort(b)), f"tile {t}: not a subset"
         assert len(b) >= int(off["tile_work"][t]), f"tile {t}: the cut-off removed an instance the forward walks"
 
 
