@@ -1119,6 +1119,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = multi.init(args.backend, dev)  # nccl == RCCL on ROCm; None when WORLD_SIZE == 1
+    if world > 1:
+        # the driver's SCALE record is only usable if the line it parses says what carried the barriers and over how many ranks:
+        # `config.collective_backend` / `config.collective_world_size` below come from these two calls, checked here on every rank
+        if dist is None or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the process group has {None if dist is None else dist.get_world_size()} ranks")
+        if dist.get_backend() != args.backend or (not args.oversubscribe and args.backend != "nccl"):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: collective backend {dist.get_backend()!r}; a measurement needs 'nccl' (= RCCL); "
+                             "'gloo' is for the oversubscribed test mode")
     global NUMA_INFO
     if world > 1 and not args.oversubscribe:
         NUMA_INFO = multi.pin_to_gpu_numa(dev_index)  # one process per GPU: keep its host threads next to that GPU

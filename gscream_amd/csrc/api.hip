@@ -377,6 +377,10 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
+    // info[3] (quadrant walks that entered the second depth tier) is zeroed by the tile scan of stage 1 and counted up by the forward
+    // blend: a stage 2 that REPEATS a speculative forward (GSR_NEED_CAPACITY) would count those walks twice and could flip the
+    // backward's launch order on exactly the frames that outgrew their hint (results never depended on it)
+    GSR_HIP(hipMemsetAsync(image.info + 3, 0, sizeof(uint32_t), stream), "reset the deep-walk counter");
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, capacity, forced_bands, false, nullptr, inference, false, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, inference, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,

@@ -631,6 +631,7 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             // (sums of the closed segments: in LDS, sRep[0..4], touched once per segment -- five registers the walk loop's
             // allocation does not have to leave room for: 74 VGPRs = 6 waves per SIMD with them, 72 = 7 without)
             __shared__ float sRep[8];
+            __shared__ float sRepCk[(GSR_SEG_MAX - 1) * 6];  // the replay's depth checkpoints {T, r, g, b, depth, feature}, stored once it is accepted
             if (lane < 5) sRep[lane] = 0.0f;
             int np2 = 0;
             uint32_t lastq = 0u;
@@ -653,9 +654,11 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
                 float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (gid_cur != 0xffffffffu) col = rec[gid_cur].c;
                 if (np2 < GSR_SEG_MAX - 1 && b0 == gsr_ckpt_pos(np2, seg_len, seg2_len)) {  // same restarts as the walk above
+                    // (staged, not stored: a replay that is dropped below must leave the pixel's checkpoints as the fast walk wrote
+                    // them -- they belong to the final T / sums the pixel then keeps)
                     if (TRAIN && lane == 0) {
-                        gsr_ckpt_a(ckpt, np2, HW)[fpid] = make_float4(Tq, S0, S1, S2);
-                        gsr_ckpt_b(ckpt, np2, HW)[fpid] = make_float2(S3, S4);
+                        float* c = sRepCk + np2 * 6;
+                        c[0] = Tq; c[1] = S0; c[2] = S1; c[3] = S2; c[4] = S3; c[5] = S4;
                     }
                     np2++;
                     if (lane < 5) sRep[lane] += lane == 0 ? S0 : lane == 1 ? S1 : lane == 2 ? S2 : lane == 3 ? S3 : S4;
@@ -711,6 +714,11 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             // (a replay that reaches the end of a partially sorted prefix without stopping would need the entries behind it: it is
             // dropped and the pixel keeps its fast walk -- a flip exactly at the cut of a list beyond 2048 entries)
             if (!(nsort < nlist && !stoppedq)) {
+                if (TRAIN && lane < np2) {  // (single-wave workgroup: lane 0's LDS stores above are ordered before these reads)
+                    const float* c = sRepCk + lane * 6;
+                    gsr_ckpt_a(ckpt, lane, HW)[fpid] = make_float4(c[0], c[1], c[2], c[3]);
+                    gsr_ckpt_b(ckpt, lane, HW)[fpid] = make_float2(c[4], c[5]);
+                }
                 if (lane == f) {
                     Tr = Tq; C0 = S0; C1 = S1; C2 = S2; Dp = S3; Uf = S4; last = lastq; npl = np2;
                     sAcc[0][lane] = sRep[0]; sAcc[1][lane] = sRep[1]; sAcc[2][lane] = sRep[2]; sAcc[3][lane] = sRep[3]; sAcc[4][lane] = sRep[4];

@@ -267,7 +267,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.N = N;
     {
         // The occlusion cut-off's mass tables (GSR_OCC_COPIES * T * GSR_OCC_BUCKETS words = 5 KB per tile) live only from the preprocess
-        // kernel to the cut-off kernel of the same forward; the checkpoint planes (192 B per pixel = 48 KB per full tile) are first
+        // kernel to the cut-off kernel of the same forward; the checkpoint planes (GSR_CKPT_PLANES * 4 = 360 B per pixel = 90 KB per full tile: 206 MB at 1008x567) are first
         // written by the forward blend, later on the same stream: the tables ALIAS the checkpoint area (sized for the larger of the
         // two: images of a few pixels) instead of adding 11.6 MB (1008x567) / 42 MB (1920x1080) to every image workspace autograd
         // keeps alive (round 5).

@@ -16,6 +16,7 @@ memory (caching allocator), the current HIP stream and autograd plumbing.
 """
 import collections
 import threading
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -47,14 +48,27 @@ _last_stage1 = {}  # debugging aid: counts reported by the most recent forward
 
 # Per-view walk depths (gsr_tuning.walk_depths): one int32[4 T] per (view, image size, device), keyed by the address of the view matrix --
 # GScream's cameras keep theirs for the whole run (scene/cameras.py:64: world_view_transform is made once per Camera; train.py:414-416 pops a stack of
-# those objects every epoch).  A key that is reused for another camera only costs that frame its dispatch order.  Per host thread (one per
-# device), least recently used out first.
+# those objects every epoch).  Per host thread (one per device), least recently used out first.  An entry remembers WHICH tensor it was
+# recorded for (weak reference): once that tensor is gone its address may belong to another camera, and the entry starts over instead of
+# ordering the new view by the old one's depths (that would only have cost the frame its dispatch order, never a result).  Forwards
+# under no_grad use a view's entry when training made one but never create one: evaluation renders are not revisited.
 _view_cache_on = [True]
 _view_cache_tls = threading.local()
 _VIEW_CACHE_MAX = 1024
 
 
-def _walk_depths(rs, dev, W, H):
+class _ViewCache(collections.OrderedDict):  # (a subclass: plain dicts cannot be weakly referenced; compared by identity in the registry)
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):
+        return self is other
+
+
+_view_caches = weakref.WeakSet()  # every host thread's cache, so that set_tuning() clears them all
+_view_caches_lock = threading.Lock()
+
+
+def _walk_depths(rs, dev, W, H, inference=False):
     """-> (tensor or None, valid): the array this view's forward records its quadrants' walk depths in, and whether it holds a previous
     visit's already."""
     vm = rs.viewmatrix
@@ -62,14 +76,26 @@ def _walk_depths(rs, dev, W, H):
         return None, 0
     cache = getattr(_view_cache_tls, "cache", None)
     if cache is None:
-        cache = _view_cache_tls.cache = collections.OrderedDict()
+        cache = _view_cache_tls.cache = _ViewCache()
+        with _view_caches_lock:
+            _view_caches.add(cache)
     key = (vm.data_ptr(), W, H, dev.index)
     hit = cache.get(key)
     if hit is not None:
+        ref, depths = hit
+        owner = ref()
         cache.move_to_end(key)
-        return hit, 1
+        if owner is vm or (owner is not None and owner.data_ptr() == key[0]):
+            return depths, 1
+        if inference:
+            return None, 0
+        cache[key] = (weakref.ref(vm), depths)  # the address changed hands: same array, recorded afresh by this forward
+        return depths, 0
+    if inference:
+        return None, 0
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    t = cache[key] = torch.empty((4 * max(T, 1),), dtype=torch.int32, device=dev)
+    t = torch.empty((4 * max(T, 1),), dtype=torch.int32, device=dev)
+    cache[key] = (weakref.ref(vm), t)
     if len(cache) > _VIEW_CACHE_MAX:
         cache.popitem(last=False)
     return t, 0
@@ -99,8 +125,9 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_band
     # view_cache: keep every view's walk depths between its visits so that the forward dispatches its deepest walks first
     # (gsr_tuning.walk_depths; ~36 KB per 1008x567 view, at most _VIEW_CACHE_MAX views per host thread)
     _view_cache_on[0] = bool(view_cache)
-    if getattr(_view_cache_tls, "cache", None) is not None:
-        _view_cache_tls.cache.clear()
+    with _view_caches_lock:
+        for c in list(_view_caches):
+            c.clear()
     _occlusion_mode[0] = occlusion_cut
     _occlusion_state.clear()
     _sync_tuning_variants()
@@ -236,7 +263,7 @@ def _forward_native(means3D, sh, colors_precomp, opacities, uncertainties, scale
         occ = _occlusion_state.get(idx, _OCC_OFF)["on"]
     variant = (1 if inference else 0, 1 if occ else 0)
     tuning = _tuning_variant_refs[variant]  # nothing shared is written per call
-    walk, walk_valid = _walk_depths(rs, dev, W, H)
+    walk, walk_valid = _walk_depths(rs, dev, W, H, inference)
     if walk is not None:  # this call's own copy of the knobs + the view's array
         tun = _native.Tuning.from_buffer_copy(_tuning_variants[variant])
         tun.walk_depths, tun.walk_depths_valid = walk.data_ptr(), walk_valid

@@ -280,6 +280,27 @@ def test_tile_to_xcd_map_and_view_cache():
             RZ._walk_depths(Rs(o), cpu, 64, 48)
         assert len(RZ._view_cache_tls.cache) == 3 and RZ._walk_depths(Rs(a), cpu, 64, 48)[1] == 0, "evicted: recorded afresh"
         assert RZ._walk_depths(Rs(None), cpu, 64, 48) == (None, 0)
+        # forwards under no_grad use an entry that training made, and never make one (evaluation views are not revisited)
+        e = torch.eye(4)
+        n = len(RZ._view_cache_tls.cache)
+        assert RZ._walk_depths(Rs(e), cpu, 64, 48, True) == (None, 0) and len(RZ._view_cache_tls.cache) == n
+        we, _ = RZ._walk_depths(Rs(e), cpu, 64, 48)
+        assert RZ._walk_depths(Rs(e), cpu, 64, 48, True) == (we, 1)
+        # an entry whose view matrix is gone does not order whatever tensor lands on its address: it starts over (same array)
+        key = next(k for k, v in RZ._view_cache_tls.cache.items() if v[1] is we)
+        stranger = torch.eye(4)
+        RZ._view_cache_tls.cache[(stranger.data_ptr(),) + key[1:]] = RZ._view_cache_tls.cache.pop(key)
+        del e
+        ws, vs = RZ._walk_depths(Rs(stranger), cpu, 64, 48)
+        assert ws is we and vs == 0 and RZ._walk_depths(Rs(stranger), cpu, 64, 48) == (we, 1)
+        # every host thread's cache is cleared by set_tuning
+        import threading
+        other = {}
+        th = threading.Thread(target=lambda: other.update(c=(RZ._walk_depths(Rs(a), cpu, 64, 48), RZ._view_cache_tls.cache)[1]))
+        th.start(); th.join()
+        assert len(other["c"]) == 1
+        RZ.set_tuning()
+        assert len(other["c"]) == 0 and len(RZ._view_cache_tls.cache) == 0
         RZ.set_tuning(view_cache=False)
         assert RZ._walk_depths(Rs(a), cpu, 64, 48) == (None, 0) and len(RZ._view_cache_tls.cache) == 0
     finally:

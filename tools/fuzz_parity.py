@@ -65,24 +65,20 @@ def main():
                 for k in got:
                     assert np.array_equal(got[k], alt[k]), (c, "view cache, visit", visit, k)
         assert (got["radii"] == st["radii"]).all(), (c, "radii")
-        for k in ("out_color", "out_depth", "out_unc"):
-            Hh.assert_images_close(got[k], st[k], f"case{c}/{k}")
-        tol = 5e-3 if mode == 1 else 1e-3
-        # images and radii are hard failures; the gradient criterion of the test-suite (helpers.assert_grads_close) is
-        # reported per case: on these tiny scenes one or two (pixel, Gaussian) pairs whose alpha sits within an ulp of
-        # 1/255 are blended by one implementation and not by the other, and each moves all components of that Gaussian
+        # round 6: the bar itself, every outlier classified (helpers.assert_parity_strict): a pixel beyond 1e-4 only in an expf tie of the
+        # oracle's own walk, a gradient element beyond 1e-3 only inside the reference algorithm's own fp32 order range or in a tie walk.
+        # Radii are hard failures; a case the gate rejects is reported (flagged) with the clause it violated.
         try:
-            rep = Hh.assert_grads_close(got, ref, tol=tol, max_bad_frac=(5e-3 if mode == 1 else 1e-3), context=f"case{c}",
-                                        min_bad_allowed=8)
+            Hh.assert_parity_strict(got, st, ref, s, grads, context=f"case{c}")
             status = "ok"
         except AssertionError as e:
-            rep = {k: Hh.grad_report(got[k], ref[k], tol)["p999"] for k in Hh.GRAD_KEYS if k in got and k in ref}
-            flagged.append((c, str(e)[:300]))
-            status = "GRADIENT OUTLIERS"
+            flagged.append((c, str(e)[:400]))
+            status = "FLAGGED"
+        rep = {k: Hh.grad_report(got[k], ref[k], 1e-3)["max"] for k in Hh.GRAD_KEYS if k in got and k in ref}
         for k, v in rep.items():
             worst[k] = max(worst.get(k, 0.0), v)
         print(f"case {c}: P={P} {W}x{H} mode={mode} R={st['num_rendered']} {status}", flush=True)
-    print("worst per family (max, or p99.9 for flagged cases):", {k: round(v, 6) for k, v in worst.items()})
+    print("worst element per family:", {k: round(v, 6) for k, v in worst.items()})
     print(f"{len(flagged)} case(s) flagged:", *flagged, sep="\n  ")
 
 if __name__ == "__main__":
