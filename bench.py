@@ -955,6 +955,60 @@ class SceneBench:
         self.g = [t(g) for g in (upstream if upstream is not None else S.upstream_grads(grad_seed, W, H, *gsel))]  # resident, zeros where unused
         self.gsel, self.inputs = gsel, self.leaves + [self.means2D]
         self.P, self.W, self.H = P, W, H
+        self._cam = (float(s["tanfovx"]), float(s["tanfovy"]), np.linalg.inv(np.asarray(s["viewmatrix"], np.float64).T), t(s["bg"]))
+        self._t = t
+        self.rot = None
+
+    def make_rotation(self, V, seed=7, angle=0.03, eps_pos=2e-4, eps_op=1e-3):
+        """Training-like view rotation (train.py:414-416 pops a shuffled stack of cameras, one per iteration, and the
+        optimiser moves the Gaussians between two visits of a view): V cameras on a small orbit around the scene's own camera -- yaw /
+        pitch of `angle` rad about the centre of the cloud, well inside the generator's 15 % lateral overshoot, so every view sees a
+        full frame --, each with its OWN view-matrix tensor (what the per-view walk-depth cache keys on), popped in a fixed-seed shuffled
+        order epoch after epoch; before every step the Gaussians are perturbed in place by an optimiser-sized step (positions by
+        eps_pos scene units = a few hundredths of a pixel, opacities by eps_op; four fixed noise tensors used in turn with alternating
+        sign, so the cloud random-walks around where it started) -- a revisit never sees the lists it recorded."""
+        from gscream_amd import GaussianRasterizer
+        from gscream_amd import synthetic as S
+        tfx, tfy, c2w0, bg = self._cam
+        centre = self.leaves[0].detach().double().mean(0).cpu().numpy()
+        rasts = []
+        for i in range(V):
+            yaw, pitch = angle * math.cos(2 * math.pi * i / V), angle * math.sin(2 * math.pi * i / V)
+            cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+            R = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+            M = np.eye(4)
+            M[:3, :3] = R
+            M[:3, 3] = centre - R @ centre            # world-space rotation about the cloud's centre
+            w2c = np.linalg.inv(M @ c2w0)
+            view, proj, campos = S.camera_matrices(tfx, tfy, w2c.astype(np.float32))
+            rs = self.rs._replace(viewmatrix=self._t(view), projmatrix=self._t(proj), campos=self._t(campos))
+            rasts.append(GaussianRasterizer(raster_settings=rs))
+        g = torch.Generator(device=self.leaves[0].device).manual_seed(seed)
+        noise = [(torch.randn(self.leaves[0].shape, device=self.leaves[0].device, generator=g),
+                  torch.randn(self.leaves[1].shape, device=self.leaves[1].device, generator=g)) for _ in range(4)]
+        rng = np.random.default_rng(seed)
+        self.rot = {"V": V, "rasts": rasts, "noise": noise, "rng": rng, "order": [], "k": 0, "eps": (eps_pos, eps_op), "angle": angle}
+
+    def step_rot(self, perturb=True):
+        """One training-like iteration: pop the next view of the shuffled epoch, move the Gaussians, forward + backward."""
+        r = self.rot
+        if not r["order"]:
+            r["order"] = list(r["rng"].permutation(r["V"]))
+        v = r["order"].pop()
+        means3D, opac, unc, colors, scales, rots = self.leaves
+        if perturb:
+            k = r["k"]
+            r["k"] = k + 1
+            dn, do = r["noise"][k & 3]
+            sign = 1.0 if (k >> 2) & 1 == 0 else -1.0
+            with torch.no_grad():
+                means3D.add_(dn, alpha=sign * r["eps"][0])
+                opac.add_(do, alpha=sign * r["eps"][1]).clamp_(0.0, 1.0)
+        color, depth, feat, radii = r["rasts"][v](means3D, self.means2D, opac, unc, colors_precomp=colors, scales=scales, rotations=rots)
+        outs = [o for o, use in zip((color, depth, feat), self.gsel) if use]
+        gos = [g for g, use in zip(self.g, self.gsel) if use]
+        torch.autograd.grad(outs, self.inputs, gos)
+        return radii
 
     def step(self):
         means3D, opac, unc, colors, scales, rots = self.leaves
@@ -1094,6 +1148,11 @@ def main():
     ap.add_argument("--no-tile-cull", action="store_true", help="bin every rectangle tile like the reference")
     ap.add_argument("--scatter-bands", type=int, default=0, help="force the scatter launch to N bands of tile rows per chunk (0 = automatic)")
     ap.add_argument("--occlusion", type=int, default=-1, help="occlusion cut-off: -1 automatic (default), 0 off, 1 on")
+    ap.add_argument("--views", type=int, default=1,
+                    help="cameras the TIMED steps rotate through (default 1 = BASELINE's line: one view, static Gaussians); V > 1: a shuffled "
+                         "epoch of V views on a small orbit, the Gaussians perturbed by an optimiser-sized step before every iteration")
+    ap.add_argument("--rotation-views", type=int, default=64,
+                    help="views of the `rotation` block reported beside the headline (training-like view rotation, per-view cache on / off); 0 = skip")
     ap.add_argument("--no-view-cache", action="store_true",
                     help="forward without the per-view walk-depth cache (the mirror's default: every step after the first is a revisit of "
                          "the bench's one view, like every epoch after the first is in training)")
@@ -1151,6 +1210,9 @@ def main():
     sb = SceneBench(dev, P, W, H, multi.scene_seed(seed, rank, world), seed, gsel, args.workload)  # one independent scene per GPU
     step, rs, P = sb.step, sb.rs, sb.P
     means3D, opac, unc, colors, scales, rots = sb.leaves
+    if args.views > 1:  # the timed steps themselves rotate through V views with moving Gaussians (not BASELINE's line: labelled)
+        sb.make_rotation(args.views)
+        step = sb.step_rot
 
     def barrier():
         multi.barrier(dist, dev)
@@ -1234,6 +1296,59 @@ def main():
             step()
         barrier()
 
+    # Training-like view rotation: what the per-view walk depths are worth when a view comes back one epoch later and
+    # the Gaussians have moved in between -- the timed region above revisits ONE static frame, i.e. its recorded depths predict perfectly.
+    rotation = None
+    if args.rotation_views > 1 and args.views <= 1:
+        from gscream_amd import rasterizer as _RZr
+        V = args.rotation_views
+        keep = [x.detach().clone() for x in (means3D, opac)]
+        sb.make_rotation(V)
+
+        def rot_run(view_cache, perturb, epochs=3):
+            apply_tuning(view_cache=view_cache)
+            with torch.no_grad():
+                means3D.copy_(keep[0]); opac.copy_(keep[1])
+            sb.rot["order"], sb.rot["k"] = [], 0
+            for _ in range(V):               # first epoch, untimed: every view seen once (this is what fills the cache)
+                sb.step_rot(perturb)
+            torch.cuda.synchronize()
+            redo, n = 0, epochs * V
+            tb = time.perf_counter()
+            for _ in range(n):
+                sb.step_rot(perturb)
+                redo += 0 if _RZr._last_stage1.get("speculative", True) else 1
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - tb) / n * 1e3
+            _native.profile_begin()
+            for _ in range(V):
+                sb.step_rot(perturb)
+            torch.cuda.synchronize()
+            pr = _native.profile_end()
+            return ms, redo / n, {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in pr.items() if v[1]}
+
+        ms_on, redo_on, st_on = rot_run(not args.no_view_cache, True)
+        ms_off, redo_off, st_off = rot_run(False, True)
+        ms_static, _, st_static = rot_run(not args.no_view_cache, False)
+        with torch.no_grad():
+            means3D.copy_(keep[0]); opac.copy_(keep[1])
+        apply_tuning()
+        for _ in range(3):
+            step()
+        barrier()
+        rotation = {"views": V, "epochs_timed": 3, "ms_per_step": round(ms_on, 4), "ms_per_step_no_view_cache": round(ms_off, 4),
+                    "ms_per_step_static_gaussians": round(ms_static, 4),
+                    "redo_rate": round(redo_on, 4), "redo_rate_no_view_cache": round(redo_off, 4),
+                    "iters_per_s": round(1e3 / ms_on, 1), "iters_per_s_no_view_cache": round(1e3 / ms_off, 1),
+                    "stage_us": st_on, "stage_us_no_view_cache": st_off, "stage_us_static_gaussians": st_static,
+                    "orbit_angle_rad": sb.rot["angle"], "perturbation": {"positions": sb.rot["eps"][0], "opacities": sb.rot["eps"][1]},
+                    "what": f"{V} cameras on a small orbit (yaw / pitch of {sb.rot['angle']} rad about the cloud's centre), popped in a shuffled order epoch "
+                            "after epoch like train.py:414-416; before every iteration the positions move by N(0, 2e-4) scene units (a few hundredths "
+                            "of a pixel) and the opacities by N(0, 1e-3) -- an optimiser-sized step (two elementwise kernels, inside the timed steps of "
+                            "both variants); first epoch untimed (it fills the per-view cache), three epochs timed; redo_rate = forwards whose "
+                            "speculative workspace guess was too small and that were redone (GSR_NEED_CAPACITY); NOT the headline: BASELINE's metric is "
+                            "one view"}
+
     my_elapsed = elapsed
     total_steps, elapsed, rate = multi.aggregate_throughput(dist, args.steps, elapsed, dev)
     # per-rank breakdown for the --gpus N line: every rank's own rate, instance count and host cost per step (median wall time of the
@@ -1293,7 +1408,8 @@ def main():
             "ms_per_step_spread": {"note": "three further blocks of `steps` steps on this rank, timed like the official region (which `value` comes from)",
                                    "blocks_ms": [round(v, 4) for v in spread_ms], "min": round(min(spread_ms), 4), "max": round(max(spread_ms), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,
+            "config": {"workload": desc if args.views <= 1 else desc + f" -- NOT BASELINE's line: the timed steps rotate through {args.views} views with perturbed Gaussians (--views)",
+                       "views": args.views, "P": P, "W": W, "H": H, "num_rendered": R, "num_rendered_reference": R_ref,
                        "visible": visible, "tile_cull": not args.no_tile_cull,
                        "parallelism": f"{world} independent scene(s), one per GPU, barrier only",
                        "collective_backend": None if dist is None else dist.get_backend(),
@@ -1322,6 +1438,7 @@ def main():
                            "ms_per_step_without": None if view_cache_off_ms is None else round(view_cache_off_ms, 4),
                            "ms_per_step_without_note": "median of three blocks of `steps` steps (compare with ms_per_step_spread, timed the same way)",
                            "iters_per_s_without": None if view_cache_off_ms is None else round(1e3 / view_cache_off_ms * world, 3)},
+            "rotation": rotation,
             "stages": stages,
             "per_rank": per_rank,
             "scene_stats": scene_stats(sb),

@@ -354,6 +354,11 @@ def assert_parity_strict(got, st, ref=None, s=None, grads=None, context="", keys
     for k in ("out_color", "out_depth", "out_unc"):
         cap = 5e-3 * max(1.0, float(np.abs(st[k]).max()) if np.asarray(st[k]).size else 1.0)
         assert rep["images"][k]["max"] <= cap, f"{context}/{k}: max abs error {rep['images'][k]['max']:.3e} (cap {cap:.1e})"
+    if "final_T_max_rel_where_same_stop" in rep and not ties:
+        # the forward's exact replay finds every pixel whose stop could differ from the reference's ONLY IF the fast walk's transmittance
+        # stays within GSR_TBAND (1e-4, relative) of the reference chain's (blend.hip, GSR_T_STOP); v_exp / v_rcp errors accumulate with
+        # the number of blends, so the bound is checked on every case here, the walks of thousands of instances included
+        assert rep["final_T_max_rel_where_same_stop"] < 1e-4, f"{context}: fast-walk T drifts {rep['final_T_max_rel_where_same_stop']:.2e} from the oracle's chain (band 1e-4)"
     if "last_contributor_differs" in rep:
         assert rep["last_contributor_differs"]["pixels"] <= ties, f"{context}: walks ending at another Gaussian than the oracle's: {rep['last_contributor_differs']}"
     if ref is not None:
@@ -375,3 +380,4 @@ def assert_parity_strict(got, st, ref=None, s=None, grads=None, context="", keys
     if ties:
         print(f"[classified] {context}: {ties} expf-tie pixel(s): {[p_ for p_ in rep['outlier_pixels'] if p_['expf_tie']]}")
     return rep
+
