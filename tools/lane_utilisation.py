@@ -77,6 +77,7 @@ def main():
     windows = (1, 4, 8, None)
     pair_now, pair_single, pair_after = 0, 0, {w: 0 for w in windows}
     box_iters = box_pixels = box_instances = 0
+    quad_pair_iters = quad_single_iters = half_iters = strip_iters = 0
     seg_len = 64 if gx * gy <= 4096 else 128
     for t in tiles:
         tx, ty = t % gx, t // gx
@@ -122,6 +123,20 @@ def main():
                     pair_after[w] += paired_iterations(seq, w)
                 if lo // seg_len >= 7:
                     break
+        # Round 6: the backward on 8x8 QUADRANTS with TWO INSTANCES per packed iteration -- per (quadrant, depth
+        # segment) the blending instances pair up in list order: ceil(n / 2) iterations of 64 pixels x 2 instances.  And its cousin that
+        # keeps today's lane map: each 8x8 half of a strip walks ITS OWN list (.x = an instance of the left half, .y = one of the right
+        # half, no pixel sees both): max(n_left, n_right) iterations per (strip, segment).
+        for lo in range(0, depth, seg_len):
+            hi = depth if lo // seg_len >= 7 else min(depth, lo + seg_len)
+            qb = blend[lo:hi].reshape(hi - lo, 2, 8, 2, 8).any(axis=(2, 4))           # [n, qy, qx]: blends in that quadrant
+            nq = qb.sum(0)                                                            # [2, 2]
+            quad_pair_iters += int(((nq + 1) // 2).sum())
+            quad_single_iters += int(nq.sum())
+            half_iters += int(nq.max(axis=1).sum())                                   # per strip (qy): max over its two halves
+            strip_iters += int(qb.any(axis=2).sum())                                  # today: instances that blend anywhere in the strip
+            if lo // seg_len >= 7:
+                break
         for k, (bw, bh) in grans.items():
             blk = blend.reshape(depth, 16 // bh, bh, 16 // bw, bw).any(axis=(2, 4))   # [n, by, bx]
             cnt = blk.sum(0)                                                        # list length per block
@@ -136,6 +151,17 @@ def main():
               f"4-block wave iterations per tile {acc[k]['iters4'] / ntiles:8.0f}  (balance {p / 4 / max(acc[k]['iters4'], 1):.2f})")
     print(f"box-mapped lanes ({wl}): {box_instances / ntiles:.0f} blending (instance, tile) pairs per tile, {box_iters / ntiles:.0f} 64-lane iterations per tile "
           f"({box_iters / max(box_instances, 1):.2f} per pair), lane utilisation {box_pixels / max(box_iters * 64, 1):.3f}")
+    # issue cycles per iteration (HISTORY 8's measured cost table applied to the instruction lists in DESIGN 11, round 6):
+    #   today, (instance, 16x8 strip), two pixels per lane:                 head 72 + blend 118 + reduction of 6 partials 106 = 296
+    #   two instances per lane (either variant): per-half dy / operands     head 88 + blend 106 (no cross-pixel adds) + reduction of
+    #   12 partials through one transposing butterfly (12 + 10 masked DPP adds, 4 dy products, 3 + 2 permlane swaps + adds, 4 quad steps, 2 LDS adds) 174 = 368
+    C_NOW, C_PAIR = 296, 368
+    print(f"two instances per packed iteration ({wl}, segments of {seg_len}), blending iterations per tile: today (instance, strip) {strip_iters / ntiles:.0f}; "
+          f"8x8 quadrant pairs {quad_pair_iters / ntiles:.0f} (from {quad_single_iters / ntiles:.0f} (instance, quadrant) units: {quad_single_iters / max(2 * strip_iters, 1):.3f} of today's lanes); "
+          f"own list per 8x8 half {half_iters / ntiles:.0f}")
+    print(f"  modelled issue cycles per tile: today {strip_iters / ntiles * C_NOW:.0f}; quadrant pairs {quad_pair_iters / ntiles * C_PAIR:.0f} "
+          f"({quad_pair_iters * C_PAIR / max(strip_iters * C_NOW, 1):.3f} x); own list per half {half_iters / ntiles * C_PAIR:.0f} "
+          f"({half_iters * C_PAIR / max(strip_iters * C_NOW, 1):.3f} x)   [gate: <= 0.88 x]")
     print(f"opposite-half pairing ({wl}, segments of {seg_len}): blending (instance, strip) iterations per tile {pair_now / ntiles:.0f}, "
           f"{pair_single / max(pair_now, 1):.1%} of them touch one 8x8 half only")
     for w in windows:
