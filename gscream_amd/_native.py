@@ -19,10 +19,10 @@ EXPORTED_SYMBOLS = (
     "gsr_rgb_loss_backward_window",
     "gsr_knn_workspace_bytes", "gsr_knn_mean_dist2", "gsr_decode_count", "gsr_decode_emit", "gsr_decode_backward",
     "gsr_depth_loss_workspace_bytes", "gsr_depth_loss_forward", "gsr_depth_loss_backward", "gsr_training_stats",
-    "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows",
+    "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows", "gsr_adaptive_reset",
 )
 NUM_STAGES = 7
-ABI_VERSION = 6  # include/gsraster.h GSR_ABI_VERSION this binding was written against
+ABI_VERSION = 7  # include/gsraster.h GSR_ABI_VERSION this binding was written against
 
 
 class Stage1Result(ctypes.Structure):
@@ -99,6 +99,9 @@ def load():
         lib.gsr_profile_begin_sampled.argtypes = [ctypes.c_uint, ctypes.c_uint]
     lib.gsr_profile_end.restype = _c_int
     lib.gsr_profile_end.argtypes = [ctypes.POINTER(Profile)]
+    if hasattr(lib, "gsr_adaptive_reset") or not os.environ.get("GSR_SKIP_ABI_CHECK"):
+        lib.gsr_adaptive_reset.restype = None
+        lib.gsr_adaptive_reset.argtypes = []
     lib.gsr_stage_name.restype = ctypes.c_char_p
     lib.gsr_stage_name.argtypes = [_c_int]
     lib.gsr_loss_workspace_bytes.restype = ctypes.c_size_t

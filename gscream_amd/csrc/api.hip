@@ -184,6 +184,10 @@ struct GsrThreadDeviceState {
     hipEvent_t ev[GSR_MAX_DEVICES] = {};
     uint8_t heavy_mode[GSR_MAX_DEVICES] = {};   // per-Gaussian backward: 1 = launch the heavy-group kernel (gsr_heavy_groups_expected)
     uint8_t heavy_probe[GSR_MAX_DEVICES] = {};  // backwards to wait before the heavy kernel is launched again just to count the groups
+    // partial sort of long tile lists, the bet and its feedback (gsr_partial_bet)
+    uint32_t fwd_serial[GSR_MAX_DEVICES] = {};   // forwards of this thread on the device (what a resumed quadrant reports back)
+    uint32_t ranoff_seen[GSR_MAX_DEVICES] = {};  // the last report acted upon
+    uint8_t bet_hold[GSR_MAX_DEVICES] = {};      // forwards left during which lists up to GSR_SORT_CAP_SMALL are sorted completely at once
     ~GsrThreadDeviceState()
     {
         for (int d = 0; d < GSR_MAX_DEVICES; d++) {
@@ -208,6 +212,9 @@ static int gsr_current_device(int* d)
 // trap, 8 = the per-Gaussian backward's report on heavy groups (0 = nothing new, 1 = the one-wave kernel met one, 2 + n = the
 // heavy kernel was given n)
 #define GSR_PINNED_HEAVY_SEEN 8
+// 9 = the forward's fix-up pass: serial number of the last forward in which a quadrant ran off its tile's partially sorted prefix
+#define GSR_PINNED_RANOFF 9
+#define GSR_BET_HOLD 64  // forwards without the partial sort after a lost bet, then one forward probes again
 #define GSR_HEAVY_MIN_GROUPS 192  // fewer heavy groups than this: the one-wave kernel does them itself (gauss_bwd.hip, launcher)
 static int gsr_info_buffer(volatile uint32_t** host, uint32_t** dev)
 {
@@ -237,6 +244,38 @@ static bool gsr_heavy_groups_expected(uint32_t report, uint8_t* mode, uint8_t* p
         else *mode = 1;
     }  // 0, or 1 in heavy mode (the heavy kernel of that call has not reported yet): nothing new
     return *mode != 0;
+}
+
+// Partial sort of long lists -- the bet and its feedback (round 6).  Lists beyond GSR_NEAR_CAP are depth-sorted only as far as the blend is
+// expected to walk (binning.hip); a tile whose pixels are still blending at the end of that prefix is sorted completely and its
+// quadrants resume in a SECOND forward-blend launch.  On frames that saturate the bet wins (large splats: tile sort 133 instead of
+// 239 us).  On the frames of an initialised, untrained scene it loses on every long list -- nothing saturates -- and the second launch is
+// ~140 us of a mostly idle GPU (init-state frame: 18 tiles of 2 049 - 3 238 entries, forward 2 x 169 us).  Which kind of frame a
+// scene produces is a property of its training state, not of the view: a resumed quadrant stores the forward's serial number in a
+// host-mapped word, and after such a report the next GSR_BET_HOLD forwards of this thread on this device sort lists that fit the
+// small LDS class (<= GSR_SORT_CAP_SMALL entries) completely at once -- one launch, no fix-up -- then one forward bets again.  Longer
+// lists always bet: a complete sort of 10 000-entry lists costs more than the fix-up.  Results never depend on any of this (the
+// partial sort is bit-identical to a complete one, tests + tools/fuzz_parity.py).  -> the partial sort is worth betting on
+static bool gsr_partial_bet(int devidx, const volatile uint32_t* pinned, int longest, bool longest_is_a_provision)
+{
+    const uint32_t rep = pinned[GSR_PINNED_RANOFF];
+    if (rep != g_tds.ranoff_seen[devidx]) { g_tds.ranoff_seen[devidx] = rep; g_tds.bet_hold[devidx] = GSR_BET_HOLD; }
+    const bool hold = g_tds.bet_hold[devidx] > 0;
+    if (hold) --g_tds.bet_hold[devidx];
+    // (a speculative caller provisions the longest list with slack over what its last frames had -- gsraster.h: 1.25 x: the call then
+    // sorts completely up to GSR_SORT_CAP_SMALL and treats anything longer like any list beyond its provision: GSR_NEED_CAPACITY)
+    const int limit = longest_is_a_provision ? GSR_SORT_CAP_SMALL + GSR_SORT_CAP_SMALL / 4 + 64 : GSR_SORT_CAP_SMALL;
+    return !(hold && longest > GSR_NEAR_CAP && longest <= limit);
+}
+
+extern "C" void gsr_adaptive_reset(void)
+{
+    // forget what this thread's previous calls taught the launch heuristics (tests, gscream_amd.set_tuning): reports that are
+    // still on their way count as seen
+    for (int d = 0; d < GSR_MAX_DEVICES; d++) {
+        g_tds.bet_hold[d] = 0;
+        if (g_tds.host[d]) g_tds.ranoff_seen[d] = ((volatile uint32_t*)g_tds.host[d])[GSR_PINNED_RANOFF];
+    }
 }
 
 static int gsr_info_event(hipEvent_t* ev)
@@ -358,18 +397,27 @@ static int gsr_enqueue_fixup(int P, int W, int H, int capacity, int max_tile_cou
                              bool inference, GsrWalkHint walk, int debug, hipStream_t stream)
 {
     if (max_tile_count <= GSR_NEAR_CAP) return GSR_OK;
+    // where a resumed quadrant reports the lost bet (gsr_partial_bet)
+    volatile uint32_t* pinned = nullptr;
+    uint32_t* pinned_dev = nullptr;
+    int devidx = 0;
+    int rc0 = gsr_info_buffer(&pinned, &pinned_dev);
+    if (rc0) return rc0;
+    rc0 = gsr_current_device(&devidx);
+    if (rc0) return rc0;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
     const GsrGeom geom = gsr_carve_geom(geom_ws, P);
     const GsrImage image = gsr_carve_image(image_ws, P, W, H);
     const GsrBinning bin = gsr_carve_binning(binning_ws, capacity);
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_sort_fixup(T, capacity, max_tile_count, image, bin, inference, stream), "tile sort (fix-up)");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, true, inference, walk.depths, walk.valid, false, stream),
+                                                            out_feature, capacity, max_tile_count, true, inference, walk.depths, walk.valid, false,
+                                                            pinned_dev + GSR_PINNED_RANOFF, g_tds.fwd_serial[devidx], stream),
               "forward blend (fix-up)");
     return GSR_OK;
 }
 
-static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, bool partial, bool inference, int forced_bands, const float* background,
+static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_count, int partial /* gsr_launch_tile_sort */, bool inference, int forced_bands, const float* background,
                               void* geom_ws, void* image_ws, void* binning_ws, float* out_color, float* out_depth,
                               float* out_feature, GsrWalkHint walk, int debug, hipStream_t stream)
 {
@@ -384,10 +432,10 @@ static int gsr_enqueue_stage2(int P, int W, int H, int capacity, int max_tile_co
     GSR_STAGE(GSR_STAGE_SCATTER, gsr_launch_scatter(P, T, gx, geom, image, bin, capacity, capacity, forced_bands, false, nullptr, inference, false, stream), "scatter");
     GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, capacity, max_tile_count, partial, false, inference, geom, image, bin, stream), "tile sort");
     GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                            out_feature, capacity, max_tile_count, false, inference, walk.depths, walk.valid, false, stream),
+                                                            out_feature, capacity, max_tile_count, false, inference, walk.depths, walk.valid, false, nullptr, 0u, stream),
               "forward blend");
     // longest list known (two-stage form): the fix-up can follow at once; the one-call form enqueues it after the read-back
-    if (partial && max_tile_count >= 0)
+    if (partial == 1 && max_tile_count >= 0)
         return gsr_enqueue_fixup(P, W, H, capacity, max_tile_count, background, geom_ws, image_ws, binning_ws, out_color,
                                  out_depth, out_feature, inference, walk, debug, stream);
     return GSR_OK;
@@ -432,7 +480,24 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
                             cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, geom_ws,
                             image_ws, radii, &info, &info_dev, fold_tile_scan, tuning, &ordered, debug, stream);
     if (rc) return rc;
-    const bool partial = gsr_partial_sort(tuning), inference = gsr_inference(tuning);
+    bool partial = gsr_partial_sort(tuning);
+    int sort_mode = partial ? 1 : 0;
+    const bool inference = gsr_inference(tuning);
+    if (partial) {  // ... unless this thread's recent forwards lost the bet on lists like these (gsr_partial_bet)
+        volatile uint32_t* pinned = nullptr;
+        uint32_t* pinned_dev = nullptr;
+        int devidx = 0;
+        rc = gsr_info_buffer(&pinned, &pinned_dev);
+        if (rc) return rc;
+        rc = gsr_current_device(&devidx);
+        if (rc) return rc;
+        ++g_tds.fwd_serial[devidx];
+        partial = gsr_partial_bet(devidx, pinned, max_tile_count_hint, true);
+        if (!partial) {  // complete sorts, the few long lists in a launch of their own, nothing beyond the small LDS class
+            sort_mode = 2;
+            if (max_tile_count_hint > GSR_SORT_CAP_SMALL) max_tile_count_hint = GSR_SORT_CAP_SMALL;
+        }
+    }
     const GsrWalkHint walk = gsr_walk_hint(tuning);
     // (speculative: the sort variants are chosen from the hint; with partial sorting the hint only sizes the LDS of the
     // lists up to GSR_NEAR_CAP)
@@ -447,10 +512,10 @@ extern "C" int gsr_forward(int P, int D, int M, int W, int H, const float* means
         // (beyond the LDS tile limit stage 1 ran the stand-alone tile scan: the same words, written earlier)
         GSR_HIP(hipEventRecord(ev, stream), "record");
         // partial: lists beyond GSR_NEAR_CAP take the fixed-LDS prefix sort whatever the hint says
-        GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, partial, true, inference, geom, image, bin, stream),
+        GSR_STAGE(GSR_STAGE_TILE_SORT, gsr_launch_tile_sort(T, binning_capacity, hint, sort_mode, true, inference, geom, image, bin, stream),
                   "tile sort");
         GSR_STAGE(GSR_STAGE_BLEND_FWD, gsr_launch_blend_forward(W, H, gx, T, background, geom, image, bin, out_color, out_depth,
-                                                                out_feature, binning_capacity, hint, false, inference, walk.depths, walk.valid, ordered, stream),
+                                                                out_feature, binning_capacity, hint, false, inference, walk.depths, walk.valid, ordered, nullptr, 0u, stream),
                   "forward blend");
     }
     if (rc) return rc;
@@ -481,7 +546,19 @@ extern "C" int gsr_forward_stage2(int P, int W, int H, int R, int max_tile_count
     if (!background || !geom_ws || !image_ws || !binning_ws || !out_color || !out_depth || !out_feature)
         return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "a required pointer is NULL");
     if (R < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "R must be >= 0");
-    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, gsr_partial_sort(tuning), gsr_inference(tuning), gsr_forced_bands(tuning), background, geom_ws, image_ws, binning_ws,
+    bool partial = gsr_partial_sort(tuning);
+    if (partial) {  // (gsr_partial_bet: not when this thread's recent forwards lost the bet on lists like these)
+        volatile uint32_t* pinned = nullptr;
+        uint32_t* pinned_dev = nullptr;
+        int devidx = 0;
+        rc = gsr_info_buffer(&pinned, &pinned_dev);
+        if (rc) return rc;
+        rc = gsr_current_device(&devidx);
+        if (rc) return rc;
+        ++g_tds.fwd_serial[devidx];
+        partial = gsr_partial_bet(devidx, pinned, max_tile_count, false);
+    }
+    return gsr_enqueue_stage2(P, W, H, R, max_tile_count, partial ? 1 : gsr_partial_sort(tuning) ? 2 : 0, gsr_inference(tuning), gsr_forced_bands(tuning), background, geom_ws, image_ws, binning_ws,
                               out_color, out_depth, out_feature, gsr_walk_hint(tuning), debug, stream);
 }
 

@@ -1150,11 +1150,13 @@ hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const G
 // the class limit -- 11 KiB instead of 34 KiB on the bench scene, twice the resident workgroups.
 static hipError_t gsr_launch_full_sorts(int T, int capacity, uint32_t lo0, uint32_t max_tile_count, const GsrImage& image,
                                         const GsrBinning& bin_in, const uint32_t* only_flagged, uint32_t* sorted_len,
-                                        bool inference, hipStream_t stream)
+                                        bool inference, hipStream_t stream, bool split_at_near_cap = false)
 {
     GsrBinning bin = bin_in;
     if (inference) bin.slot_written = nullptr;  // the written-slot flags belong to the backward
-    const uint32_t caps[] = { (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)GSR_SORT_CAP_LARGE };
+    // split_at_near_cap (the partial sort's bet is off, api.hip gsr_partial_bet): the many lists up to GSR_NEAR_CAP keep their 256-thread
+    // kernel and only the few longer ones take the 1024-thread one (one class for both gives every 400-entry list 1024 threads)
+    const uint32_t caps[] = { split_at_near_cap ? (uint32_t)GSR_NEAR_CAP : 0u, (uint32_t)GSR_SORT_CAP_SMALL, (uint32_t)GSR_SORT_CAP_LARGE };
     uint32_t lo = lo0;
     for (uint32_t cap : caps) {
         if (cap > lo && max_tile_count > lo) {
@@ -1180,7 +1182,8 @@ static hipError_t gsr_launch_full_sorts(int T, int capacity, uint32_t lo0, uint3
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, bool inference, const GsrGeom& geom,
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, int partial /* 0 = complete sorts, 1 = long lists bet on a sorted
+                                prefix, 2 = complete sorts, lists beyond GSR_NEAR_CAP in a launch of their own */, bool speculative, bool inference, const GsrGeom& geom,
                                 const GsrImage& image, const GsrBinning& bin_in, hipStream_t stream)
 {
     (void)geom;
@@ -1190,7 +1193,7 @@ hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool pa
     // caller's guess (it sizes the LDS; the host checks it against the truth afterwards)
     if (capacity <= 0) return hipSuccess;
     const uint32_t mx = max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count;
-    if (!partial) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, inference, stream);
+    if (partial != 1) return gsr_launch_full_sorts(T, capacity, 0u, mx, image, bin, nullptr, nullptr, inference, stream, partial == 2 && mx > GSR_NEAR_CAP);
     // lists up to GSR_NEAR_CAP: full sort in LDS; longer ones: sorted prefix only (gsr_tile_sort_near_kernel)
     // (a guess below the cap that turns out too small fails the host's check anyway and stage 2 is redone)
     // (round 4 measured the alternative for frames whose longest list is in (2048, 4096] -- complete sorts, 256-thread kernel for the

@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     uint32_t* __restrict__ tile_work, float* __restrict__ ckpt, int seg_len, uint32_t capacity, uint32_t longest_sorted,
     const uint32_t* __restrict__ sorted_len, uint32_t* __restrict__ need_full, const uint32_t* __restrict__ only_flagged,
     uint32_t* __restrict__ qresume, uint32_t* __restrict__ deep_walks /* info[3]: quadrant waves that entered the second tier */,
-    const uint32_t* __restrict__ qorder /* dispatch order of the XCDs' task slots, or NULL */, uint32_t* __restrict__ walk_out /* gsr_tuning.walk_depths or NULL */)
+    const uint32_t* __restrict__ qorder /* dispatch order of the XCDs' task slots, or NULL */, uint32_t* __restrict__ walk_out /* gsr_tuning.walk_depths or NULL */,
+    uint32_t* __restrict__ ranoff_report /* host-mapped word (fix-up pass only, may be NULL): a resumed quadrant stores `serial` */, uint32_t serial)
 {
     __shared__ float4 sPair[GSR_FWB / 2][4];
     __shared__ float4 sC[GSR_FWB];
@@ -393,6 +394,9 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
     if (only_flagged) {
         start = (int)qresume[u];
         if (start == 0) return;  // wave-uniform
+        // the partial sort lost its bet on this tile: tell the host which forward it was (api.hip, gsr_partial_bet: the next calls sort
+        // lists of this length completely at once and spare themselves this whole second launch); every resumed wave stores the same word
+        if (lane == 0 && ranoff_report) *ranoff_report = serial;
         bool stopped = !inside;
         if (inside) {
             const uint32_t nc = n_contrib[pid];
@@ -1221,7 +1225,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
                                     float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference,
-                                    uint32_t* walk_depths, bool walk_depths_valid, bool already_ordered, hipStream_t stream)
+                                    uint32_t* walk_depths, bool walk_depths_valid, bool already_ordered, uint32_t* ranoff_report, uint32_t serial,
+                                    hipStream_t stream)
 {
     if (T <= 0) return hipSuccess;
     // per-view walk depths: order the tasks by the previous visit's (not in the fix-up pass: a few flagged tiles), record this visit's
@@ -1237,7 +1242,7 @@ hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg
                        gx, T, bg, out_color, out_depth, out_feature, image.final_T, image.n_contrib, image.tile_work, image.ckpt,     \
                        gsr_seg_len(T), (uint32_t)capacity, max_tile_count < 0 ? 0x7fffffffu : (uint32_t)max_tile_count,               \
                        image.sorted_len, image.need_full, only_flagged ? image.need_full : (const uint32_t*)nullptr, image.qresume, image.info + 3,        \
-                       qorder, walk_depths)
+                       qorder, walk_depths, only_flagged ? ranoff_report : (uint32_t*)nullptr, serial)
     if (inference) GSR_FWD_LAUNCH(false);
     else GSR_FWD_LAUNCH(true);
 #undef GSR_FWD_LAUNCH

@@ -326,12 +326,13 @@ int gsr_scatter_bands(int P, int T, int gx, int expected_instances, int forced);
 hipError_t gsr_launch_scatter(int P, int T, int gx, const GsrGeom& geom, const GsrImage& image, const GsrBinning& bin,
                               int capacity, int expected_instances, int forced_bands, bool fused_tile_scan, uint32_t* fused_info_host, bool inference,
                               bool occlusion_cut, hipStream_t stream);
-hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, bool partial, bool speculative, bool inference, const GsrGeom& geom, const GsrImage& image,
+hipError_t gsr_launch_tile_sort(int T, int capacity, int max_tile_count, int partial /* 0 complete, 1 prefix bet, 2 complete with the long lists apart */, bool speculative, bool inference, const GsrGeom& geom, const GsrImage& image,
                                 const GsrBinning& bin, hipStream_t stream);
 hipError_t gsr_launch_blend_forward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,
                                     const GsrImage& image, const GsrBinning& bin, float* out_color, float* out_depth,
                                     float* out_feature, int capacity, int max_tile_count, bool only_flagged, bool inference,
-                                    uint32_t* walk_depths, bool walk_depths_valid, bool already_ordered, hipStream_t stream);
+                                    uint32_t* walk_depths, bool walk_depths_valid, bool already_ordered, uint32_t* ranoff_report /* fix-up pass: host-mapped word */,
+                                    uint32_t serial, hipStream_t stream);
 hipError_t gsr_launch_sort_fixup(int T, int capacity, int max_tile_count, const GsrImage& image, const GsrBinning& bin,
                                  bool inference, hipStream_t stream);
 hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* bg, const GsrGeom& geom,

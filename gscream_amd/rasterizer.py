@@ -130,6 +130,9 @@ def set_tuning(tile_cull=True, speculative=True, partial_sort=True, scatter_band
             c.clear()
     _occlusion_mode[0] = occlusion_cut
     _occlusion_state.clear()
+    lib = _native._lib  # (the library's own feedback heuristics start over too: the partial sort's bet, gsraster.h gsr_adaptive_reset)
+    if lib is not None and hasattr(lib, "gsr_adaptive_reset"):
+        lib.gsr_adaptive_reset()
     _sync_tuning_variants()
     _capacity_hint.clear()
     _recent.clear()

@@ -108,9 +108,15 @@ typedef struct gsr_profile {
 const char* gsr_version(void);
 /* Integer version of this header's binary interface: bumped whenever an entry point's argument list, a struct layout or a
  * workspace size formula changes incompatibly.  Bindings compare it with GSR_ABI_VERSION at load time. */
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
+/* Forget what the calling thread's previous calls taught the launch heuristics that learn from feedback (ABI 7): today the partial
+ * sort's bet -- after a forward in which a quadrant ran off its tile's partially sorted prefix, the next 64 forwards sort lists of up to
+ * 4096 entries completely at once instead of paying a second forward-blend launch (api.hip gsr_partial_bet; no counterpart in the
+ * reference, which always sorts everything: rasterizer_impl.cu:300-320).  Results never depend on these heuristics; tests and
+ * benchmarks that compare launch patterns call this between cases (gscream_amd.set_tuning does). */
+void gsr_adaptive_reset(void);
 /* Number of visible HIP devices, or a negative gsr_status. */
 int gsr_device_count(void);
 

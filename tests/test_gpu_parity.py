@@ -243,6 +243,53 @@ def test_partial_sort_of_long_lists(scale_mul, expect_fixup):
     Hh.assert_parity_strict(Hh.hip_run(s, grads), st, ref, s, grads, context=f"partial sort, scales x{scale_mul}", nthreads=NT)
 
 
+def test_partial_sort_bet_is_dropped_after_it_was_lost():
+    """Round 6 (api.hip gsr_partial_bet): on a frame where nothing saturates every long list loses the partial sort's bet -- its tile is
+    sorted a second time and its quadrants resume in a second forward-blend launch.  A resumed quadrant reports the forward's serial
+    number through a host-mapped word; the thread's next forwards then sort lists of up to 4096 entries completely at once (no flagged
+    tile, no resumed quadrant), with the same bits; gsr_adaptive_reset (set_tuning) makes the next forward bet again."""
+    import torch
+    from gscream_amd import rasterizer as RZ
+    s = S.scene_config1(seed=33, P=7_000, W=32, H=32, lateral=0.3)
+    s["scales"] *= np.float32(0.15)                       # small faint splats: most pixels never saturate
+    st = Hh.oracle_forward(s)
+    counts = (st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0])
+    assert 2048 < counts.max() <= 4096 and (counts > 2048).sum() >= 2, counts.max()
+    P, W, H = s["means3D"].shape[0], s["W"], s["H"]
+
+    def run():
+        got = Hh.hip_run(s, keep_state=True)
+        iv = _layout.image_views(got["img"], P, W, H)
+        torch.cuda.synchronize()                          # (the report of this forward has landed)
+        return got, iv["need_full"].cpu().numpy().astype(bool), iv["sorted_len"].cpu().numpy().astype(np.int64)
+
+    set_tuning(tile_cull=False)                           # the oracle's lists; resets the library's feedback state
+    a, flagged_a, _ = run()                               # two-stage (no capacity history yet): bets, loses
+    assert flagged_a[counts > 2048].any(), "the scene must lose the bet"
+    b, flagged_b, slen_b = run()                          # speculative, bet off: complete sorts at once
+    assert RZ._last_stage1["speculative"] is True
+    assert not flagged_b.any() and (slen_b == counts).all(), (int(flagged_b.sum()), int((slen_b != counts).sum()))
+    c, flagged_c, slen_c = run()
+    assert not flagged_c.any() and (slen_c == counts).all()
+    for k in ("out_color", "out_depth", "out_unc", "radii"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    Hh.assert_parity_strict(b, st, context="bet off: images", nthreads=NT)
+    RZ._native.load().gsr_adaptive_reset()                # (what set_tuning does, without clearing the capacity history)
+    d, flagged_d, _ = run()
+    assert RZ._last_stage1["speculative"] is True and flagged_d[counts > 2048].any(), "after a reset the next forward bets again"
+    for k in ("out_color", "out_depth", "out_unc", "radii"):
+        assert np.array_equal(a[k], d[k]), k
+    # gradients: bet on vs bet off, same bits
+    grads = S.upstream_grads(9, W, H)
+    set_tuning(tile_cull=False)
+    g_on = Hh.hip_run(s, grads)
+    torch.cuda.synchronize()
+    g_off = Hh.hip_run(s, grads)
+    for k in Hh.GRAD_KEYS:
+        if k in g_on:
+            assert np.array_equal(g_on[k], g_off[k]), k
+
+
 def test_speculative_hint_exactly_at_the_partial_sort_cap():
     """A caller of the C ABI may pass max_tile_count_hint == GSR_NEAR_CAP (2048) while a real list is longer: the prefix-sort
     kernel is only launched for provisions > 2048, so the call must come back as NEED_CAPACITY and be redone, never

@@ -33,7 +33,7 @@ def test_tuning_struct_layout_and_the_inference_twin():
     import ctypes
     from gscream_amd import _native, rasterizer as RZ
     assert ctypes.sizeof(_native.Tuning) == 40 and _native.Tuning.inference.offset == 12
-    assert _native.Tuning.walk_depths_valid.offset == 28 and _native.Tuning.walk_depths.offset == 32 and _native.ABI_VERSION == 6
+    assert _native.Tuning.walk_depths_valid.offset == 28 and _native.Tuning.walk_depths.offset == 32 and _native.ABI_VERSION == 7
     RZ.set_tuning(tile_cull=False, partial_sort=False)
     try:
         assert RZ._tuning_variants[(1, 0)].inference == 1 and RZ._tuning.inference == 0 and RZ._tuning_variants[(0, 1)].occlusion_cut == 1
