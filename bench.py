@@ -644,6 +644,16 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
     host.sort()
     host_ms = host[len(host) // 2] * 1e3  # median call
     kms, top = gpu_kernel_ms(step, 5)
+    if os.environ.get("GSR_TI_HOST_PROFILE"):  # diagnostic: where the Python call's time goes (cProfile over 200 iterations -> stderr)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(45)
     # SURVEY 8(d)-style algorithmic bytes of the iteration: the rasterizer's 420 P + 304 R + 56 N at this scene's P and R, the
     # decode (per visible anchor 41 + 3K floats in, per emitted Gaussian 15 floats out; the same again, mirrored, in the backward),
     # the RGB loss (44 B per pixel-channel + the weight map) and the depth loss (5 planes in + 1 out, forward and backward)
@@ -955,7 +965,6 @@ class SceneBench:
         self.g = [t(g) for g in (upstream if upstream is not None else S.upstream_grads(grad_seed, W, H, *gsel))]  # resident, zeros where unused
         self.gsel, self.inputs = gsel, self.leaves + [self.means2D]
         self.P, self.W, self.H = P, W, H
-        self._cam = (float(s["tanfovx"]), float(s["tanfovy"]), np.linalg.inv(np.asarray(s["viewmatrix"], np.float64).T), t(s["bg"]))
         self._t = t
         self.rot = None
 
@@ -969,7 +978,8 @@ class SceneBench:
         sign, so the cloud random-walks around where it started) -- a revisit never sees the lists it recorded."""
         from gscream_amd import GaussianRasterizer
         from gscream_amd import synthetic as S
-        tfx, tfy, c2w0, bg = self._cam
+        tfx, tfy = float(self.rs.tanfovx), float(self.rs.tanfovy)
+        c2w0 = np.linalg.inv(self.rs.viewmatrix.detach().double().cpu().numpy().T)  # (the settings hold W2C^T)
         centre = self.leaves[0].detach().double().mean(0).cpu().numpy()
         rasts = []
         for i in range(V):

@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
         }
     }
     double acc[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // the per-tile partials are summed in double, rounded once
+    uint32_t any_written = 0;                              // (wave-uniform) some slot of the group was written
     // Waves that hold a Gaussian with more than 24 slots spread the summation over the lanes as (Gaussian, field) tasks
     // instead of letting that Gaussian's lane walk all its slots 11 fields at a time while 63 lanes wait: 11 consecutive
     // lanes share a Gaussian, each sums one field in the same ascending order (so both schemes give the same bits).
@@ -389,6 +390,7 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
         if (lo < nf) ci0 = gbase[lo >> 6] + (uint32_t)__popcll(gmask[lo >> 6] & ((1ull << (lo & 63)) - 1ull));
         if (hi < nf) ci1 = gbase[hi >> 6] + (uint32_t)__popcll(gmask[hi >> 6] & ((1ull << (hi & 63)) - 1ull));
 #endif
+        any_written |= run;
         for (uint32_t w0 = 0; w0 < run; w0 += WCH) {
             const uint32_t nw = min(run - w0, (uint32_t)WCH);
             float4 v[WCH * 3 / 64];
@@ -432,7 +434,12 @@ __global__ void __launch_bounds__(64, GSR_K7_WAVES) gsr_gauss_bwd_kernel(const G
         for (int v = 0; v < 11; v++) acc[v] = accG[lane * 11 + v];
     }
     if (!live) return;
-    gsr_gauss_finish(A, idx, vis, acc, m, sc, q);
+    // A group none of whose slots was written (wave-uniform: every Gaussian of it culled, or behind the depth its tiles are walked to):
+    // all eleven sums of all its lanes are zero and every row is an exact zero -- the second half is skipped.  (Round 6: in storage order
+    // a trained scene keeps the offsets of an anchor, and mostly neighbouring anchors, next to each other, so whole groups are hidden
+    // together; the synthetic bench cloud is stored in random order and has no such group: see DESIGN 11 for the compaction
+    // experiments that tried to get the same saving there.)
+    gsr_gauss_finish(A, idx, vis && any_written != 0u, acc, m, sc, q);
 }
 
 // HEAVY groups (more than GSR_K7_HEAVY_SLOTS gradient slots: a splat can cover thousands of tiles): four wavefronts per group.  A lone wave has ~6 KB of slot data in flight per memory round trip and walks a dense range of
