@@ -305,8 +305,13 @@ __device__ __forceinline__ float2* gsr_ckpt_b(float* ckpt, int k, size_t HW) { r
 __device__ __forceinline__ const float4* gsr_ckpt_a(const float* ckpt, int k, size_t HW) { return reinterpret_cast<const float4*>(ckpt + (size_t)k * 6 * gsr_ckpt_stride(HW)); }
 __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, size_t HW) { return reinterpret_cast<const float2*>(ckpt + ((size_t)k * 6 + 4) * gsr_ckpt_stride(HW)); }
 
+// Waves per SIMD the forward's register allocation is held to.  Round 6: 7 (72 VGPRs + one 8-byte spill that is reloaded once per
+// 64-instance batch) instead of the 74 registers = 6 waves the allocator settles on by itself: 7 168 instead of 6 144 resident quadrant
+// waves of the launch's ~9 000 -- fewer late starters.  Same-box A/B (profiles/r06_waves_per_simd_ab.txt), forward blend us: config 2 without
+// the per-view order 104.5 -> 100.2, with it 93.5 -> 93.2; config 4 207 -> 200; init-state 277 -> 268-276; 8 waves (64 VGPRs, 40 B of
+// scratch) loses everywhere.  0 = no constraint.
 #ifndef GSR_FWD_WAVES
-#define GSR_FWD_WAVES 0
+#define GSR_FWD_WAVES 7
 #endif
 #if GSR_FWD_WAVES > 0
 #define GSR_FWD_ATTR __attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES)))
@@ -807,8 +812,13 @@ __device__ __forceinline__ int gsr_compact2(const uint32_t* sQ, uint16_t* list, 
     return n;
 }
 
+// Waves per SIMD of the backward (64-entry form).  Round 6: 6 (80 VGPRs; the RGB-only variant without a spill, the AUX variant with four
+// dwords spilled in its prologue) instead of 5 (90 / 98 VGPRs): the kernel is VALU-issue-bound at ~77 % of the issue slots, and a sixth
+// wave per SIMD fills some of the rest -- backward blend us, same box: config 2 152 -> 147-150, config 3 172 -> 168.5, config 4 386 ->
+// 372-378, init-state 343 -> 332, `surfaces` 158 -> 153 (profiles/r06_waves_per_simd_ab.txt).  7 (72 VGPRs, 24 / 52 B of scratch): config 2
+// the same, config 3 +9 us.  (Rounds 2-4 had measured 6 as a loss on the kernels of their time.)
 #ifndef GSR_BWD_WAVES
-#define GSR_BWD_WAVES 5
+#define GSR_BWD_WAVES 6
 #endif
 // SL = the launch's segment length (64 up to 4096 tiles, 128 beyond): sizes the LDS arrays.
 template <bool AUX, int SL>

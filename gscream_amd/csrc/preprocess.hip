@@ -47,8 +47,16 @@ __device__ __forceinline__ float3 gsr_sh_to_rgb(int idx, int deg, int M, float3 
 }
 
 // MODE 0: full preprocess (writes the geometry state)   MODE 1: radii only   MODE 2: radii + px/py
+#ifndef GSR_PRE_WAVES
+#define GSR_PRE_WAVES 0  // waves per SIMD the register allocation is held to (0 = the allocator's own choice: 76 VGPRs = 6 waves)
+#endif
+#if GSR_PRE_WAVES > 0
+#define GSR_PRE_ATTR __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAVES, GSR_PRE_WAVES)))
+#else
+#define GSR_PRE_ATTR
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256) gsr_preprocess_kernel(
+__global__ void __launch_bounds__(256) GSR_PRE_ATTR gsr_preprocess_kernel(
     int P, int D, int M, int tile_cull, const GsrCam cam, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ features,
     const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
