@@ -11,4 +11,4 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench.err | t
 for wl in config2 config3 config4; do bash tools/snapshot.sh r06_$wl $wl > $OUT/snap_$wl.log 2>&1; done
 for wl in init_state surfaces; do timeout 900 python bench.py --workload $wl 2> $OUT/bench_$wl.err | tail -1 > $OUT/bench_$wl.json; done
 for wl in config2 config3 config4 init_state; do timeout 300 python tools/bwd_traffic_model.py $wl 2>/dev/null | tail -1 > $OUT/traffic_$wl.json; done
-tail -3 $OUT/pytest.txt $OUT/smoke.txt
+tail -n 3 $OUT/pytest.txt; tail -n 3 $OUT/smoke.txt
