@@ -251,7 +251,11 @@ def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_or
         # pixels whose walk ended at another Gaussian than the oracle's: a flipped T = 1e-4 stop (or a flipped alpha test of the last instance)
         ref_last = last_gaussian(st["ranges"], st["point_list"], st["n_contrib"], W, H)
         diff = got["last_gid"] != ref_last
-        out["last_contributor_differs"] = {"pixels": int(diff.sum()), "near_T_stop": int((diff & near_t).sum()), "near_alpha": int((diff & near_a & ~near_t).sum())}
+        # ... of which the ORACLE's own stop test came within an ulp-sized margin (1e-6 relative) of T = 1e-4: which side test_T falls on
+        # then depends on the last bit of an expf upstream (glibc in the oracle, ocml on the GPU; the parity build flips the same pixels) --
+        # the T-stop twin of the alpha expf tie
+        out["last_contributor_differs"] = {"pixels": int(diff.sum()), "near_T_stop": int((diff & near_t).sum()), "near_alpha": int((diff & near_a & ~near_t).sum()),
+                                           "expf_tie_at_the_T_stop": int((diff & (mg["m_T"] < 1e-6)).sum())}
         ft, rt = got["final_T"].astype(np.float64), st["final_T"].astype(np.float64)
         same = ~diff & (rt > 0)
         out["final_T_max_rel_where_same_stop"] = float((np.abs(ft[same] - rt[same]) / rt[same]).max()) if same.any() else 0.0
@@ -341,7 +345,8 @@ def assert_parity_strict(got, st, ref=None, s=None, grads=None, context="", keys
     alpha guard band and the T = 1e-4 replay):
       * a pixel may differ from the oracle by more than 1e-4 only if the ORACLE's own walk of it holds a pair within 1e-6 (relative)
         of alpha = 1/255 -- an expf tie, settled by the libm (glibc in the oracle, ocml on the GPU, CUDA's in the reference);
-      * no pixel's walk may end at another Gaussian than the oracle's, ties apart;
+      * no pixel's walk may end at another Gaussian than the oracle's, ties apart (alpha ties, and pixels whose stop test in the oracle
+        lies within 1e-6 (relative) of T = 1e-4: the same expf tie on the other decision);
       * a gradient element may differ by more than 1e-3 (rel; |ref| + 1e-3 max|ref|) only if our value lies inside the range the
         reference algorithm's own unordered fp32 atomicAdd sums span (oracle.backward_envelope, 256 random orders), or its Gaussian
         is blended by a tie pixel; every such element is examined, none is waved through.
@@ -360,7 +365,11 @@ def assert_parity_strict(got, st, ref=None, s=None, grads=None, context="", keys
         # the number of blends, so the bound is checked on every case here, the walks of thousands of instances included
         assert rep["final_T_max_rel_where_same_stop"] < 1e-4, f"{context}: fast-walk T drifts {rep['final_T_max_rel_where_same_stop']:.2e} from the oracle's chain (band 1e-4)"
     if "last_contributor_differs" in rep:
-        assert rep["last_contributor_differs"]["pixels"] <= ties, f"{context}: walks ending at another Gaussian than the oracle's: {rep['last_contributor_differs']}"
+        lc = rep["last_contributor_differs"]
+        if lc["pixels"]:
+            print(f"[classified] {context}: walks ending at another Gaussian than the oracle's: {lc}")
+        assert lc["pixels"] <= ties + lc["expf_tie_at_the_T_stop"] and lc["expf_tie_at_the_T_stop"] <= max_ties, \
+            f"{context}: walks ending at another Gaussian than the oracle's: {lc}"
     if ref is not None:
         nb = rep["grad_elems_gt_1e-3"]
         if nb:

@@ -299,7 +299,7 @@ def test_full_size_element_wise_parity(seed, P, W, H, use, build):
         assert v["max"] < 5e-3, (k, v)
     for k, v in r["grads"].items():
         assert v["n_bad"] <= PRECISE_MAX_GRAD_ELEMS and v["p999"] <= 1e-4, (k, v)
-    assert pc["last_contributor_differs"]["pixels"] <= (0 if build == "shipped" else 1) + ties, pc["last_contributor_differs"]
+    assert pc["last_contributor_differs"]["pixels"] <= (0 if build == "shipped" else 1) + ties + pc["last_contributor_differs"].get("expf_tie_at_the_T_stop", 0), pc["last_contributor_differs"]
     env = pc.get("order_noise_envelope")
     if env:
         print(f"[{build}] order-noise envelope: {env['elements_inside']} of {env['elements_inside'] + env['elements_outside']} elements beyond 1e-3 lie inside the "
