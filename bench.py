@@ -699,6 +699,17 @@ def train_iteration_row(dev, W=1008, H=567, N=200_000, K=10, log_scale_shift=0.0
             "log_scale_shift": float(log_scale_shift), "num_rendered": _last_num_rendered(), "num_occluded": _last_num_occluded()}
 
 
+def fit_row(dev, W, H, iters=200):
+    """End to end under a real optimiser (gscream_amd/fit.py): train.py's iteration with the reference's Adam groups on the init-state
+    model against 16 views of a synthetic teacher scene -- does the loss fall, how long does an iteration INCLUDING the optimiser step take."""
+    from gscream_amd import fit as F
+    _s, info = F.scene_fitted(1, W, H, iters=iters, device=dev, return_info=True)
+    return {"what": f"{iters} iterations of train.py's loop (prefilter -> decode -> rasterize @ {W}x{H} -> RGB + depth loss -> backward -> training_statis -> "
+                    "torch.optim.Adam step, reference parameter groups / learning rates) on the init-state model against 16 views of a synthetic teacher "
+                    "scene; PSNR of the reference view before / after (eval mode)",
+            **{k: (round(v, 4) if isinstance(v, float) else ([round(x, 5) for x in v] if isinstance(v, list) else v)) for k, v in info.items()}}
+
+
 def render_fps_row(dev, sb, N=200_000, K=10):
     """The reference's OTHER timing: render FPS of the evaluation loops (train.py:756-763 per-view timing inside render_set,
     :861-878 spiral / train / test FPS = 1 / mean latency): `prefilter_position2D` + `render` under torch.no_grad() with the
@@ -1500,6 +1511,7 @@ def main():
                     # N(0, 3) anchors / N(-2, 0.3) log-scales are arbitrary; this cloud and its scales follow create_from_pcd)
                     ("train_iteration_init_state", lambda: train_iteration_row(dev, model_kind="init_state")),
                     ("render_fps", lambda: render_fps_row(dev, sb)),
+                    ("fit_run", lambda: fit_row(dev, W, H)),
                     ("simple_knn", lambda: knn_row(dev, not args.no_cpu_baseline)))
             out["next_rows"] = {}
             for name, fn in rows:  # the 8(f) rows, reported beside the north-star line; never allowed to break it
