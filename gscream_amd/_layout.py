@@ -3,12 +3,16 @@ decodes the opaque geom / image / binning byte tensors the forward returns."""
 import torch
 
 
-SEG1, SEG2 = 7, 8        # GSR_SEG1, GSR_SEG2 (gsr_common.h): two tiers of depth segments
+import os
+
+SEG1, SEG2 = 7, int(os.environ.get("GSR_SEG2", "16"))  # GSR_SEG1, GSR_SEG2 (gsr_common.h): three tiers of depth segments (the env knob: A/B against a library built with another -DGSR_SEG2)
 SEG_MAX = SEG1 + SEG2    # GSR_SEG_MAX: segments per tile = checkpoint slots (SEG_MAX - 1 checkpoints + the "last" slot)
 CKPT_PLANES = SEG_MAX * 6
 
 
-SEG2_ENDS = (8, 10, 13, 17, 23, 31, 43)   # ends of the second tier's segments in units of L (lengths 1, 2, 3, 4, 6, 8, 12; gsr_common.h)
+# ends of the second tier's segments in units of L (lengths 1, 2, 3, 4, 6, 8, 12), then the third tier's (16 each; gsr_common.h)
+SEG3_LEN = int(os.environ.get("GSR_SEG3_LEN", "16"))
+SEG2_ENDS = (8, 10, 13, 17, 23, 31, 43) + tuple(43 + SEG3_LEN * j for j in range(1, 64))
 
 
 def seg2_len(n, L):

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "gsr_decode_weight_grad_workspace_bytes", "gsr_decode_zero_hidden_rows", "gsr_decode_visible_rows", "gsr_adaptive_reset",
 )
 NUM_STAGES = 7
-ABI_VERSION = 7  # include/gsraster.h GSR_ABI_VERSION this binding was written against
+ABI_VERSION = 8  # include/gsraster.h GSR_ABI_VERSION this binding was written against
 
 
 class Stage1Result(ctypes.Structure):

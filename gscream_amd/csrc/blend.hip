@@ -39,6 +39,7 @@
 //     resident from the start, so a launch lasts as long as its most loaded SIMD.  Hence independent quadrant waves in
 //     the forward and uniform depth-segment tasks, several per wavefront slot, in the backward.
 #include <stdlib.h>
+#include <algorithm>
 #include "gsr_math.h"
 
 // Fast-math knobs of the blend inner loops.  Default: exp via v_exp_f32 (the records hold the quadratic form
@@ -298,7 +299,7 @@ __device__ __forceinline__ gsr_f2 gsr_splat(float v) { gsr_f2 r = {v, v}; return
 __device__ __forceinline__ gsr_f2 gsr_fma2(gsr_f2 a, gsr_f2 b, gsr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // Checkpoint planes (gsr_common.h): slot k of a pixel = float4 {T_k (last slot: checkpoints passed), r, g, b} + float2
-// {depth, feature}; slot k < GSR_SEG_MAX-1 belongs to list position gsr_ckpt_pos(k) (two tiers, gsr_common.h), the last one to the end.
+// {depth, feature}; slot k < GSR_SEG_MAX-1 belongs to list position gsr_ckpt_pos(k) (three tiers, gsr_common.h), the last one to the end.
 __device__ __forceinline__ size_t gsr_ckpt_stride(size_t HW) { return (HW + 3) & ~(size_t)3; }  // keeps the float4 slots aligned
 __device__ __forceinline__ float4* gsr_ckpt_a(float* ckpt, int k, size_t HW) { return reinterpret_cast<float4*>(ckpt + (size_t)k * 6 * gsr_ckpt_stride(HW)); }
 __device__ __forceinline__ float2* gsr_ckpt_b(float* ckpt, int k, size_t HW) { return reinterpret_cast<float2*>(ckpt + ((size_t)k * 6 + 4) * gsr_ckpt_stride(HW)); }
@@ -1266,10 +1267,10 @@ hipError_t gsr_launch_blend_backward(int W, int H, int gx, int T, const float* b
 {
     if (T <= 0) return hipSuccess;
     float4* s4 = reinterpret_cast<float4*>(slots);
-    // the grid covers `nseg` segments of every tile; workgroups of segments a tile does not have leave at once.  No list of the frame
-    // reaches into the second tier (longest list <= GSR_SEG1 segments): the grid stops at the first tier, as before it existed
+    // the grid covers `nseg` segments of every tile -- as many as the frame's longest list has (round 6; rounds 4-5: all of them as soon
+    // as one list reached the second tier) --; workgroups of segments a tile does not have leave at once
     const int sl = gsr_seg_len(T);
-    const int nseg = (max_tile_count >= 0 && max_tile_count <= GSR_SEG1 * sl) ? GSR_SEG1 + 1 : GSR_SEG_MAX;
+    const int nseg = std::max(GSR_SEG1 + 1, gsr_segments_for(max_tile_count, sl));
     const dim3 grid(8u * (uint32_t)gsr_xcd_tiles(T) * (uint32_t)nseg);
 #define GSR_BWD_LAUNCH(A, SLEN, GD, GF)                                                                                          \
     hipLaunchKernelGGL((gsr_blend_bwd_kernel<A, SLEN>), grid, dim3(128), 0, stream, image.ranges, bin.point_list, geom.rec, W, H, \

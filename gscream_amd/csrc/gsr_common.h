@@ -123,7 +123,7 @@ __device__ __forceinline__ void gsr_fwd_order_block(int x, int T, int xt, const 
 }
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
-// Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in TWO TIERS (round 5):
+// Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in THREE TIERS (rounds 5, 6):
 //   tier 1: GSR_SEG1 segments of the launch's segment length L (64 / 128) -- the fine cut the bench-like frames live in (their
 //           pixels saturate within a few hundred instances);
 //   tier 2: GSR_SEG2 segments of GROWING length behind GSR_SEG1 * L -- 1, 2, 3, 4, 6, 8, 12 x L, then whatever is left (with L = 64:
@@ -134,9 +134,16 @@ __device__ __forceinline__ void gsr_fwd_order_block(int x, int T, int xt, const 
 //           parts of a length chosen from the tile's list length, and the occlusion cut-off -- which only removes instances behind
 //           everything that blends -- then moved the boundaries, i.e. changed how the forward's segment sums associate: images and
 //           gradients differed in the last bit with the knob (tools/fuzz_parity.py, case 5049).
+//   tier 3 (round 6): GSR_SEG2 - 7 more segments of 16 x L each behind position 43 L (with L = 64: boundaries every 1 024 positions from
+//           2 752 to 10 944), then whatever is left.  Tier 2 ended at 43 L: a frame early in an optimisation run (gscream_amd/fit.py, the
+//           init-state model after 25 - 400 steps) has tiles walked 4 000 - 6 000 deep, and the ONE task behind position 2 752 -- up to
+//           3 300 instances on one workgroup -- was the backward blend (898 us of a 1.61 ms frame after 25 steps, 380 of 907 after 400).
 #define GSR_SEG1 7
+#ifndef GSR_SEG3_LEN
+#define GSR_SEG3_LEN 16  // length of a third-tier segment in units of L
+#endif
 #ifndef GSR_SEG2
-#define GSR_SEG2 8
+#define GSR_SEG2 16      // segments behind the first tier: 7 of the second tier + the third tier's + the rest
 #endif
 #define GSR_SEG_MAX (GSR_SEG1 + GSR_SEG2)   // segments per tile = checkpoint slots (GSR_SEG_MAX - 1 checkpoints + the "last" slot)
 #define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
@@ -145,10 +152,19 @@ __host__ __device__ static inline int gsr_seg2_len(int /* n */, int L) { return 
 // list position of checkpoint k (k = 0 .. GSR_SEG_MAX-2) = end of segment k = start of segment k + 1
 __host__ __device__ static inline int gsr_ckpt_pos(int k, int L, int unit)
 {
-    static_assert(GSR_SEG1 == 7 && GSR_SEG2 == 8, "the table below");
-    // ends of the second tier's segments in units of L: lengths 1, 2, 3, 4, 6, 8, 12 behind position 7
+    static_assert(GSR_SEG1 == 7 && GSR_SEG2 >= 8, "the table below");
+    // ends of the second tier's segments in units of L: lengths 1, 2, 3, 4, 6, 8, 12 behind position 7; third tier: GSR_SEG3_LEN each behind 43
     return k < GSR_SEG1 ? (k + 1) * L
-         : unit * (k == 7 ? 8 : k == 8 ? 10 : k == 9 ? 13 : k == 10 ? 17 : k == 11 ? 23 : k == 12 ? 31 : 43);
+         : unit * (k == 7 ? 8 : k == 8 ? 10 : k == 9 ? 13 : k == 10 ? 17 : k == 11 ? 23 : k == 12 ? 31 : 43 + GSR_SEG3_LEN * (k - 13));
+}
+// segments a backward launch has to cover for lists of up to `longest` entries (< 0: unknown): the one that holds position longest - 1
+// and everything in front of it (the workgroups of segments no list reaches would only be dispatched to leave at once)
+static inline int gsr_segments_for(int longest, int L)
+{
+    if (longest < 0) return GSR_SEG_MAX;
+    int k = 0;
+    while (k < GSR_SEG_MAX - 1 && gsr_ckpt_pos(k, L, L) < longest) k++;
+    return k + 1;
 }
 // Segment length of a launch: small images have few tiles, so their lists are cut finer to get enough tasks for the
 // 5120 wavefront slots; large ones already have them and shorter tasks would only add fixed costs (measured both ways).
@@ -267,7 +283,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.N = N;
     {
         // The occlusion cut-off's mass tables (GSR_OCC_COPIES * T * GSR_OCC_BUCKETS words = 5 KB per tile) live only from the preprocess
-        // kernel to the cut-off kernel of the same forward; the checkpoint planes (GSR_CKPT_PLANES * 4 = 360 B per pixel = 90 KB per full tile: 206 MB at 1008x567) are first
+        // kernel to the cut-off kernel of the same forward; the checkpoint planes (GSR_CKPT_PLANES * 4 = 552 B per pixel = 138 KB per full tile: 315 MB at 1008x567) are first
         // written by the forward blend, later on the same stream: the tables ALIAS the checkpoint area (sized for the larger of the
         // two: images of a few pixels) instead of adding 11.6 MB (1008x567) / 42 MB (1920x1080) to every image workspace autograd
         // keeps alive (round 5).

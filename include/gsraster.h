@@ -108,7 +108,7 @@ typedef struct gsr_profile {
 const char* gsr_version(void);
 /* Integer version of this header's binary interface: bumped whenever an entry point's argument list, a struct layout or a
  * workspace size formula changes incompatibly.  Bindings compare it with GSR_ABI_VERSION at load time. */
-#define GSR_ABI_VERSION 7
+#define GSR_ABI_VERSION 8
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
 /* Forget what the calling thread's previous calls taught the launch heuristics that learn from feedback (ABI 7): today the partial

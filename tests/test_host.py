@@ -33,7 +33,7 @@ def test_tuning_struct_layout_and_the_inference_twin():
     import ctypes
     from gscream_amd import _native, rasterizer as RZ
     assert ctypes.sizeof(_native.Tuning) == 40 and _native.Tuning.inference.offset == 12
-    assert _native.Tuning.walk_depths_valid.offset == 28 and _native.Tuning.walk_depths.offset == 32 and _native.ABI_VERSION == 7
+    assert _native.Tuning.walk_depths_valid.offset == 28 and _native.Tuning.walk_depths.offset == 32 and _native.ABI_VERSION == 8
     RZ.set_tuning(tile_cull=False, partial_sort=False)
     try:
         assert RZ._tuning_variants[(1, 0)].inference == 1 and RZ._tuning.inference == 0 and RZ._tuning_variants[(0, 1)].occlusion_cut == 1
@@ -226,18 +226,18 @@ def test_init_state_generator_follows_create_from_pcd():
 
 def test_segment_position_helpers_mirror_the_header():
     """gscream_amd/_layout.py seg2_len / ckpt_pos = gsr_common.h gsr_seg2_len / gsr_ckpt_pos: seven segments of L, then segments of
-    1, 2, 3, 4, 6, 8, 12 x L at FIXED list positions (they must not follow the list length: the occlusion cut-off shortens lists behind
-    everything that blends, and moving boundaries would re-associate the forward's sums), then the rest.  (The GPU kernels and this
+    1, 2, 3, 4, 6, 8, 12 x L, then (round 6) segments of 16 x L, all at FIXED list positions (they must not follow the list length: the occlusion
+    cut-off shortens lists behind everything that blends, and moving boundaries would re-associate the forward's sums), then the rest.  (The GPU kernels and this
     mirror are compared through the checkpoints in test_second_tier_of_depth_segments.)"""
     from gscream_amd import _layout as LY
-    assert LY.SEG_MAX == LY.SEG1 + LY.SEG2 == 15
+    assert LY.SEG_MAX == LY.SEG1 + LY.SEG2 == 23
     for L in (64, 128):
         for n in (10, 7 * L, 7 * L + 1, 3238, 14000):
             assert LY.seg2_len(n, L) == L
         pos = [LY.ckpt_pos(k, L, L) for k in range(LY.SEG_MAX - 1)]
         assert pos[:7] == [(k + 1) * L for k in range(7)]
-        assert [b - a for a, b in zip(pos[6:-1], pos[7:])] == [m * L for m in (1, 2, 3, 4, 6, 8, 12)]
-        assert pos[-1] == 43 * L and all(p % 64 == 0 for p in pos)
+        assert [b - a for a, b in zip(pos[6:-1], pos[7:])] == [m * L for m in (1, 2, 3, 4, 6, 8, 12) + (16,) * 8]
+        assert pos[13] == 43 * L and pos[-1] == 171 * L and all(p % 64 == 0 for p in pos)
 
 
 def test_C_stub_module_imports_and_exports_the_five_entry_points():
