@@ -193,6 +193,7 @@ def parity_check(Hh, s, grads, st, ref, threads):
             "outlier_pixels": rep.get("outlier_pixels"), "grad_elems_in_walks_of_expf_tie_pixels": rep.get("grad_elems_in_walks_of_expf_tie_pixels"),
             "last_contributor_differs": rep.get("last_contributor_differs"),
             "final_T_max_rel_where_same_stop": rep.get("final_T_max_rel_where_same_stop"),
+            "final_T_in_expf_tie_walks": rep.get("final_T_in_expf_tie_walks"),
             "order_noise_envelope": rep.get("order_noise_envelope")}
 
 

@@ -258,7 +258,13 @@ def parity_report(got, st, ref=None, nthreads=1, s=None, grads=None, envelope_or
                                            "expf_tie_at_the_T_stop": int((diff & (mg["m_T"] < 1e-6)).sum())}
         ft, rt = got["final_T"].astype(np.float64), st["final_T"].astype(np.float64)
         same = ~diff & (rt > 0)
-        out["final_T_max_rel_where_same_stop"] = float((np.abs(ft[same] - rt[same]) / rt[same]).max()) if same.any() else 0.0
+        # ... measured over the pixels whose oracle walk holds no expf tie at alpha = 1/255: where one does, glibc's and ocml's expf may put
+        # that instance on opposite sides of the test somewhere IN THE MIDDLE of the walk -- T then differs by exactly that instance's
+        # (1 - 1/255) = 0.39 % although both walks end at the same Gaussian and the colours agree to 1e-4 (fuzz case 56 of seed 1000)
+        tie = mg["m_alpha"] < 1e-6
+        rel_T = np.where(same, np.abs(ft - rt) / np.where(rt > 0, rt, 1.0), 0.0)
+        out["final_T_max_rel_where_same_stop"] = float(rel_T[same & ~tie].max()) if (same & ~tie).any() else 0.0
+        out["final_T_in_expf_tie_walks"] = {"pixels": int((same & tie).sum()), "max_rel": float(rel_T[same & tie].max()) if (same & tie).any() else 0.0}
     if ref is not None:
         P = st["radii"].shape[0]
         ga = np.zeros(P, bool); gt = np.zeros(P, bool)
@@ -359,7 +365,7 @@ def assert_parity_strict(got, st, ref=None, s=None, grads=None, context="", keys
     for k in ("out_color", "out_depth", "out_unc"):
         cap = 5e-3 * max(1.0, float(np.abs(st[k]).max()) if np.asarray(st[k]).size else 1.0)
         assert rep["images"][k]["max"] <= cap, f"{context}/{k}: max abs error {rep['images'][k]['max']:.3e} (cap {cap:.1e})"
-    if "final_T_max_rel_where_same_stop" in rep and not ties:
+    if "final_T_max_rel_where_same_stop" in rep and not ties:  # (over the pixels without an expf tie in their oracle walk: parity_report)
         # the forward's exact replay finds every pixel whose stop could differ from the reference's ONLY IF the fast walk's transmittance
         # stays within GSR_TBAND (1e-4, relative) of the reference chain's (blend.hip, GSR_T_STOP); v_exp / v_rcp errors accumulate with
         # the number of blends, so the bound is checked on every case here, the walks of thousands of instances included
