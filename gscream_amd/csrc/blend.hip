@@ -438,8 +438,14 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
 
     sAcc[0][lane] = A0; sAcc[1][lane] = A1; sAcc[2][lane] = A2; sAcc[3][lane] = A3; sAcc[4][lane] = A4;  // (a lane reads only its own words)
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+    // List entries are requested TWO batches ahead, records one (round 6): entry -> record is a chain of two dependent round trips, and a
+    // wave that has its SIMD to itself -- every deep walk of a frame that does not saturate early -- waited for both at the top of every
+    // batch with few survivors (the blend loop of such a batch is shorter than one round trip): ~56 ns per list position, which is what
+    // bounds the forward of the init-state and `fitted` frames.
+    uint32_t idn = 0u;  // the NEXT batch's list entry of this lane
     {
         const int cnt0 = min(GSR_FWB - (start & (GSR_FWB - 1)), n - start);  // batches end at multiples of 64 list positions
+        if (start + cnt0 + lane < n) idn = ids[start + cnt0 + lane];
         if (lane < cnt0) {
             const float4* r = reinterpret_cast<const float4*>(rec + (ids[start + lane] & 0x7fffffffu));
             a = r[0]; b = r[1]; c = r[2];
@@ -497,12 +503,14 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             float* dst = reinterpret_cast<float*>(&sPair[nq >> 1][0]) + 1;
             dst[0] = 0.f; dst[2] = 0.f; dst[4] = 0.f; dst[6] = 0.f; dst[8] = 0.f; dst[10] = 0.f; dst[12] = 0.f; dst[14] = 0.f;
         }
-        {  // next batch's records: in flight during the blend loop
-            const int i = base + cnt + lane;  // (the next batch is a full one, or the list's tail)
+        {  // next batch's records (their list entries arrived during the previous batch) + the list entries of the batch after it:
+           // in flight during the blend loop
+            const int i = base + cnt + lane;  // (the next batch is a full one, or the list's tail; it starts at a multiple of 64)
             if (i < n) {
-                const float4* r = reinterpret_cast<const float4*>(rec + (ids[i] & 0x7fffffffu));
+                const float4* r = reinterpret_cast<const float4*>(rec + (idn & 0x7fffffffu));
                 a = r[0]; b = r[1]; c = r[2];
             }
+            if (i + GSR_FWB < n) idn = ids[i + GSR_FWB];
         }
         __syncthreads();  // single-wave workgroup: orders the LDS writes above against the reads below
 

@@ -1,7 +1,20 @@
 #!/bin/bash
+# The CURRENT GPU session's command list.  usage: gpurun -- 'bash tools/gpu_session.sh'
+# Round 6, second session: forward blend with its list entries requested two batches ahead: A/B against HEAD on every workload, then the parity suites
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/fuzz_final; mkdir -p $OUT
-FUZZ_KNOBS=1 timeout 1500 python tools/fuzz_parity.py 60 > $OUT/fuzz.txt 2>&1
-tail -n 5 $OUT/fuzz.txt | cut -c1-300; grep -c " ok" $OUT/fuzz.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prefetch_ab; mkdir -p $OUT; rm -f $OUT/ab.txt
+row() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], d.get('view_cache',{}).get('ms_per_step_without'), {k:round(v['avg_ms']*1e3,1) for k,v in d.get('stages',{}).items()})" "$1" "$2"; }
+run() { local wl=$1 name=$2; shift 2
+  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity --steps 50 --warmup 10 --workload $wl 2>>$OUT/err.log | tail -1 | row $wl $name | tee -a $OUT/ab.txt; }
+HEADENV="GSR_LIB=$PWD/gscream_amd/libgsraster_head.so"
+for wl in config2 config3 config4 surfaces init_state; do
+  run $wl head $HEADENV; run $wl prefetch A=1; run $wl head $HEADENV; run $wl prefetch A=1
+done
+for it in 25 400; do
+  run fitted head_$it $HEADENV GSR_FIT_ITERS=$it; run fitted prefetch_$it GSR_FIT_ITERS=$it
+done
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_precise.py tests/test_gpu_render.py -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -4 | tee $OUT/pytest.txt
