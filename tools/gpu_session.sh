@@ -1,20 +1,15 @@
 #!/bin/bash
-# The CURRENT GPU session's command list.  usage: gpurun -- 'bash tools/gpu_session.sh'
-# Round 6, second session: forward blend with its list entries requested two batches ahead: A/B against HEAD on every workload, then the parity suites
+# The CURRENT GPU session's command list (one file, rewritten per gpurun call; the parametrised pieces it calls --
+# tools/gpu_ab.sh, tools/snapshot.sh, tools/pmc_run.sh -- are the reusable ones).  usage: gpurun -- 'bash tools/gpu_session.sh'
+# Round 6, final library (third tier + list prefetch): the full check -- GPU tests, smoke, the driver's bench command line, the tracked
+# snapshots of every workload (PMC first, bench line, rocprofv3 kernel stats), the fitted frame at 25 iterations.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prefetch_ab; mkdir -p $OUT; rm -f $OUT/ab.txt
-row() { python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], d.get('view_cache',{}).get('ms_per_step_without'), {k:round(v['avg_ms']*1e3,1) for k,v in d.get('stages',{}).items()})" "$1" "$2"; }
-run() { local wl=$1 name=$2; shift 2
-  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity --steps 50 --warmup 10 --workload $wl 2>>$OUT/err.log | tail -1 | row $wl $name | tee -a $OUT/ab.txt; }
-HEADENV="GSR_LIB=$PWD/gscream_amd/libgsraster_head.so"
-for wl in config2 config3 config4 surfaces init_state; do
-  run $wl head $HEADENV; run $wl prefetch A=1; run $wl head $HEADENV; run $wl prefetch A=1
-done
-for it in 25 400; do
-  run fitted head_$it $HEADENV GSR_FIT_ITERS=$it; run fitted prefetch_$it GSR_FIT_ITERS=$it
-done
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_precise.py tests/test_gpu_render.py -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -4 | tee $OUT/pytest.txt
+OUT=$GRAFT_REPO_ROOT/gpurun_out/final_check; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -25 > $OUT/pytest.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench_driver_style.json
+for wl in config2 config3 config4 fitted; do bash tools/snapshot.sh r06f_$wl $wl > $OUT/snap_$wl.log 2>&1; done
+for wl in init_state surfaces; do timeout 900 python bench.py --workload $wl 2> $OUT/bench_$wl.err | tail -1 > $OUT/bench_$wl.json; done
+GSR_FIT_ITERS=25 timeout 900 python bench.py --workload fitted --no-next-rows --no-strict-parity 2> $OUT/bench_fitted25.err | tail -1 > $OUT/bench_fitted_25.json
+tail -n 3 $OUT/pytest.txt; tail -n 3 $OUT/smoke.txt
