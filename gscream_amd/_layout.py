@@ -5,14 +5,16 @@ import torch
 
 import os
 
-SEG1, SEG2 = 7, int(os.environ.get("GSR_SEG2", "16"))  # GSR_SEG1, GSR_SEG2 (gsr_common.h): three tiers of depth segments (the env knob: A/B against a library built with another -DGSR_SEG2)
+# GSR_SEG1, GSR_T2_LEN, GSR_T2_N, GSR_SEG3_LEN, GSR_SEG2 (gsr_common.h): three tiers of depth segments at fixed list positions
+# (the env knobs: A/B against a library built with other -D values)
+SEG1 = 7
+T2_LEN, T2_N = int(os.environ.get("GSR_T2_LEN", "3")), int(os.environ.get("GSR_T2_N", "6"))
+SEG3_LEN = int(os.environ.get("GSR_SEG3_LEN", "8"))
+SEG2 = int(os.environ.get("GSR_SEG2", "20"))
 SEG_MAX = SEG1 + SEG2    # GSR_SEG_MAX: segments per tile = checkpoint slots (SEG_MAX - 1 checkpoints + the "last" slot)
 CKPT_PLANES = SEG_MAX * 6
-
-
-# ends of the second tier's segments in units of L (lengths 1, 2, 3, 4, 6, 8, 12), then the third tier's (16 each; gsr_common.h)
-SEG3_LEN = int(os.environ.get("GSR_SEG3_LEN", "16"))
-SEG2_ENDS = (8, 10, 13, 17, 23, 31, 43) + tuple(43 + SEG3_LEN * j for j in range(1, 64))
+# ends of the segments behind the first tier in units of L
+SEG2_ENDS = tuple(SEG1 + T2_LEN * (j + 1) for j in range(T2_N)) + tuple(SEG1 + T2_LEN * T2_N + SEG3_LEN * (j + 1) for j in range(128))
 
 
 def seg2_len(n, L):

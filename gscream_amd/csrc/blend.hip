@@ -311,6 +311,9 @@ __device__ __forceinline__ const float2* gsr_ckpt_b(const float* ckpt, int k, si
 // waves of the launch's ~9 000 -- fewer late starters.  Same-box A/B (profiles/r06_waves_per_simd_ab.txt), forward blend us: config 2 without
 // the per-view order 104.5 -> 100.2, with it 93.5 -> 93.2; config 4 207 -> 200; init-state 277 -> 268-276; 8 waves (64 VGPRs, 40 B of
 // scratch) loses everywhere.  0 = no constraint.
+#ifndef GSR_DEEP_FLAG_AT
+#define GSR_DEEP_FLAG_AT (GSR_SEG1 + 4)  // checkpoints passed when a walk counts as deep for the backward's launch order: position gsr_ckpt_pos(10) = 19 L
+#endif
 #ifndef GSR_FWD_WAVES
 #define GSR_FWD_WAVES 7
 #endif
@@ -475,6 +478,10 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR gsr_blend_fwd_kernel(
             // entering the second tier of depth segments: counted (one fire-and-forget atomic per quadrant wave that gets there), so
             // that the backward knows whether its big tasks are the rule or the exception on this frame
             if (TRAIN && npass == GSR_SEG1 && lane == 0) atomicAdd(deep_walks, 1u);
+            // ... and a walk that passes checkpoint GSR_DEEP_FLAG_AT (list position 19 L = 1 216 with L = 64) sets the word's top bit: behind
+            // it lie the 8 L backward tasks, which must not start last whatever the count says (round 6: a frame late in an optimisation
+            // run has a few dozen deep tiles among 2 268 and kept them at the grid's tail: backward blend 133 -> 106 us)
+            if (TRAIN && npass == GSR_DEEP_FLAG_AT && lane == 0) atomicOr(deep_walks, 0x80000000u);
             sAcc[0][lane] += C0; sAcc[1][lane] += C1; sAcc[2][lane] += C2; sAcc[3][lane] += Dp; sAcc[4][lane] += Uf;
             C0 = 0.f; C1 = 0.f; C2 = 0.f; Dp = 0.f; Uf = 0.f;
         }
@@ -854,6 +861,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     __shared__ uint16_t sList[2][SL];
 
     GSR_TRACE_BEGIN
+#ifdef GSR_TRACE
+    int gsr_tr_it = 0, gsr_tr_bl = 0;
+#endif
     // Workgroup b runs on XCD b % 8 and takes the (b >> 3)-th slot of that XCD: slot i = (depth segment rank i / xcd_tiles, the
     // XCD's (i % xcd_tiles)-th tile, gsr_xcd_tile: the forward's tile -> XCD map): all tasks of one rank come first, then the next
     // rank's, ...; a tile has min(GSR_SEG_MAX, ...) segments and the workgroups of the ones it does not have leave at once.
@@ -871,7 +881,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
 #ifdef GSR_BWD_BIG_FIRST  // (A/B knob: force one order)
     const bool big_first = GSR_BWD_BIG_FIRST;
 #else
-    const bool big_first = *deep_walks * 4u >= (uint32_t)T;  // (wave-uniform scalar load)
+    const uint32_t dw = *deep_walks;  // (wave-uniform scalar load) low bits: quadrant walks that entered the second tier; top bit: one went past 19 L
+    const bool big_first = (dw >> 31) != 0u || (dw & 0x7fffffffu) * 4u >= (uint32_t)T;
 #endif
 #ifdef GSR_BWD_TIER2_ASCENDING  // (A/B knob: second-tier segments in list order instead of longest first)
     const int seg = big_first ? (rank < nbig ? GSR_SEG1 + rank : rank - nbig) : rank;
@@ -1126,7 +1137,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
                     unsigned long long okmb = __builtin_amdgcn_ballot_w64(p < lastcb) & __builtin_amdgcn_ballot_w64(power.y <= 0.0f) &
                                               __builtin_amdgcn_ballot_w64(al.y >= alpha_min);
                     GSR_COUNT_ADD(0, 1);
+#ifdef GSR_TRACE
+                    gsr_tr_it++;
+#endif
                     if ((okma | okmb) != 0ull) {  // wave-uniform: some pixel of this strip blends the instance
+#ifdef GSR_TRACE
+                        gsr_tr_bl++;
+#endif
 #ifndef GSR_PRECISE_MATH
                         unsigned long long banda = 0ull, bandb = 0ull;
                         // (a second copy of the loop body without this test for batches with no flagged instance: no gain, 161 vs 158.5 us)
@@ -1238,6 +1255,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
         __syncthreads();
     }
     GSR_TRACE_END(2)
+#ifdef GSR_TRACE  // + evaluated / blending iterations of the wave, its tile and segment (tools/wave_trace.py)
+    if ((threadIdx.x & 63) == 0)
+        gsr_trace_buf[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 4 + 3] |= ((unsigned long long)(gsr_tr_it & 0xffff) << 4) | ((unsigned long long)(gsr_tr_bl & 0xffff) << 20) |
+                                                                              ((unsigned long long)(tile & 0xffff) << 36) | ((unsigned long long)(seg & 0x3f) << 52);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -123,39 +123,49 @@ __device__ __forceinline__ void gsr_fwd_order_block(int x, int T, int xt, const 
 }
 #define GSR_SLOT_FLOATS 12
 #define GSR_SEG_LEN 128          // longest depth segment of a tile list = instances per backward task (LDS provision)
-// Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in THREE TIERS (rounds 5, 6):
-//   tier 1: GSR_SEG1 segments of the launch's segment length L (64 / 128) -- the fine cut the bench-like frames live in (their
+// Depth segments of a tile's list (= backward tasks; the forward leaves a checkpoint at every boundary), in THREE TIERS at FIXED list
+// positions (rounds 5, 6):
+//   tier 1: GSR_SEG1 = 7 segments of the launch's segment length L (64 / 128) -- the fine cut the bench-like frames live in (their
 //           pixels saturate within a few hundred instances);
-//   tier 2: GSR_SEG2 segments of GROWING length behind GSR_SEG1 * L -- 1, 2, 3, 4, 6, 8, 12 x L, then whatever is left (with L = 64:
-//           boundaries at 512, 640, 832, 1088, 1472, 1984, 2752).  Rounds 1-4 had ONE segment there: on frames whose pixels do not
-//           saturate -- the faint splats of an initialised, untrained scene walk every list to its end -- a 3000-entry list left a
-//           2500-instance task to a single workgroup that ended up alone on its SIMD (init-state frame: backward blend 1.17 ms for
-//           1.2 M instances).  The boundaries are FIXED list positions: the first version of this tier cut the tail into eight equal
-//           parts of a length chosen from the tile's list length, and the occlusion cut-off -- which only removes instances behind
-//           everything that blends -- then moved the boundaries, i.e. changed how the forward's segment sums associate: images and
-//           gradients differed in the last bit with the knob (tools/fuzz_parity.py, case 5049).
-//   tier 3 (round 6): GSR_SEG2 - 7 more segments of 16 x L each behind position 43 L (with L = 64: boundaries every 1 024 positions from
-//           2 752 to 10 944), then whatever is left.  Tier 2 ended at 43 L: a frame early in an optimisation run (gscream_amd/fit.py, the
-//           init-state model after 25 - 400 steps) has tiles walked 4 000 - 6 000 deep, and the ONE task behind position 2 752 -- up to
-//           3 300 instances on one workgroup -- was the backward blend (898 us of a 1.61 ms frame after 25 steps, 380 of 907 after 400).
+//   tier 2: GSR_T2_N = 6 segments of GSR_T2_LEN = 3 L behind position 7 L (with L = 64: boundaries at 640, 832, ..., 1 600);
+//   tier 3: segments of GSR_SEG3_LEN = 8 L behind that (2 112, 2 624, ... 8 256), then whatever is left.
+// History.  Rounds 1-4 had ONE segment behind tier 1: on frames whose pixels do not saturate -- the faint splats of an initialised,
+// untrained scene walk every list to its end -- a 3000-entry list left a 2500-instance task to a single workgroup that ended up alone on
+// its SIMD (init-state frame: backward blend 1.17 ms for 1.2 M instances).  Round 5 cut the tail into segments of 1, 2, 3, 4, 6, 8, 12 x L
+// and one rest.  Round 6 (gscream_amd/fit.py: frames of a scene early in an optimisation run, tiles walked 4 000 - 6 000 deep): the rest
+// behind 43 L -- up to 3 300 instances on one workgroup -- WAS the backward blend (900 us of a 1.61 ms frame), so the tiers went on; and
+// the per-wave trace of those frames showed the launch ending with the 8 L / 12 L / 16 L tasks of a few deep tiles in which ONE strip has
+// all the stragglers -- 770 iterations x 320 ns on a wave alone on its SIMD = 250 us whatever else the GPU does -- hence segments of at most
+// 8 L, and 3 L where most pixels are still alive (profiles/r06_segment_layout_ab.txt: backward blend of the frame after 400 optimiser steps
+// 256 -> 180 us; 2 L / 4 L / 6 L cuts: the same within noise, more checkpoint slots).
+// The boundaries are FIXED list positions: the first version of tier 2 cut the tail into equal parts of a length chosen from the tile's
+// list length, and the occlusion cut-off -- which only removes instances behind everything that blends -- then moved the boundaries,
+// i.e. changed how the forward's segment sums associate: images and gradients differed in the last bit with the knob
+// (tools/fuzz_parity.py, case 5049).
 #define GSR_SEG1 7
+#ifndef GSR_T2_LEN
+#define GSR_T2_LEN 3     // length of a second-tier segment in units of L
+#endif
+#ifndef GSR_T2_N
+#define GSR_T2_N 6       // second-tier segments
+#endif
 #ifndef GSR_SEG3_LEN
-#define GSR_SEG3_LEN 16  // length of a third-tier segment in units of L
+#define GSR_SEG3_LEN 8   // length of a third-tier segment in units of L
 #endif
 #ifndef GSR_SEG2
-#define GSR_SEG2 16      // segments behind the first tier: 7 of the second tier + the third tier's + the rest
+#define GSR_SEG2 20      // segments behind the first tier: GSR_T2_N of the second tier + 13 of the third + the rest
 #endif
 #define GSR_SEG_MAX (GSR_SEG1 + GSR_SEG2)   // segments per tile = checkpoint slots (GSR_SEG_MAX - 1 checkpoints + the "last" slot)
 #define GSR_CKPT_PLANES (GSR_SEG_MAX * 6)
-// (kept for the call sites: the unit of the second tier's boundaries is the launch's segment length, whatever the list length)
+// (kept for the call sites: the unit of the boundaries behind tier 1 is the launch's segment length, whatever the list length)
 __host__ __device__ static inline int gsr_seg2_len(int /* n */, int L) { return L; }
 // list position of checkpoint k (k = 0 .. GSR_SEG_MAX-2) = end of segment k = start of segment k + 1
 __host__ __device__ static inline int gsr_ckpt_pos(int k, int L, int unit)
 {
-    static_assert(GSR_SEG1 == 7 && GSR_SEG2 >= 8, "the table below");
-    // ends of the second tier's segments in units of L: lengths 1, 2, 3, 4, 6, 8, 12 behind position 7; third tier: GSR_SEG3_LEN each behind 43
+    static_assert(GSR_SEG2 > GSR_T2_N + 1, "tiers");
     return k < GSR_SEG1 ? (k + 1) * L
-         : unit * (k == 7 ? 8 : k == 8 ? 10 : k == 9 ? 13 : k == 10 ? 17 : k == 11 ? 23 : k == 12 ? 31 : 43 + GSR_SEG3_LEN * (k - 13));
+         : k < GSR_SEG1 + GSR_T2_N ? (GSR_SEG1 + GSR_T2_LEN * (k - GSR_SEG1 + 1)) * unit
+         : (GSR_SEG1 + GSR_T2_LEN * GSR_T2_N + GSR_SEG3_LEN * (k - GSR_SEG1 - GSR_T2_N + 1)) * unit;
 }
 // segments a backward launch has to cover for lists of up to `longest` entries (< 0: unknown): the one that holds position longest - 1
 // and everything in front of it (the workgroups of segments no list reaches would only be dispatched to leave at once)
@@ -283,7 +293,7 @@ static inline GsrImage gsr_carve_image(void* base, int P, int W, int H)
     im.N = N;
     {
         // The occlusion cut-off's mass tables (GSR_OCC_COPIES * T * GSR_OCC_BUCKETS words = 5 KB per tile) live only from the preprocess
-        // kernel to the cut-off kernel of the same forward; the checkpoint planes (GSR_CKPT_PLANES * 4 = 552 B per pixel = 138 KB per full tile: 315 MB at 1008x567) are first
+        // kernel to the cut-off kernel of the same forward; the checkpoint planes (GSR_CKPT_PLANES * 4 = 648 B per pixel = 162 KB per full tile: 370 MB at 1008x567) are first
         // written by the forward blend, later on the same stream: the tables ALIAS the checkpoint area (sized for the larger of the
         // two: images of a few pixels) instead of adding 11.6 MB (1008x567) / 42 MB (1920x1080) to every image workspace autograd
         // keeps alive (round 5).

@@ -225,19 +225,19 @@ def test_init_state_generator_follows_create_from_pcd():
 
 
 def test_segment_position_helpers_mirror_the_header():
-    """gscream_amd/_layout.py seg2_len / ckpt_pos = gsr_common.h gsr_seg2_len / gsr_ckpt_pos: seven segments of L, then segments of
-    1, 2, 3, 4, 6, 8, 12 x L, then (round 6) segments of 16 x L, all at FIXED list positions (they must not follow the list length: the occlusion
-    cut-off shortens lists behind everything that blends, and moving boundaries would re-associate the forward's sums), then the rest.  (The GPU kernels and this
-    mirror are compared through the checkpoints in test_second_tier_of_depth_segments.)"""
+    """gscream_amd/_layout.py seg2_len / ckpt_pos = gsr_common.h gsr_seg2_len / gsr_ckpt_pos: seven segments of L, six of 3 L, then
+    segments of 8 L (round 6), all at FIXED list positions (they must not follow the list length: the occlusion cut-off shortens lists
+    behind everything that blends, and moving boundaries would re-associate the forward's sums), then the rest.  (The GPU kernels and
+    this mirror are compared through the checkpoints in test_second_tier_of_depth_segments.)"""
     from gscream_amd import _layout as LY
-    assert LY.SEG_MAX == LY.SEG1 + LY.SEG2 == 23
+    assert LY.SEG_MAX == LY.SEG1 + LY.SEG2 == 27
     for L in (64, 128):
         for n in (10, 7 * L, 7 * L + 1, 3238, 14000):
             assert LY.seg2_len(n, L) == L
         pos = [LY.ckpt_pos(k, L, L) for k in range(LY.SEG_MAX - 1)]
         assert pos[:7] == [(k + 1) * L for k in range(7)]
-        assert [b - a for a, b in zip(pos[6:-1], pos[7:])] == [m * L for m in (1, 2, 3, 4, 6, 8, 12) + (16,) * 8]
-        assert pos[13] == 43 * L and pos[-1] == 171 * L and all(p % 64 == 0 for p in pos)
+        assert [b - a for a, b in zip(pos[6:-1], pos[7:])] == [m * L for m in (3,) * 6 + (8,) * 13]
+        assert pos[12] == 25 * L and pos[-1] == 129 * L and all(p % 64 == 0 for p in pos)
 
 
 def test_C_stub_module_imports_and_exports_the_five_entry_points():

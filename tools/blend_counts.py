@@ -17,7 +17,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "config2"
 P, W, H, seed, gsel, desc = B.WORKLOADS[wl]
 dev = torch.device("cuda", 0)
 lib = _native.load()
-sb = B.SceneBench(dev, P, W, H, seed, seed, gsel)
+sb = B.SceneBench(dev, P, W, H, seed, seed, gsel, wl)
 for _ in range(3):
     sb.step()
 torch.cuda.synchronize()

@@ -63,6 +63,7 @@ cu = (hw >> 8) & 15
 sh = (hw >> 12) & 1
 se = (hw >> 13) & 7
 x = xcc & 15
+tr_it, tr_bl, tr_tile, tr_seg = (xcc >> 4) & 0xffff, (xcc >> 20) & 0xffff, (xcc >> 36) & 0xffff, (xcc >> 52) & 0x3f  # (backward, trace build: iterations evaluated / blending, tile, segment)
 slot = x * 10000 + se * 1000 + sh * 100 + cu
 print("distinct XCC", len(set(x.tolist())), "distinct (xcc,se,sh,cu)", len(set(slot.tolist())))
 print("waves per SIMD id", sorted(collections.Counter(simd.tolist()).items()))
@@ -93,9 +94,11 @@ if which == "bwd":
     xt = _layout.xcd_tiles(T)
     rank = (blk >> 3) // xt
     order = np.argsort(-en)
-    print("the 30 waves that end last: start, end, life, segment rank, XCD")
+    print("the 30 waves that end last: start, end, life, segment rank, XCD | iterations evaluated, blending, tile, segment, ns per evaluated iteration")
     for i in order[:30]:
-        print("   %6.1f %6.1f %6.1f %3d %d" % (st[i], en[i], life[i], rank[i], blk[i] & 7))
+        print("   %6.1f %6.1f %6.1f %3d %d | %5d %5d %5d %3d %7.0f" % (st[i], en[i], life[i], rank[i], blk[i] & 7, tr_it[i], tr_bl[i], tr_tile[i], tr_seg[i], 1e3 * life[i] / max(int(tr_it[i]), 1)))
+    if tr_it.sum():
+        print("all waves: iterations evaluated %d, blending %d; ns of wave life per evaluated iteration: pct(5,50,95) %s" % (int(tr_it.sum()), int(tr_bl.sum()), np.round(np.percentile(1e3 * life[tr_it > 0] / tr_it[tr_it > 0], [5, 50, 95]), 0)))
     for r in range(int(rank.max()) + 1):
         sel = rank == r
         if sel.sum():
