@@ -898,7 +898,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SL == 
     const int nproc = min((int)(rg.y - rg.x), (int)tile_work[tile]);
     const int seg2_len = gsr_seg2_len((int)(rg.y - rg.x), seg_len);  // unit of the second tier's (fixed) boundaries, as in the forward
     const int seg_lo = seg == 0 ? 0 : gsr_ckpt_pos(seg - 1, seg_len, seg2_len);
-    const int seg_hi = seg == GSR_SEG_MAX - 1 ? nproc : min(nproc, gsr_ckpt_pos(seg, seg_len, seg2_len));
+    // (the grid's last segment takes everything that is left: with the forward's own longest list as the grid's measure that is what its end
+    // is anyway; with a SMALLER figure from the caller the lists beyond it are still traversed completely, just by one longer task)
+    const int seg_hi = seg == nseg - 1 ? nproc : min(nproc, gsr_ckpt_pos(seg, seg_len, seg2_len));
     if (seg_hi <= seg_lo) return;
 #if defined(GSR_BWD_DIAG) && GSR_BWD_DIAG == 1  // diagnostic: dispatch + task lookup only
     return;

@@ -1007,3 +1007,30 @@ def test_view_cache_orders_the_forward_and_changes_nothing():
                     assert np.array_equal(base[k], other[k]), f"{what}: {k} differs from the forward without the view cache"
     finally:
         RZ.set_tuning()
+
+
+def test_backward_with_a_too_small_longest_list_hint_still_traverses_everything():
+    """gsr_backward's `max_tile_count` sizes the grid of depth-segment tasks (round 6: as many segment ranks as the longest list has).
+    A binding that passes a figure SMALLER than the forward's must not lose gradients: the grid's last segment takes whatever is left of a
+    list (one longer task; the pixels start it from their final state like the reference, backward.cu:500-520)."""
+    from gscream_amd import GaussianRasterizer
+    s = S.scene_config1(seed=91, P=6000, W=64, H=48, lateral=0.35)
+    s["opacities"] = (s["opacities"] * 0.02 + 0.004).astype(np.float32)
+    s["scales"] = (s["scales"] * 2.0).astype(np.float32)
+    grads = S.upstream_grads(91, s["W"], s["H"])
+    ref = Hh.hip_run(s, grads)
+    t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a)).cuda().requires_grad_(rg)
+    leaves = {k: t(s[k], True) for k in ("means3D", "opacities", "uncertainties", "colors", "scales", "rotations")}
+    m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, depth, unc, _radii = GaussianRasterizer(raster_settings=Hh.hip_settings(s))(
+        means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], uncertainties=leaves["uncertainties"],
+        colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+    assert int(color.grad_fn.max_tile_count) > 7 * 64 + 8 * 64
+    color.grad_fn.max_tile_count = 100  # a stale / wrong hint: far below the longest list
+    gc, gd, gu = (torch.from_numpy(g).cuda() for g in grads)
+    ((color * gc).sum() + (depth * gd).sum() + (unc * gu).sum()).backward()
+    for name, key in (("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("colors", "dL_dcolors"), ("scales", "dL_dscales"), ("rotations", "dL_drotations")):
+        g = leaves[name].grad.cpu().numpy()
+        scale = np.abs(ref[key]).max()
+        assert np.abs(g - ref[key]).max() <= 2e-4 * scale, (name, float(np.abs(g - ref[key]).max()), float(scale))
+        assert np.abs(g).max() > 0
