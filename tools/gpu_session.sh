@@ -1,14 +1,8 @@
 #!/bin/bash
-# Round 6: the rotation block (64 shuffled views): final library vs the first session's (40601fb) on one box -- why is the cached variant's
-# wall time above its kernel sum now?
+# Round 6, final library: second randomised sweep again (120 cases, seed 2000, every knob) with the T-stop tie classified; the parity suites
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/rotation_ab; mkdir -p $OUT
-show() { python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); r=d['rotation']
-print(sys.argv[1], d['ms_per_step'], '| rot with', r['ms_per_step'], round(sum(r['stage_us'].values()),1), '| without', r['ms_per_step_no_view_cache'], round(sum(r['stage_us_no_view_cache'].values()),1), '| static', r['ms_per_step_static_gaussians'], round(sum(r['stage_us_static_gaussians'].values()),1))" "$1"; }
-for k in 1 2; do
-timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity 2>>$OUT/err.log | tail -1 | show final
-GSR_LIB=$PWD/gscream_amd/libgsraster_s1.so GSR_SKIP_ABI_CHECK=1 GSR_SEG2=8 GSR_T2_LEN=1 GSR_T2_N=0 GSR_SEG3_LEN=1 timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity 2>>$OUT/err.log | tail -1 | show session1
-done
+OUT=$GRAFT_REPO_ROOT/gpurun_out/fuzz120; mkdir -p $OUT
+FUZZ_KNOBS=1 timeout 2400 python tools/fuzz_parity.py 120 2000 > $OUT/fuzz.txt 2>&1
+tail -n 4 $OUT/fuzz.txt | cut -c1-300; grep -c " ok" $OUT/fuzz.txt; grep "classified" $OUT/fuzz.txt | head -5 | cut -c1-300
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -3
