@@ -26,7 +26,7 @@ from . import standin_model as SM
 from . import synthetic as S
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
-__all__ = ["teacher_scene", "orbit_cameras", "render_teacher", "adam_groups", "fit", "scene_fitted"]
+__all__ = ["teacher_scene", "orbit_cameras", "render_teacher", "adam_groups", "expon_lr", "update_learning_rate", "fit", "scene_fitted"]
 
 
 class _Pipe:
@@ -101,7 +101,8 @@ def render_teacher(ts, cams, device="cuda"):
 
 def adam_groups(model, spatial_lr_scale=1.0):
     """The reference's parameter groups and learning rates (scene/gaussian_model.py:376-390, arguments/__init__.py:96-133; the
-    schedules' initial values -- a few hundred steps do not move them).  The anchors' rate is 0 there, so they are left out."""
+    schedules' initial values; fit() applies the reference's per-iteration schedule, update_learning_rate below).  The anchors' rate is 0
+    there, so they are left out."""
     return [{"params": [model._offset], "lr": 0.01 * spatial_lr_scale, "name": "offset"},
             {"params": [model._anchor_feat], "lr": 0.0075, "name": "anchor_feat"},
             {"params": [model._scaling], "lr": 0.007, "name": "scaling"},
@@ -109,6 +110,30 @@ def adam_groups(model, spatial_lr_scale=1.0):
             {"params": model.mlp_uncertainty.parameters(), "lr": 0.002, "name": "mlp_uncertainty"},
             {"params": model.mlp_cov.parameters(), "lr": 0.004, "name": "mlp_cov"},
             {"params": model.mlp_color.parameters(), "lr": 0.008, "name": "mlp_color"}]
+
+
+# (init, final, max_steps) of the groups update_learning_rate() reschedules every iteration (scene/gaussian_model.py:412-439, 460-483;
+# arguments/__init__.py:101-133; lr_delay_steps is 0 there, so the delay factor is 1)
+LR_SCHEDULES = {"offset": (0.01, 0.0001, 30_000), "mlp_opacity": (0.002, 0.00002, 30_000), "mlp_uncertainty": (0.002, 0.00002, 30_000),
+                "mlp_cov": (0.004, 0.004, 30_000), "mlp_color": (0.008, 0.00005, 30_000)}
+
+
+def expon_lr(step, lr_init, lr_final, max_steps):
+    """utils/general_utils.py:104-136 get_expon_lr_func without a delay: log-linear interpolation from lr_init (step 0) to lr_final
+    (step >= max_steps)."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1.0 - t) + math.log(lr_final) * t)
+
+
+def update_learning_rate(opt, iteration, spatial_lr_scale=1.0):
+    """GaussianModel.update_learning_rate (scene/gaussian_model.py:460-483) for the groups of adam_groups()."""
+    for g in opt.param_groups:
+        sch = LR_SCHEDULES.get(g.get("name"))
+        if sch is not None:
+            scale = spatial_lr_scale if g["name"] == "offset" else 1.0
+            g["lr"] = expon_lr(iteration, sch[0] * scale, sch[1] * scale, sch[2])
 
 
 def psnr(a, b):
@@ -145,6 +170,7 @@ def fit(model, cams, gts, gdepths, iters, seed=0, lambda_dssim=0.2, depth_weight
     t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
     for it in range(iters):
+        update_learning_rate(opt, it + 1)  # train.py:408 (iterations count from 1)
         if not stack:
             stack = list(rng.permutation(len(cams)))   # train.py:414-416
         v = int(stack.pop())

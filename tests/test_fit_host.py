@@ -49,3 +49,28 @@ def test_fit_defaults_are_the_references():
     assert inspect.signature(SM.Model.__init__).parameters["feat_dim"].default == ref["ModelParams"]["feat_dim"]
     assert inspect.signature(SM.voxelize).parameters["voxel_size"].default == ref["ModelParams"]["voxel_size"]
     assert ref["ModelParams"]["use_feat_bank"] is False
+
+
+def test_learning_rate_schedule_is_the_references():
+    """fit.expon_lr / LR_SCHEDULES against the reference's get_expon_lr_func configured as training_setup configures it
+    (scene/gaussian_model.py:412-439), evaluated by the reference itself at a few iterations (ref_optim.json)."""
+    from gscream_amd import fit as F
+    ref = _ref()
+    op = ref["OptimizationParams"]
+    assert set(F.LR_SCHEDULES) == set(ref["schedules"])
+    for name, (init, final, steps) in F.LR_SCHEDULES.items():
+        assert (init, final, steps) == (op[name + "_lr_init"], op[name + "_lr_final"], op[name + "_lr_max_steps"]), name
+        assert op[name + "_lr_delay_mult"] == 0.01  # (no effect: lr_delay_steps stays at its default 0)
+        for st, want in zip(ref["schedule_steps"], ref["schedules"][name]):
+            got = F.expon_lr(st, init, final, steps)
+            assert abs(got - want) <= 1e-12 * max(abs(want), 1e-30) + 1e-18, (name, st, got, want)
+    # the optimiser's groups follow it
+    from gscream_amd import standin_model as SM
+    m = SM.Model(8, 10, seed=0, dtype=torch.float32)
+    opt = torch.optim.Adam(F.adam_groups(m), lr=0.0, eps=1e-15)
+    F.update_learning_rate(opt, 1600)
+    lrs = {g["name"]: g["lr"] for g in opt.param_groups}
+    i = ref["schedule_steps"].index(1600)
+    for name in F.LR_SCHEDULES:
+        assert abs(lrs[name] - ref["schedules"][name][i]) < 1e-15
+    assert lrs["anchor_feat"] == op["feature_lr"] and lrs["scaling"] == op["scaling_lr"]
