@@ -1,14 +1,17 @@
 #!/bin/bash
-# The CURRENT GPU session's command list (one file, rewritten per gpurun call; the parametrised pieces it calls --
-# tools/gpu_ab.sh, tools/snapshot.sh, tools/pmc_run.sh -- are the reusable ones).  usage: gpurun -- 'bash tools/gpu_session.sh'
-# Round 6, final library: snapshots (PMC, bench line, rocprofv3 kernel stats) of the two remaining probe workloads, init_state and surfaces
+# The CURRENT GPU session's command list.  usage: gpurun -- 'bash tools/gpu_session.sh'
+# Round 6: the first tier's last 3 / 4 segments cut in two (backward tasks of 32 instances at the end of the grid: a shorter drain?) -- A/B
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/final_check5; mkdir -p $OUT
-for wl in init_state surfaces; do bash tools/snapshot.sh r06j_$wl $wl > $OUT/snap_$wl.log 2>&1; done
-python - <<'PY'
-import json
-for wl in ("init_state","surfaces"):
-    s=json.load(open(f"gpurun_out/snap_r06j_{wl}/bench.json")); pc=s.get("parity_check") or {}
-    print(wl, s["value"], s["ms_per_step"], s.get("ms_per_step_spread",{}).get("blocks_ms"), s["roofline"]["frac"], pc.get("px_gt_1e-4"), pc.get("grad_elems_gt_1e-3"))
-PY
+OUT=$GRAFT_REPO_ROOT/gpurun_out/t1_half; mkdir -p $OUT; rm -f $OUT/ab.txt
+row() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], {k:round(v['avg_ms']*1e3,1) for k,v in d.get('stages',{}).items()})" "$1" "$2"; }
+run() { local wl=$1 name=$2; shift 2
+  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity --steps 50 --warmup 10 --workload $wl 2>>$OUT/err.log | tail -1 | row $wl $name | tee -a $OUT/ab.txt; }
+H3="GSR_LIB=$PWD/gscream_amd/libgsraster_h3.so GSR_SKIP_ABI_CHECK=1 GSR_T1_HALF=3"
+H4="GSR_LIB=$PWD/gscream_amd/libgsraster_h4.so GSR_SKIP_ABI_CHECK=1 GSR_T1_HALF=4"
+for wl in config2 config3 surfaces config4 init_state; do
+  run $wl shipped A=1; run $wl half3 $H3; run $wl half4 $H4; run $wl shipped A=1; run $wl half3 $H3
+done
