@@ -1,17 +1,16 @@
 #!/bin/bash
-# The CURRENT GPU session's command list.  usage: gpurun -- 'bash tools/gpu_session.sh'
-# Round 6: the first tier's last 3 / 4 segments cut in two (backward tasks of 32 instances at the end of the grid: a shorter drain?) -- A/B
+# The CURRENT GPU session's command list (one file, rewritten per gpurun call; the parametrised pieces it calls --
+# tools/gpu_ab.sh, tools/snapshot.sh, tools/pmc_run.sh -- are the reusable ones).  usage: gpurun -- 'bash tools/gpu_session.sh'
+# Round 6, as left at the end of the round: the full check -- GPU tests, smoke, the driver's bench command line, the tracked snapshots of
+# every workload (PMC first, bench line, rocprofv3 kernel stats), the fitted frame along the optimisation run, both fuzz sweeps.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/t1_half; mkdir -p $OUT; rm -f $OUT/ab.txt
-row() { python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], {k:round(v['avg_ms']*1e3,1) for k,v in d.get('stages',{}).items()})" "$1" "$2"; }
-run() { local wl=$1 name=$2; shift 2
-  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-next-rows --no-strict-parity --steps 50 --warmup 10 --workload $wl 2>>$OUT/err.log | tail -1 | row $wl $name | tee -a $OUT/ab.txt; }
-H3="GSR_LIB=$PWD/gscream_amd/libgsraster_h3.so GSR_SKIP_ABI_CHECK=1 GSR_T1_HALF=3"
-H4="GSR_LIB=$PWD/gscream_amd/libgsraster_h4.so GSR_SKIP_ABI_CHECK=1 GSR_T1_HALF=4"
-for wl in config2 config3 surfaces config4 init_state; do
-  run $wl shipped A=1; run $wl half3 $H3; run $wl half4 $H4; run $wl shipped A=1; run $wl half3 $H3
-done
+OUT=$GRAFT_REPO_ROOT/gpurun_out/full_check; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[Gloo\]" | tail -25 > $OUT/pytest.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench_driver_style.json
+for wl in config2 config3 config4 fitted init_state surfaces; do bash tools/snapshot.sh r06_$wl $wl > $OUT/snap_$wl.log 2>&1; done
+for it in 25 100 1600; do GSR_FIT_ITERS=$it timeout 900 python bench.py --workload fitted --no-next-rows --no-strict-parity --cpu-budget 6 2> $OUT/bench_fitted$it.err | tail -1 > $OUT/bench_fitted_$it.json; done
+FUZZ_KNOBS=1 timeout 1500 python tools/fuzz_parity.py 60 > $OUT/fuzz_60_seed1000.txt 2>&1
+FUZZ_KNOBS=1 timeout 2400 python tools/fuzz_parity.py 120 2000 > $OUT/fuzz_120_seed2000.txt 2>&1
+tail -n 3 $OUT/pytest.txt; tail -n 3 $OUT/smoke.txt; tail -n 2 $OUT/fuzz_60_seed1000.txt $OUT/fuzz_120_seed2000.txt
