@@ -1233,6 +1233,8 @@ def main():
     def apply_tuning(view_cache=True, **over):
         kw = dict(tile_cull=not args.no_tile_cull, scatter_bands=args.scatter_bands, occlusion_cut=None if args.occlusion < 0 else bool(args.occlusion),
                   view_cache=view_cache and not args.no_view_cache)
+        if os.environ.get("GSR_BENCH_HEAVY_GROUPS"):  # (diagnostic: force the per-Gaussian backward's cooperative kernel on / off: 1 / 0)
+            kw["heavy_groups"] = os.environ["GSR_BENCH_HEAVY_GROUPS"] == "1"
         kw.update(over)
         set_tuning(**kw)
     apply_tuning()
