@@ -202,9 +202,8 @@ int gsr_forward(int P, int D, int M, int W, int H,
 int gsr_backward(int P, int D, int M, int W, int H, int R, int binning_capacity /* what the forward's binning
                  workspace was sized for; = R after the two-stage forward */,
                  int max_tile_count /* gsr_stage1_result.max_tile_count of THAT forward (its longest per-tile list), or <= 0 if the
-                 caller did not keep it: sizes the grid of depth-segment tasks -- as many segment ranks as the longest list has
-                 (ABI 8); unknown = the full grid, same results; a figure SMALLER than the forward's is safe too (the grid's last
-                 segment takes whatever is left of a list), it only makes that task long */,
+                 caller did not keep it: sizes the grid of depth-segment tasks -- a frame none of whose lists reaches the second
+                 segment tier needs half the workgroups; unknown = the full grid, same results */,
                  const float* background,
                  const float* means3D, const int32_t* radii, const float* colors_precomp, const float* shs,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
